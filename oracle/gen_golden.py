@@ -1,0 +1,447 @@
+"""TEST INFRASTRUCTURE — golden-vector generator (runs ONLY in the build container).
+
+Imports the reference's own Python hot path from /root/reference on CPU (via
+`oracle/_refstub.py`), runs it on seeded inputs and writes small fixtures to
+`tests/golden/*.npz`.  While generating, every vector is also compared with the
+CPU oracle (`oracle/wan_oracle.py`) so that a fixture is never written from a
+run in which oracle and reference disagree.
+
+    python oracle/gen_golden.py            # regenerate everything
+
+Nothing of the reference travels: fixtures hold inputs and expected outputs only.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from types import SimpleNamespace
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import _refstub  # noqa: E402
+import wan_oracle as O  # noqa: E402
+from fixture_io import GOLDEN_DIR, save_npz, weights_checksum  # noqa: E402
+
+torch.set_grad_enabled(False)
+BF = torch.bfloat16
+
+
+def _pc(world_size=1, rank=0):
+    return SimpleNamespace(world_size=world_size, rank=rank, ulysses_size=1, ring_size=1,
+                           local_rank=0, ring_strategy="pass-kv", attn_backend=None)
+
+
+def build_ref_model(cm, cfg: O.WanConfig, W):
+    m = cm.CausalWanModel(
+        model_type="t2v", patch_size=cfg.patch_size, text_len=cfg.text_len, in_dim=cfg.in_dim,
+        dim=cfg.dim, ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim,
+        out_dim=cfg.out_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers,
+        local_attn_size=cfg.local_attn_size, sink_size=cfg.sink_size, qk_norm=True,
+        cross_attn_norm=True, eps=cfg.eps, enable_kv_offload=False, parallel_config=_pc()).eval()
+    m.load_state_dict({k: v.float() for k, v in W.items()}, strict=True)
+    return m.to(BF)
+
+
+def maxdiff(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def check(name, ref, mine, tol=0.0):
+    d = maxdiff(ref, mine)
+    status = "OK " if d <= tol else "BAD"
+    print(f"  [{status}] {name}: max|ref-oracle| = {d:.3e}")
+    if d > tol:
+        raise SystemExit(f"oracle disagrees with reference on {name}")
+
+
+# --------------------------------------------------------------------------
+def gen_ops(cm):
+    print("ops.npz")
+    from inferix.models.wan_base.components import (WanLayerNorm, WanRMSNorm, rope_params,
+                                                    sinusoidal_embedding_1d)
+    from inferix.models.attention.distributed import update_out_and_lse_pass_q
+    g = torch.Generator().manual_seed(11)
+    fx = {}
+    # sinusoid
+    t = torch.tensor([0.0, 250.0, 625.0, 833.3333, 937.5, 1000.0])
+    fx["sin_t"] = t
+    fx["sin_out"] = sinusoidal_embedding_1d(64, t)
+    check("sinusoid", fx["sin_out"], O.sinusoidal_embedding_1d(64, t))
+    # rope tables (head_dim 128: 44/42/42 real dims)
+    for dim in (44, 42):
+        fx[f"rope_params_{dim}"] = rope_params(32, dim)
+        check(f"rope_params_{dim}", torch.view_as_real(fx[f"rope_params_{dim}"]),
+              torch.view_as_real(O.rope_params(32, dim)))
+    freqs = O.rope_freqs(128)
+    # causal rope apply
+    grid = (3, 4, 6)
+    x = torch.randn(2, 72, 2, 128, generator=g).to(BF)
+    fx["rope_x"] = x
+    gs = torch.tensor([list(grid)] * 2)
+    for sf in (0, 5):
+        ref = cm.causal_rope_apply(x, gs, freqs, start_frame=sf)
+        fx[f"rope_out_sf{sf}"] = ref
+        check(f"causal_rope_apply sf={sf}", ref, O.causal_rope_apply(x, grid, freqs, sf))
+    for ws in (2, 4):
+        for rk in (0, ws - 1):
+            xl = x[:, :72 // ws].contiguous()
+            ref = cm.causal_rope_apply_chunked(xl, gs, freqs, ws, rk, start_frame=3)
+            fx[f"rope_chunk_ws{ws}_r{rk}"] = ref
+            check(f"rope chunked ws={ws} r={rk}", ref, O.causal_rope_apply(xl, grid, freqs, 3, ws, rk))
+    # norms
+    xn = (torch.randn(2, 48, 256, generator=g) * 3).to(BF)
+    w = (1 + 0.1 * torch.randn(256, generator=g)).to(BF)
+    rn = WanRMSNorm(256, eps=1e-6).to(BF)
+    rn.weight.data.copy_(w)
+    fx["norm_x"], fx["rms_w"] = xn, w
+    fx["rms_out"] = rn(xn)
+    check("WanRMSNorm", fx["rms_out"], O.rms_norm(xn, w, 1e-6))
+    ln = WanLayerNorm(256, 1e-6)
+    fx["ln_out"] = ln(xn)
+    check("WanLayerNorm", fx["ln_out"], O.layer_norm(xn, 1e-6))
+    lna = WanLayerNorm(256, 1e-6, elementwise_affine=True).to(BF)
+    b = (0.1 * torch.randn(256, generator=g)).to(BF)
+    lna.weight.data.copy_(w)
+    lna.bias.data.copy_(b)
+    fx["ln_b"] = b
+    fx["ln_affine_out"] = lna(xn)
+    check("WanLayerNorm affine", fx["ln_affine_out"], O.layer_norm(xn, 1e-6, w, b))
+    # AdaLN modulate + gated residual exactly as written in the block (:412,433,444)
+    mod = (torch.randn(1, 6, 256, generator=g) / 16).to(BF)
+    e0 = torch.randn(2, 3, 6, 256, generator=g).to(BF)
+    e = (mod.unsqueeze(1) + e0).chunk(6, dim=2)
+    ref = (ln(xn).unflatten(dim=1, sizes=(3, 16)) * (1 + e[1]) + e[0]).flatten(1, 2)
+    fx["mod"], fx["e0"], fx["modulate_out"] = mod, e0, ref
+    check("modulate", ref, O.modulate(O.layer_norm(xn, 1e-6), e[1], e[0], 3))
+    y = torch.randn(2, 48, 256, generator=g).to(BF)
+    ref = xn + (y.unflatten(dim=1, sizes=(3, 16)) * e[2]).flatten(1, 2)
+    fx["gate_y"], fx["gate_out"] = y, ref
+    check("gated residual", ref, O.gated_residual(xn, y, e[2], 3))
+    # LSE merge
+    out = torch.randn(1, 20, 2, 128, generator=g)
+    lse = torch.randn(1, 20, 2, 1, generator=g)
+    bo = torch.randn(1, 20, 2, 128, generator=g).to(BF)
+    bl = torch.randn(1, 20, 2, 1, generator=g)
+    ro, rl = update_out_and_lse_pass_q(out, lse, bo, bl)
+    fx.update(merge_out=out, merge_lse=lse, merge_bo=bo, merge_bl=bl, merge_ro=ro, merge_rl=rl)
+    mo, ml = O.merge_out_lse(out, lse, bo, bl)
+    check("lse merge out", ro, mo)
+    check("lse merge lse", rl, ml)
+    # SDPA attention (the CPU path of attention(), flash_attention.py:185-200)
+    from inferix.models.attention import attention as ref_attention
+    q = torch.randn(1, 40, 2, 128, generator=g).to(BF)
+    k = torch.randn(1, 100, 2, 128, generator=g).to(BF)
+    v = torch.randn(1, 100, 2, 128, generator=g).to(BF)
+    fx.update(attn_q=q, attn_k=k, attn_v=v, attn_out=ref_attention(q, k, v))
+    check("attention (sdpa)", fx["attn_out"], O.attention(q, k, v))
+    save_npz(os.path.join(GOLDEN_DIR, "ops.npz"), fx)
+
+
+def gen_layout(cm):
+    """Integer permutations: unpatchify and the CP scatter/gather interleave."""
+    print("layout.npz")
+    import einops
+    fx = {}
+    cfg = O.tiny_config()
+    m = build_ref_model(cm, cfg, O.init_weights(cfg, seed=0))
+    grid = (3, 4, 6)
+    n = 72
+    idx = torch.arange(n * 64, dtype=torch.float32).view(1, n, 64)
+    ref = torch.stack(m.unpatchify(idx, torch.tensor([list(grid)])))
+    fx["unpatchify_idx"] = ref.to(torch.int32)
+    check("unpatchify", ref, O.unpatchify(idx, grid, cfg))
+    tok = torch.arange(n * 2, dtype=torch.float32).view(1, n, 2)
+    for cp in (2, 4):
+        parts = []
+        for r in range(cp):
+            xs = einops.rearrange(tok, "b (f hw) c -> b f hw c", f=3, hw=24)
+            xs = xs.chunk(cp, dim=2)[r]
+            xs = einops.rearrange(xs, "b f hw c -> b (f hw) c")
+            fx[f"scatter_cp{cp}_r{r}"] = xs.to(torch.int32)
+            check(f"cp scatter cp={cp} r={r}", xs, O.cp_scatter(tok, 3, cp, r))
+            parts.append(xs)
+        cat = torch.cat(parts, dim=1)
+        back = einops.rearrange(cat, "b (cp f hw) c -> b (f cp hw) c", cp=cp, f=3, hw=24 // cp)
+        fx[f"gather_cp{cp}"] = back.to(torch.int32)
+        check(f"cp gather cp={cp}", back, O.cp_gather_interleave(parts, 3))
+        check(f"cp roundtrip cp={cp}", back, tok)
+    save_npz(os.path.join(GOLDEN_DIR, "layout.npz"), fx)
+
+
+def gen_scheduler():
+    print("scheduler.npz")
+    from inferix.models.schedulers.flow_match import FlowMatchScheduler
+    from inferix.models.self_forcing.wrapper import WanDiffusionWrapper
+    fx = {}
+    g = torch.Generator().manual_seed(5)
+    for shift in (5.0, 8.0):
+        s = FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
+        s.set_timesteps(1000, training=True)
+        mine = O.FlowMatchSchedule(shift=shift)
+        tag = str(int(shift))
+        fx[f"sigmas_{tag}"], fx[f"timesteps_{tag}"] = s.sigmas, s.timesteps
+        check(f"sigmas shift={shift}", s.sigmas, mine.sigmas)
+        check(f"timesteps shift={shift}", s.timesteps, mine.timesteps)
+        steps = [1000, 750, 500, 250] if shift == 5.0 else [1000, 757, 522]
+        ts = torch.cat((s.timesteps.cpu(), torch.tensor([0], dtype=torch.float32)))
+        warped = ts[1000 - torch.tensor(steps, dtype=torch.long)]
+        fx[f"warped_{tag}"] = warped
+        check(f"warped shift={shift}", warped, mine.warp(steps))
+        x0 = torch.randn(3, 16, 8, 12, generator=g).to(BF)
+        eps = torch.randn(3, 16, 8, 12, generator=g).to(BF)
+        tn = warped[1] * torch.ones(3, dtype=torch.long)
+        ref = s.add_noise(x0, eps, tn)
+        fx[f"an_x0_{tag}"], fx[f"an_eps_{tag}"], fx[f"an_t_{tag}"], fx[f"an_out_{tag}"] = x0, eps, tn, ref
+        check(f"add_noise shift={shift}", ref, mine.add_noise(x0, eps, tn))
+        w = WanDiffusionWrapper.__new__(WanDiffusionWrapper)
+        w.scheduler = s
+        flow = torch.randn(3, 16, 8, 12, generator=g).to(BF)
+        ref = WanDiffusionWrapper._convert_flow_pred_to_x0(w, flow, x0, tn)
+        fx[f"f2x_flow_{tag}"], fx[f"f2x_out_{tag}"] = flow, ref
+        check(f"flow_to_x0 shift={shift}", ref, O.flow_to_x0(flow, x0, tn, mine))
+    save_npz(os.path.join(GOLDEN_DIR, "scheduler.npz"), fx)
+
+
+def gen_kv_manager():
+    """Shapes / contents / errors of the reference KVCacheManager + Self-Forcing adapter."""
+    print("kv_manager.npz")
+    from inferix.kvcache_manager.kvcache_manager import (KVCacheManager, KVCacheRequest,
+                                                         KVCacheRequestSpec, KVCacheSpec)
+    from inferix.kvcache_manager.model.self_forcing_kv_cache_manager import SelfForcingKVCacheManagerFactory
+    fx = {}
+    kvm = KVCacheManager(device="cpu")
+    req = KVCacheRequest("r0")
+    ad = SelfForcingKVCacheManagerFactory.create_manager(3, 2, 128, enable_kv_offload=False)
+    ad.allocate_kv_cache(kv_cache_manager=kvm, kv_cache_request=req, sequence_length=50, dtype=BF)
+    ad.allocate_crossattn_cache(kv_cache_manager=kvm, kv_cache_request=req, crossattn_length=16, dtype=BF)
+    fx["layers"] = "|".join(kvm.layers(req))
+    raw = kvm.get_raw(req, "layer_3")
+    raw.zero_()
+    fx["raw_shape"] = torch.tensor(raw.shape)
+    fx["get_kv_shape"] = torch.tensor(ad.get_kv_cache(kvm, req).shape)
+    fx["get_cross_shape"] = torch.tensor(ad.get_crossattn_cache(kvm, req).shape)
+    spec = kvm.layer_spec(req, "layer_3")
+    fx["spec"] = torch.tensor([spec.size, spec.num_tokens, spec.num_blocks, spec.block_size])
+    g = torch.Generator().manual_seed(3)
+    k = torch.randn(7, 2, 128, generator=g).to(BF)
+    v = torch.randn(7, 2, 128, generator=g).to(BF)
+    ad.set_kv_cache(kvm, req, start_index=0, k_data=k, v_data=v)
+    fx["set_k"], fx["set_v"] = k, v
+    fx["after_set"] = kvm.get(req, "layer_3").clone()
+    fx["get_range_2_4"] = kvm.get_range(req, "layer_3", 2, 4)
+    fx["select_1_5"] = kvm.select(req, "layer_3", [1, 5])
+    # block_size > 1 layout (generic manager): 10 tokens, block 4 -> 3 blocks
+    kvm.allocate_slots(KVCacheRequest("r1"), KVCacheRequestSpec(
+        num_tokens=10, block_size=4,
+        specs={"L": KVCacheSpec(num_kv_heads=2, head_size=8, dtype=torch.float32, kv_offload=False, use_mla=False),
+               "M": KVCacheSpec(num_kv_heads=1, head_size=8, dtype=torch.float32, kv_offload=False, use_mla=True)}))
+    fx["bs4_shape"] = torch.tensor(kvm.get_raw(KVCacheRequest("r1"), "L").shape)
+    fx["mla_shape"] = torch.tensor(kvm.get_raw(KVCacheRequest("r1"), "M").shape)
+    s = kvm.layer_spec(KVCacheRequest("r1"), "L")
+    fx["bs4_spec"] = torch.tensor([s.size, s.num_tokens, s.num_blocks, s.block_size])
+    errs = []
+    try:
+        ad.allocate_kv_cache(kv_cache_manager=kvm, kv_cache_request=req, sequence_length=50, dtype=BF)
+    except Exception as e:  # noqa: BLE001
+        errs.append(type(e).__name__)
+    try:
+        kvm.free(KVCacheRequest("nope"))
+    except Exception as e:  # noqa: BLE001
+        errs.append(type(e).__name__)
+    ad.clear_cache(kvm, req)
+    fx["layers_after_clear"] = "|".join(kvm.layers(req))
+    kvm.free(req)
+    fx["layers_after_free"] = "|".join(kvm.layers(req))
+    fx["errors"] = "|".join(errs)
+    print("   errors:", errs, " layers:", fx["layers"])
+    save_npz(os.path.join(GOLDEN_DIR, "kv_manager.npz"), fx)
+
+
+# --------------------------------------------------------------------------
+class _FakeTextEncoder:
+    def __init__(self, embeds):
+        self.embeds = embeds
+
+    def __call__(self, text_prompts):
+        return {"prompt_embeds": self.embeds}
+
+
+def _run_ref_rollout(cm, cfg, W, noise, prompt_embeds, steps, shift, nfb, free_cache=False,
+                     initial_latent=None):
+    """Drive the reference's own CausalInferencePipeline.inference(NO_DECODE) on CPU."""
+    from inferix.core.types import DecodeMode
+    from inferix.kvcache_manager.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix.models.schedulers.flow_match import FlowMatchScheduler
+    from inferix.models.self_forcing.wrapper import WanDiffusionWrapper
+    from inferix.pipeline.self_forcing.CausalInferencePipeline import CausalInferencePipeline
+
+    m = build_ref_model(cm, cfg, W)
+    pc = m.parallel_config
+    w = WanDiffusionWrapper.__new__(WanDiffusionWrapper)
+    torch.nn.Module.__init__(w)
+    w.model, w.uniform_timestep, w.seq_len, w.parallel_config = m, False, 32760, pc
+    w.scheduler = FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
+    w.scheduler.set_timesteps(1000, training=True)
+    args = SimpleNamespace(denoising_step_list=list(steps), warp_denoising_step=True,
+                           num_frame_per_block=nfb, independent_first_frame=False, context_noise=0,
+                           model_kwargs={})
+    pipe = CausalInferencePipeline(args, "cpu", generator=w, text_encoder=_FakeTextEncoder(prompt_embeds),
+                                   vae=object(), parallel_config=pc)
+    pipe.num_transformer_blocks = cfg.num_layers
+    pipe.frame_seq_length = cfg.frame_seqlen
+
+    calls, drawn = [], []
+
+    def hook(mod, a, kw, out):
+        meta = kw["kv_cache_meta"][0]
+        calls.append(dict(x_in=kw["noisy_image_or_video"].clone(), timestep=kw["timestep"].clone(),
+                          current_start=int(kw["current_start"]), flow=out[0].clone(), x0=out[1].clone(),
+                          global_end=int(meta["global_end_index"].item()),
+                          local_end=int(meta["local_end_index"].item())))
+
+    h = w.register_forward_hook(hook, with_kwargs=True)
+    real_randn_like = torch.randn_like
+
+    def rec_randn_like(t, *a, **k):
+        r = real_randn_like(t, *a, **k)
+        drawn.append(r.clone())
+        return r
+
+    torch.manual_seed(1234)
+    torch.randn_like = rec_randn_like
+    kvm = KVCacheManager(device="cpu")
+    reqs = [KVCacheRequest(f"req{i}") for i in range(noise.shape[0])]
+    try:
+        out = pipe.inference(noise=noise, text_prompts=["x"] * noise.shape[0], kv_cache_manager=kvm,
+                             kv_cache_requests=reqs, initial_latent=initial_latent,
+                             decode_mode=DecodeMode.NO_DECODE, profile=False,
+                             free_cache_before_vae=free_cache)
+    finally:
+        torch.randn_like = real_randn_like
+        h.remove()
+    caches = [kvm.get_raw(reqs[0], f"layer_{l}").clone() for l in range(cfg.num_layers)]
+    return out, calls, drawn, caches
+
+
+def gen_rollout(cm, name, cfg, num_blocks, steps, shift, batch=1, with_initial=False):
+    print(name)
+    W = O.init_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    nfb = 3
+    noise = torch.randn(batch, num_blocks * nfb, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF)
+    pe = torch.zeros(batch, cfg.text_len, cfg.text_dim)
+    pe[:, :10] = torch.randn(batch, 10, cfg.text_dim, generator=g)
+    pe = pe.to(BF)
+    init = None
+    if with_initial:
+        init = torch.randn(batch, nfb, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF)
+    out, calls, drawn, caches = _run_ref_rollout(cm, cfg, W, noise, pe, steps, shift, nfb,
+                                                 initial_latent=init)
+    rec = []
+    cache_tokens = caches[0].shape[1]
+    state = O.CacheState.allocate(cfg, batch, BF, cache_tokens=cache_tokens)
+    mine, state = O.inference(W, cfg, noise, list(pe), steps, renoise=drawn, shift=shift,
+                              num_frame_per_block=nfb, state=state, record=rec, initial_latent=init)
+    check("rollout output", out, mine)
+    le = state.layers[0].local_end        # reference cache is torch.empty(): compare the live prefix only
+    check("cache K layer0", caches[0][0, :le, 0], state.layers[0].k[0, :le])
+    check("cache V last layer", caches[-1][1, :le, 0], state.layers[-1].v[0, :le])
+    n_pref = 1 if with_initial else 0
+    assert len(state.trace) == len(calls), (len(state.trace), len(calls))
+    for c, s in zip(calls, state.trace):
+        assert (c["global_end"], c["local_end"]) == (s.global_end, s.local_end), (c, s)
+    print(f"   {len(calls)} generator forwards, integer trace identical; "
+          f"local_end trace = {[c['local_end'] for c in calls]}")
+    fx = dict(noise=noise, prompt_embeds=pe, out=out,
+              steps=torch.tensor(steps), shift=torch.tensor(shift),
+              weights_checksum=torch.tensor(weights_checksum(W)),
+              trace=torch.tensor([[c["current_start"], c["global_end"], c["local_end"]] for c in calls]),
+              trace_oracle=torch.tensor([[s.local_start, s.local_end, s.global_end, s.evicted, s.rolled]
+                                         for s in state.trace]),
+              cache_tokens=torch.tensor(cache_tokens),
+              cache_k_layer0=caches[0][0, :state.layers[0].local_end, 0],
+              cache_v_layer0=caches[0][1, :state.layers[0].local_end, 0],
+              cache_k_last=caches[-1][0, :state.layers[0].local_end, 0])
+    if init is not None:
+        fx["initial_latent"] = init
+    for i, d in enumerate(drawn):
+        fx[f"renoise_{i}"] = d
+    for i, c in enumerate(calls):
+        fx[f"call{i}_x_in"], fx[f"call{i}_t"] = c["x_in"], c["timestep"]
+        fx[f"call{i}_flow"], fx[f"call{i}_x0"] = c["flow"], c["x0"]
+    fx["num_calls"] = torch.tensor(len(calls))
+    fx["num_renoise"] = torch.tensor(len(drawn))
+    save_npz(os.path.join(GOLDEN_DIR, name), fx)
+
+
+def gen_block(cm):
+    """One CausalWanAttentionBlock forward at the REAL channel geometry (dim 1536, 12 heads,
+    ffn 8960) on a small token grid, two consecutive blocks of frames (prefix growth)."""
+    print("block_real_dims.npz")
+    from inferix.kvcache_manager.kvcache_manager import KVCacheManager, KVCacheRequest
+    cfg = O.WanConfig(num_layers=1, text_len=32, text_dim=64, freq_dim=64, latent_h=8, latent_w=12)
+    W = O.init_weights(cfg, seed=3)
+    m = build_ref_model(cm, cfg, W)
+    g = torch.Generator().manual_seed(9)
+    nf, fs = 3, cfg.frame_seqlen
+    n = nf * fs
+    kvm = KVCacheManager(device="cpu")
+    req = [KVCacheRequest("r")]
+    blk = m.blocks[0]
+    blk.kv_cache_manager.allocate_kv_cache(kv_cache_manager=kvm, kv_cache_request=req[0],
+                                           sequence_length=6 * fs, dtype=BF)
+    blk.kv_cache_manager.allocate_crossattn_cache(kv_cache_manager=kvm, kv_cache_request=req[0],
+                                                  crossattn_length=cfg.text_len, dtype=BF)
+    kvm.get_raw(req[0], "layer_0").zero_()
+    meta = {"global_end_index": torch.tensor([0]), "local_end_index": torch.tensor([0])}
+    cmeta = {"is_init": False}
+    ctx = torch.randn(1, cfg.text_len, cfg.dim, generator=g).to(BF)
+    state = O.CacheState.allocate(cfg, 1, BF, cache_tokens=6 * fs)
+    freqs = O.rope_freqs(cfg.head_dim)
+    grid = (nf, cfg.latent_h // 2, cfg.latent_w // 2)
+    fx = dict(context=ctx, weights_checksum=torch.tensor(weights_checksum(W)))
+    for b in range(2):
+        x = torch.randn(1, n, cfg.dim, generator=g).to(BF)
+        e0 = (torch.randn(1, nf, 6, cfg.dim, generator=g) * 0.5).to(BF)
+        ref = blk(x, e=e0, seq_lens=torch.tensor([n]), grid_sizes=torch.tensor([list(grid)]),
+                  freqs=m.freqs, context=ctx, context_lens=None, block_mask=None, kv_cache_meta=meta,
+                  crossattn_cache_meta=cmeta, current_start=b * n, cache_start=None,
+                  kv_cache_manager=kvm, kv_cache_requests=req)
+        mine = O.block_forward(x, e0, ctx, W, 0, cfg, grid, freqs, state, b * n)
+        check(f"block fwd #{b}", ref, mine)
+        fx[f"x{b}"], fx[f"e0_{b}"], fx[f"out{b}"] = x, e0, ref
+    raw = kvm.get_raw(req[0], "layer_0")
+    check("block cache K", raw[0, :, 0], state.layers[0].k[0])
+    fx["cache_k"], fx["cache_v"] = raw[0, :2 * n, 0], raw[1, :2 * n, 0]
+    craw = kvm.get_raw(req[0], "crossattn_layer_0")
+    fx["cross_k"], fx["cross_v"] = craw[0, :, 0], craw[1, :, 0]
+    save_npz(os.path.join(GOLDEN_DIR, "block_real_dims.npz"), fx)
+
+
+def main():
+    if not _refstub.available():
+        raise SystemExit("reference tree not present — fixtures can only be generated in the build container")
+    cm = _refstub.import_hot_path()
+    gen_ops(cm)
+    gen_layout(cm)
+    gen_scheduler()
+    gen_kv_manager()
+    gen_block(cm)
+    gen_rollout(cm, "rollout_tiny.npz", O.tiny_config(), num_blocks=3, steps=[1000, 750, 500, 250], shift=5.0)
+    gen_rollout(cm, "rollout_tiny_local.npz", O.tiny_config(local_attn_size=6, sink_size=1), num_blocks=4,
+                steps=[1000, 500], shift=5.0)
+    # initial_latent prefill (I2V / segment continuation, CausVid-style step list); the reference's
+    # prefill only works for batch 1 when num_frame_per_block > 1 (timestep is [B,1], wrapper.py:282)
+    gen_rollout(cm, "rollout_tiny_prefill.npz", O.tiny_config(), num_blocks=2, steps=[1000, 757, 522],
+                shift=8.0, batch=1, with_initial=True)
+    gen_rollout(cm, "rollout_tiny_b2.npz", O.tiny_config(), num_blocks=2, steps=[1000, 500],
+                shift=5.0, batch=2)
+    tot = sum(os.path.getsize(os.path.join(GOLDEN_DIR, f)) for f in os.listdir(GOLDEN_DIR))
+    print(f"golden fixtures total {tot / 1e6:.2f} MB in {GOLDEN_DIR}")
+
+
+if __name__ == "__main__":
+    main()
