@@ -1,0 +1,184 @@
+/*
+ * inferix_hip.h — C-ABI of libinferix_hip.so: the MI355X (gfx950) kernels of the
+ * semi-autoregressive block-diffusion denoising step (causal Wan DiT) behind
+ * Inferix's generator / attention / KV-cache interfaces.
+ *
+ * The reference (alibaba-damo-academy/Inferix) has no FFI layer: its hot path is
+ * Python calling un-vendored CUDA libraries.  Each entry point below names the
+ * reference Python call site(s) it replaces (paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - plain C: device pointers + sizes, no torch types; caller owns every buffer
+ *     (PyTorch caching allocator or the KV-cache manager); no hidden allocation.
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); nothing
+ *     synchronises.
+ *   - returns 0 on success, a negative IFX_E* code otherwise; never throws.
+ *     ifx_last_error() returns a thread-local human-readable message.
+ *   - bf16 = IEEE bfloat16 stored as uint16_t; activations are token-major
+ *     [rows, channels] with the channel dimension contiguous.
+ *   - rounding points follow the reference's bf16 module boundaries (documented
+ *     per function) so results match its PyTorch path to bf16 rounding noise.
+ */
+#ifndef INFERIX_HIP_H
+#define INFERIX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFX_OK 0
+#define IFX_EINVAL (-1)   /* bad argument (null pointer, unsupported shape) */
+#define IFX_ELAUNCH (-2)  /* HIP launch error */
+#define IFX_EUNSUP (-3)   /* configuration not built into this library */
+
+typedef uint16_t ifx_bf16;
+
+/* library identity ------------------------------------------------------- */
+int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
+const char* ifx_last_error(void);      /* thread-local, never NULL */
+const char* ifx_arch(void);            /* "gfx950" */
+
+/* ------------------------------------------------------------------------
+ * Paged KV cache view (one request, one layer).
+ * Replaces the tensors handed around by inferix/kvcache_manager/kvcache_manager.py:145-220
+ * (`get` / `set`) and the slice arithmetic of
+ * inferix/models/self_forcing/causal_model.py:277-304.
+ *
+ * Physical layout is the reference manager's own: K and V each
+ * [num_slots][kv_heads][head_dim] bf16, token-major (manager tensor
+ * (2, num_blocks, block_size, kv_heads, head_dim), kvcache_manager.py:222-244).
+ * Logical token t lives in physical slot
+ *     page_table ? page_table[t / page_size] * page_size + t % page_size : t
+ * so sink+rolling eviction (causal_model.py:282-300) is a page-table rotation
+ * instead of a data move whenever the evicted span is page-aligned.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  ifx_bf16* k;                 /* device */
+  ifx_bf16* v;                 /* device */
+  const int32_t* page_table;   /* device, may be NULL (identity) */
+  int32_t page_size;           /* tokens per page (ignored when page_table == NULL) */
+  int32_t num_slots;           /* capacity in tokens */
+  int32_t kv_heads;
+  int32_t head_dim;            /* 128 */
+} ifx_kv_view;
+
+/* ------------------------------------------------------------------------
+ * Block-causal flash-attention forward over the cached prefix, KV read in place.
+ *   out[r,h,:] = softmax_j(q[r,h,:]·K[j,h,:] * scale) · V[j,h,:],  j in [0, kv_len)
+ * No mask: block causality is realised by what is in the cache
+ * (causal_model.py:307-315).  Replaces `attention()` / `flash_attention()`
+ * (inferix/models/attention/flash_attention.py:42-200) and the registry backends'
+ * (out, lse) contract (inferix/models/attention/backends.py:36-76).
+ *   q, out : [q_rows, heads, 128] bf16 (row stride = heads*128)
+ *   lse    : optional [heads, q_rows] fp32 (natural log), NULL to skip
+ *   scale  : softmax scale (1/sqrt(128) when <= 0)
+ * bf16 in, fp32 softmax/accumulate, P rounded to bf16 for the PV product, bf16 out.
+ * ---------------------------------------------------------------------- */
+int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
+                       int32_t q_rows, int32_t heads, int32_t kv_len, float scale, void* stream);
+
+/* Merge two partial attention results over disjoint key sets (split-KV / context
+ * parallel).  Replaces update_out_and_lse_pass_q
+ * (inferix/models/attention/distributed.py:30-48).
+ *   out_a/out_b [rows, heads, 128] bf16, lse_a/lse_b [heads, rows] fp32;
+ *   result written to out_a / lse_a. */
+int ifx_lse_merge(ifx_bf16* out_a, float* lse_a, const ifx_bf16* out_b, const float* lse_b,
+                  int32_t rows, int32_t heads, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused QK-RMSNorm + 3-axis RoPE + KV append.
+ * Replaces, per layer: WanRMSNorm on q and k over ALL channels
+ * (inferix/models/wan_base/components.py:107-126, applied causal_model.py:172-173),
+ * causal_rope_apply[_chunked] (causal_model.py:33-100) and the cache write
+ * causal_model.py:303-304 (+ the manager round trip :416-441).
+ *
+ *   qkv      : [rows, 3*dim] bf16 — fused q|k|v projection output (bias included)
+ *   q_out    : [rows, dim] bf16   — RMSNorm(q)*wq then RoPE
+ *   K slot(local_start + r) <- RoPE(RMSNorm(k)*wk),  V slot <- v   (via kv page table)
+ *   rope     : position tables + token grid (NULL = no rotation: cross-attn q)
+ *   kv       : NULL = no append (cross-attention query path)
+ * Row r of this rank is token (frame r / hw_local, hw index hw_offset + r % hw_local):
+ * temporal position start_frame + frame, height (hw / width), width (hw % width) — the
+ * single-GPU case is hw_offset = 0, hw_local = height*width; the context-parallel case
+ * is the reference's per-frame hw slice (causal_model.py:64-100,939-942).
+ * Pairs are adjacent channels (2i, 2i+1); per head the head_dim/2 complex pairs split
+ * [c-2*(c/3) temporal | c/3 height | c/3 width] (causal_model.py:34-37).
+ * Rounding: y = bf16(x * rsqrt(mean(x^2)+eps)) ; y = bf16(y * w) ; rotation in fp64 ; bf16.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const double* freqs;   /* device [max_pos, head_dim/2, 2] = (cos, sin): the reference's
+                            complex128 `self.freqs` (causal_model.py:636-641) viewed as real */
+  int32_t max_pos;       /* 1024 */
+  int32_t start_frame;   /* current_start // frame_seqlen (causal_model.py:255-256) */
+  int32_t height, width; /* patch grid of one frame */
+  int32_t hw_offset;     /* rank * hw_local */
+  int32_t hw_local;      /* height*width / world_size */
+} ifx_rope_grid;
+
+int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t qkv_row_stride, ifx_bf16* q_out,
+                               const ifx_bf16* wq, const ifx_bf16* wk, const ifx_rope_grid* rope,
+                               const ifx_kv_view* kv, int32_t local_start, int32_t rows,
+                               int32_t dim, float eps, void* stream);
+
+/* RMSNorm only, in place or out of place, [rows, dim] (cross-attention q / text K). */
+int ifx_rmsnorm(const ifx_bf16* x, int32_t x_row_stride, ifx_bf16* y, int32_t y_row_stride,
+                const ifx_bf16* w, int32_t rows, int32_t dim, float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm (+ AdaLN modulation).  Replaces WanLayerNorm
+ * (components.py:129-142) and the per-frame modulation
+ * `norm(x).unflatten(1,(F,fs)) * (1 + e[scale]) + e[shift]`
+ * (causal_model.py:433,451-452,514).
+ *   mode IFX_LN_PLAIN    : y = bf16(LN(x))
+ *   mode IFX_LN_AFFINE   : y = bf16(LN(x) * gamma + beta)                 (norm3)
+ *   mode IFX_LN_MODULATE : y = bf16(bf16(bf16(LN(x)) * bf16(1 + s)) + t), s/t = rows of `mod`
+ *   mod : [groups, mod_slots, dim] bf16 = (modulation + e0) of this layer;
+ *         row r uses group r / rows_per_group; shift_slot/scale_slot select the chunk.
+ * ---------------------------------------------------------------------- */
+enum { IFX_LN_PLAIN = 0, IFX_LN_AFFINE = 1, IFX_LN_MODULATE = 2 };
+int ifx_layernorm(const ifx_bf16* x, ifx_bf16* y, int32_t rows, int32_t dim, float eps, int32_t mode,
+                  const ifx_bf16* gamma, const ifx_bf16* beta, const ifx_bf16* mod,
+                  int32_t mod_slots, int32_t shift_slot, int32_t scale_slot, int32_t rows_per_group,
+                  void* stream);
+
+/* ------------------------------------------------------------------------
+ * bf16 linear layer  y = epilogue(x @ W^T + bias)  on MFMA, fp32 accumulate.
+ * Replaces nn.Linear calls of the block (causal_model.py:125-128,171-175,332-333,377-379,
+ * wan_base/model.py:66-100) together with the elementwise ops that follow them.
+ *   x [M, K] bf16 (row stride ldx), W [N, K] bf16 (nn.Linear layout), bias [N] bf16 or NULL,
+ *   y [M, N] bf16 (row stride ldy).
+ *   IFX_EPI_BIAS      : y = bf16(acc + b)
+ *   IFX_EPI_GELU_TANH : y = bf16(gelu_tanh(bf16(acc + b)))                   (ffn.0 + GELU)
+ *   IFX_EPI_RESIDUAL  : y = bf16(res + bf16(acc + b))                         (cross-attn o)
+ *   IFX_EPI_GATE_RES  : y = bf16(res + bf16(bf16(acc + b) * gate[r / rows_per_group]))
+ *                       gate = rows of `mod` [groups, mod_slots, N] at gate_slot   (:444,455-456)
+ * ---------------------------------------------------------------------- */
+enum { IFX_EPI_BIAS = 0, IFX_EPI_GELU_TANH = 1, IFX_EPI_RESIDUAL = 2, IFX_EPI_GATE_RES = 3 };
+typedef struct {
+  int32_t epilogue;
+  const ifx_bf16* residual;  /* [M, N], row stride ld_res */
+  int32_t ld_res;
+  const ifx_bf16* mod;       /* [groups, mod_slots, N] */
+  int32_t mod_slots;
+  int32_t gate_slot;
+  int32_t rows_per_group;
+} ifx_epilogue;
+int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias,
+                  ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
+                  const ifx_epilogue* epi, void* stream);
+
+/* ------------------------------------------------------------------------
+ * KV cache maintenance.  ifx_kv_roll: the reference's eviction shift
+ * cache[sink : sink+rolled] <- cache[sink+evicted : sink+evicted+rolled]
+ * (causal_model.py:287-292) as a physical move, for spans that are not page aligned
+ * (page-aligned spans are handled by rotating the page table on the host). */
+int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t evicted, int32_t rolled,
+                ifx_bf16* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFERIX_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libinferix_hip.so (C-ABI declared in include/inferix_hip.h).
+
+The HIP library is the product: there is NO fallback.  Importing this module
+without the built library, or calling an op on a non-GPU tensor, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinferix_hip.so")
+
+IFX_LN_PLAIN, IFX_LN_AFFINE, IFX_LN_MODULATE = 0, 1, 2
+IFX_EPI_BIAS, IFX_EPI_GELU_TANH, IFX_EPI_RESIDUAL, IFX_EPI_GATE_RES = 0, 1, 2, 3
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class KvView(C.Structure):
+    """ifx_kv_view"""
+    _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("page_table", C.c_void_p),
+                ("page_size", C.c_int32), ("num_slots", C.c_int32), ("kv_heads", C.c_int32),
+                ("head_dim", C.c_int32)]
+
+
+class RopeGrid(C.Structure):
+    """ifx_rope_grid"""
+    _fields_ = [("freqs", C.c_void_p), ("max_pos", C.c_int32), ("start_frame", C.c_int32),
+                ("height", C.c_int32), ("width", C.c_int32), ("hw_offset", C.c_int32),
+                ("hw_local", C.c_int32)]
+
+
+class Epilogue(C.Structure):
+    """ifx_epilogue"""
+    _fields_ = [("epilogue", C.c_int32), ("residual", C.c_void_p), ("ld_res", C.c_int32),
+                ("mod", C.c_void_p), ("mod_slots", C.c_int32), ("gate_slot", C.c_int32),
+                ("rows_per_group", C.c_int32)]
+
+
+# name -> (restype, argtypes); the complete export list of include/inferix_hip.h
+_vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
+SIGNATURES = {
+    "ifx_version": (C.c_int, []),
+    "ifx_last_error": (C.c_char_p, []),
+    "ifx_arch": (C.c_char_p, []),
+    "ifx_attn_fwd_paged": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _f32, _vp]),
+    "ifx_lse_merge": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "ifx_rmsnorm_rope_kv_append": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.POINTER(RopeGrid), C.POINTER(KvView),
+                                             _i32, _i32, _i32, _f32, _vp]),
+    "ifx_rmsnorm": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _vp]),
+    "ifx_layernorm": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ifx_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
+    "ifx_kv_roll": (C.c_int, [C.POINTER(KvView), _i32, _i32, _i32, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (built by `__graft_entry__.build()` / `make -C inferix_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  inferix_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ifx_last_error().decode("utf-8", "replace")
+        raise HipKernelError(f"{what} failed (code {rc}): {msg}")
+
+
+def version() -> str:
+    v = load().ifx_version()
+    return f"{v >> 16}.{(v >> 8) & 255}.{v & 255}"

@@ -1,0 +1,210 @@
+// bf16 linear layer on MFMA with fused epilogues (gfx950).
+//
+//   y[M,N] = epilogue( x[M,K] @ W[N,K]^T + bias[N] )
+//
+// Both operands are K-contiguous (activations token-major, nn.Linear weights
+// [out,in]), which is the natural MFMA layout: every lane's 8-element fragment is one
+// 16-byte load.  The kernel computes the TRANSPOSED tile D = W_tile · x_tile^T
+// (A-operand = W rows, B-operand = x rows) so that each lane ends up with 4
+// CONSECUTIVE output channels of one token: bias / gate / residual / store are
+// 8-byte vector accesses along the contiguous dimension.
+//
+// Tiling (v1): 128(tokens) x 128(channels) x 64(K) per workgroup, 4 waves (2x2),
+// each wave 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16; operands staged
+// global -> registers -> LDS (double buffered, one barrier per K-tile, loads for
+// tile t+1 issued before the MFMAs of tile t); LDS rows are 128 B with the 16-byte
+// chunk index XOR-swizzled by (row & 7) so ds_read_b128 fragment reads are
+// bank-conflict free.  64 KiB LDS -> 2 workgroups per CU.
+#include "ifx_common.h"
+
+namespace ifx {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct EpiArgs {
+  const unsigned short* bias;
+  const unsigned short* residual;
+  int ld_res;
+  const unsigned short* mod;
+  int mod_slots, gate_slot, rows_per_group;
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5*x*(1+tanh(u)) == x*sigmoid(2u),  u = sqrt(2/pi)*(x + 0.044715 x^3)
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                           const unsigned short* __restrict__ w,
+                                                           unsigned short* __restrict__ y, int ldy, int M, int N,
+                                                           int K, int tiles_m, EpiArgs ea) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [buf][X|W][128 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+
+  // staging assignment: 4 chunks of 16 B per matrix per thread
+  const unsigned short* gx[4];
+  const unsigned short* gw[4];
+  int lds_off[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = tid + 256 * p, row = q >> 3, c = q & 7;
+    const int mr = min(m_base + row, M - 1), nr = min(n_base + row, N - 1);
+    gx[p] = x + (size_t)mr * ldx + c * 8;
+    gw[p] = w + (size_t)nr * K + c * 8;
+    lds_off[p] = row * 128 + ((c ^ (row & 7)) << 4);
+  }
+  u32x4 rx[4], rw[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      rx[p] = *reinterpret_cast<const u32x4*>(gx[p] + (size_t)kt * BK);
+      rw[p] = *reinterpret_cast<const u32x4*>(gw[p] + (size_t)kt * BK);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* bx = smem + buf * 32768;
+    unsigned char* bw = bx + 16384;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<u32x4*>(bx + lds_off[p]) = rx[p];
+      *reinterpret_cast<u32x4*>(bw + lds_off[p]) = rw[p];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    const unsigned char* bx = smem + buf * 32768;
+    const unsigned char* bw = bx + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+      const int c = ks * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wn * 64 + i * 16 + fr;
+        a[i] = *reinterpret_cast<const bf16x8*>(bw + row * 128 + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wm * 64 + j * 16 + fr;
+        b[j] = *reinterpret_cast<const bf16x8*>(bx + row * 128 + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds D[n = n0+16i+4*fq+{0..3}][m = m0+16j+fr]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m_base + wm * 64 + j * 16 + fr;
+    if (m >= M) continue;
+    const unsigned short* gate_row = nullptr;
+    if (EPI == IFX_EPI_GATE_RES)
+      gate_row = ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n_base + wn * 64 + i * 16 + fq * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (ea.bias) {
+        const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+      }
+      u16x4 o;
+      if (EPI == IFX_EPI_BIAS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+      } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_tanh_f(rbf(v[e])));
+      } else {
+        const u16x4 rv = *reinterpret_cast<const u16x4*>(ea.residual + (size_t)m * ea.ld_res + n);
+        if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(v[e]));
+        } else {
+          const u16x4 gv = *reinterpret_cast<const u16x4*>(gate_row + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(rbf(v[e]) * bf2f(gv[e])));
+        }
+      }
+      *reinterpret_cast<u16x4*>(y + (size_t)m * ldy + n) = o;
+    }
+  }
+}
+
+}  // namespace ifx
+
+using namespace ifx;
+
+extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
+                             int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* stream) {
+  IFX_REQUIRE(x && w && y && M >= 0 && N > 0 && K > 0, "ifx_gemm_bf16: null/empty operand");
+  IFX_REQUIRE(K % BK == 0, "ifx_gemm_bf16: K (%d) must be a multiple of %d", K, BK);
+  IFX_REQUIRE(N % 4 == 0 && ldx % 8 == 0 && ldy % 4 == 0, "ifx_gemm_bf16: N %% 4, ldx %% 8, ldy %% 4 required");
+  const int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
+  EpiArgs ea{bias, nullptr, 0, nullptr, 1, 0, 1};
+  if (mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES) {
+    IFX_REQUIRE(epi->residual && epi->ld_res % 4 == 0, "ifx_gemm_bf16: residual epilogue needs residual/ld_res");
+    ea.residual = epi->residual;
+    ea.ld_res = epi->ld_res;
+  }
+  if (mode == IFX_EPI_GATE_RES) {
+    IFX_REQUIRE(epi->mod && epi->rows_per_group > 0 && epi->gate_slot >= 0 && epi->gate_slot < epi->mod_slots,
+                "ifx_gemm_bf16: gate epilogue needs mod/mod_slots/gate_slot/rows_per_group");
+    ea.mod = epi->mod;
+    ea.mod_slots = epi->mod_slots;
+    ea.gate_slot = epi->gate_slot;
+    ea.rows_per_group = epi->rows_per_group;
+  }
+  if (M == 0) return IFX_OK;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const dim3 grid(tiles_m * tiles_n), block(256);
+  const size_t lds = 65536;
+  hipStream_t s = (hipStream_t)stream;
+#define IFX_LAUNCH_GEMM(E)                                                                                    \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                    \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, ea);  \
+  } while (0)
+  switch (mode) {
+    case IFX_EPI_BIAS: IFX_LAUNCH_GEMM(IFX_EPI_BIAS); break;
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_GEMM(IFX_EPI_GELU_TANH); break;
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_GEMM(IFX_EPI_RESIDUAL); break;
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_GEMM(IFX_EPI_GATE_RES); break;
+    default: set_error("ifx_gemm_bf16: unknown epilogue %d", mode); return IFX_EINVAL;
+  }
+#undef IFX_LAUNCH_GEMM
+  return check_launch("ifx_gemm_bf16");
+}

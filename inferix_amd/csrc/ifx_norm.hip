@@ -1,0 +1,368 @@
+// HBM-bound row kernels of the denoising step (gfx950):
+//   * LayerNorm / AdaLN-modulated LayerNorm           (ifx_layernorm)
+//   * WanRMSNorm                                       (ifx_rmsnorm)
+//   * fused QK-RMSNorm + 3-axis RoPE + paged KV append (ifx_rmsnorm_rope_kv_append)
+//
+// Design: one 64-lane wavefront owns one token row.  The row lives in registers
+// (8 bf16 = 16 B per lane per 512-channel chunk, fully coalesced 1 KiB per wave
+// load), statistics are reduced with wavefront shuffles (no LDS, no barriers),
+// and every elementwise consumer of the normalised row is fused behind it so the
+// row is read once and written once.  4 waves per workgroup, grid = rows / 4, which
+// is >> 256 workgroups for the 4680-row blocks of the 480p path.
+//
+// Rounding points reproduce the reference's bf16 module boundaries (see
+// include/inferix_hip.h); statistics are fp32, the rotation is fp64 like the
+// reference's complex128 multiply (causal_model.py:33-61).
+#include "ifx_common.h"
+
+namespace ifx {
+
+template <int NCH>
+struct Row {
+  float v[NCH][8];
+  __device__ __forceinline__ void load(const unsigned short* p, int dim, int lane) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = c * 512 + lane * 8;
+      if (col < dim) {
+        u16x8 u = *reinterpret_cast<const u16x8*>(p + col);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] = bf2f(u[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ float sum() const {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[c][i];
+    return s;
+  }
+  __device__ __forceinline__ float sumsq() const {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[c][i] * v[c][i];
+    return s;
+  }
+};
+
+// ---------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int rows, int dim, float eps,
+    int mode, const unsigned short* __restrict__ gamma, const unsigned short* __restrict__ beta,
+    const unsigned short* __restrict__ mod, int mod_slots, int shift_slot, int scale_slot,
+    int rows_per_group) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  Row<NCH> row;
+  row.load(x + (size_t)r * dim, dim, lane);
+  const float inv_n = 1.0f / (float)dim;
+  const float mean = wave_sum(row.sum()) * inv_n;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c * 512 + lane * 8 < dim) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float d = row.v[c][i] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float var = wave_sum(ss) * inv_n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+
+  const unsigned short* shift_p = nullptr;
+  const unsigned short* scale_p = nullptr;
+  if (mode == IFX_LN_MODULATE) {
+    const size_t g = (size_t)(r / rows_per_group) * mod_slots;
+    shift_p = mod + (g + shift_slot) * dim;
+    scale_p = mod + (g + scale_slot) * dim;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col >= dim) continue;
+    u16x8 o;
+    if (mode == IFX_LN_MODULATE) {
+      u16x8 sc = *reinterpret_cast<const u16x8*>(scale_p + col);
+      u16x8 sh = *reinterpret_cast<const u16x8*>(shift_p + col);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = rbf((row.v[c][i] - mean) * rstd);   // norm output is a bf16 tensor
+        float s1 = rbf(1.0f + bf2f(sc[i]));           // (1 + e) evaluated in bf16
+        t = rbf(t * s1);
+        o[i] = f2bf(t + bf2f(sh[i]));
+      }
+    } else if (mode == IFX_LN_AFFINE) {
+      u16x8 g = *reinterpret_cast<const u16x8*>(gamma + col);
+      u16x8 b = *reinterpret_cast<const u16x8*>(beta + col);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        o[i] = f2bf((row.v[c][i] - mean) * rstd * bf2f(g[i]) + bf2f(b[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = f2bf((row.v[c][i] - mean) * rstd);
+    }
+    *reinterpret_cast<u16x8*>(y + (size_t)r * dim + col) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                      unsigned short* __restrict__ y, int ldy,
+                                                      const unsigned short* __restrict__ w, int rows,
+                                                      int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  Row<NCH> row;
+  row.load(x + (size_t)r * ldx, dim, lane);
+  const float rs = 1.0f / sqrtf(wave_sum(row.sumsq()) / (float)dim + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col >= dim) continue;
+    u16x8 wv = *reinterpret_cast<const u16x8*>(w + col);
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(rbf(row.v[c][i] * rs) * bf2f(wv[i]));
+    *reinterpret_cast<u16x8*>(y + (size_t)r * ldy + col) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct RopeArgs {
+  const double* freqs;
+  int max_pos, start_frame, height, width, hw_offset, hw_local;
+};
+
+// rotate the 4 adjacent-channel pairs held in t[0..7]; pair index jp0..jp0+3 within the head
+__device__ __forceinline__ void rope4(float (&t)[8], int jp0, const RopeArgs& ra, int half, int n_t,
+                                      int n_h, int pos_t, int pos_h, int pos_w) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int j = jp0 + p;
+    const int pos = (j < n_t) ? pos_t : ((j < n_t + n_h) ? pos_h : pos_w);
+    const double2 cs = *reinterpret_cast<const double2*>(ra.freqs + ((size_t)pos * half + j) * 2);
+    const double a = (double)t[2 * p], b = (double)t[2 * p + 1];
+    // complex multiply exactly as (a+ib)(c+is) evaluates in complex128:
+    // re = a*c - b*s ; im = a*s + b*c  (each product and sum rounded in fp64)
+    const double re = __dmul_rn(a, cs.x) - __dmul_rn(b, cs.y);
+    const double im = __dmul_rn(a, cs.y) + __dmul_rn(b, cs.x);
+    t[2 * p] = (float)re;       // torch's double->bf16 goes through float
+    t[2 * p + 1] = (float)im;
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
+    const unsigned short* __restrict__ qkv, int ld, unsigned short* __restrict__ q_out,
+    const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk, RopeArgs ra, int has_rope,
+    unsigned short* __restrict__ kc, unsigned short* __restrict__ vc, KvAddr ka, int local_start, int rows,
+    int dim, int head_dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const unsigned short* base = qkv + (size_t)r * ld;
+
+  int pos_t = 0, pos_h = 0, pos_w = 0;
+  const int half = head_dim >> 1;
+  const int n_h = half / 3, n_t = half - 2 * n_h;
+  if (has_rope) {
+    const int f = r / ra.hw_local;
+    const int p = ra.hw_offset + (r - f * ra.hw_local);
+    pos_t = ra.start_frame + f;
+    pos_h = p / ra.width;
+    pos_w = p - pos_h * ra.width;
+  }
+  size_t slot_off = 0;
+  if (kc != nullptr) slot_off = (size_t)ka.slot(local_start + r) * dim;
+
+  // ---- q ----
+  {
+    Row<NCH> row;
+    row.load(base, dim, lane);
+    const float rs = 1.0f / sqrtf(wave_sum(row.sumsq()) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col >= dim) continue;
+      u16x8 wv = *reinterpret_cast<const u16x8*>(wq + col);
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = rbf(rbf(row.v[c][i] * rs) * bf2f(wv[i]));
+      if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
+      u16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i]);
+      *reinterpret_cast<u16x8*>(q_out + (size_t)r * dim + col) = o;
+    }
+  }
+  if (kc == nullptr) return;
+  // ---- k ----
+  {
+    Row<NCH> row;
+    row.load(base + dim, dim, lane);
+    const float rs = 1.0f / sqrtf(wave_sum(row.sumsq()) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col >= dim) continue;
+      u16x8 wv = *reinterpret_cast<const u16x8*>(wk + col);
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = rbf(rbf(row.v[c][i] * rs) * bf2f(wv[i]));
+      if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
+      u16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i]);
+      *reinterpret_cast<u16x8*>(kc + slot_off + col) = o;
+    }
+  }
+  // ---- v (raw copy into the cache slot) ----
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col >= dim) continue;
+    *reinterpret_cast<u16x8*>(vc + slot_off + col) = *reinterpret_cast<const u16x8*>(base + 2 * dim + col);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// KV roll: physical realisation of the eviction shift (causal_model.py:287-292)
+__global__ __launch_bounds__(256) void kv_copy_rows_kernel(const unsigned short* __restrict__ src,
+                                                           unsigned short* __restrict__ dst, KvAddr ka,
+                                                           int src_tok0, int dst_tok0, int ntok, int row_elems,
+                                                           int src_is_paged, int dst_is_paged) {
+  const int chunks = row_elems / 8;
+  const size_t total = (size_t)ntok * chunks;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / chunks), c = (int)(i - (size_t)t * chunks);
+    const size_t s = (size_t)(src_is_paged ? ka.slot(src_tok0 + t) : (src_tok0 + t)) * row_elems + c * 8;
+    const size_t d = (size_t)(dst_is_paged ? ka.slot(dst_tok0 + t) : (dst_tok0 + t)) * row_elems + c * 8;
+    *reinterpret_cast<u16x8*>(dst + d) = *reinterpret_cast<const u16x8*>(src + s);
+  }
+}
+
+template <typename F>
+static int dispatch_nch(int dim, F&& f) {
+  const int nch = (dim + 511) / 512;
+  if (nch <= 1) return f(std::integral_constant<int, 1>{});
+  if (nch <= 2) return f(std::integral_constant<int, 2>{});
+  if (nch <= 3) return f(std::integral_constant<int, 3>{});
+  if (nch <= 4) return f(std::integral_constant<int, 4>{});
+  if (nch <= 6) return f(std::integral_constant<int, 6>{});
+  if (nch <= 8) return f(std::integral_constant<int, 8>{});
+  if (nch <= 10) return f(std::integral_constant<int, 10>{});
+  set_error("row kernels support dim <= 5120 (got %d)", dim);
+  return IFX_EUNSUP;
+}
+
+}  // namespace ifx
+
+using namespace ifx;
+
+extern "C" int ifx_layernorm(const ifx_bf16* x, ifx_bf16* y, int32_t rows, int32_t dim, float eps, int32_t mode,
+                             const ifx_bf16* gamma, const ifx_bf16* beta, const ifx_bf16* mod, int32_t mod_slots,
+                             int32_t shift_slot, int32_t scale_slot, int32_t rows_per_group, void* stream) {
+  IFX_REQUIRE(x && y && rows >= 0 && dim > 0 && dim % 8 == 0, "ifx_layernorm: bad x/y/rows/dim(%d)", dim);
+  IFX_REQUIRE(mode >= IFX_LN_PLAIN && mode <= IFX_LN_MODULATE, "ifx_layernorm: bad mode %d", mode);
+  if (mode == IFX_LN_AFFINE) IFX_REQUIRE(gamma && beta, "ifx_layernorm: affine mode needs gamma/beta");
+  if (mode == IFX_LN_MODULATE)
+    IFX_REQUIRE(mod && rows_per_group > 0 && mod_slots > 0 && shift_slot >= 0 && shift_slot < mod_slots &&
+                    scale_slot >= 0 && scale_slot < mod_slots,
+                "ifx_layernorm: modulate mode needs mod/slots/rows_per_group");
+  if (rows == 0) return IFX_OK;
+  return dispatch_nch(dim, [&](auto nch) {
+    hipLaunchKernelGGL((layernorm_kernel<decltype(nch)::value>), dim3((rows + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, x, y, rows, dim, eps, mode, gamma, beta, mod, mod_slots, shift_slot,
+                       scale_slot, rows_per_group > 0 ? rows_per_group : 1);
+    return check_launch("ifx_layernorm");
+  });
+}
+
+extern "C" int ifx_rmsnorm(const ifx_bf16* x, int32_t ldx, ifx_bf16* y, int32_t ldy, const ifx_bf16* w,
+                           int32_t rows, int32_t dim, float eps, void* stream) {
+  IFX_REQUIRE(x && y && w && rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0,
+              "ifx_rmsnorm: bad arguments (dim %d)", dim);
+  if (rows == 0) return IFX_OK;
+  return dispatch_nch(dim, [&](auto nch) {
+    hipLaunchKernelGGL((rmsnorm_kernel<decltype(nch)::value>), dim3((rows + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, y, ldy, w, rows, dim, eps);
+    return check_launch("ifx_rmsnorm");
+  });
+}
+
+extern "C" int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t ld, ifx_bf16* q_out, const ifx_bf16* wq,
+                                          const ifx_bf16* wk, const ifx_rope_grid* rope, const ifx_kv_view* kv,
+                                          int32_t local_start, int32_t rows, int32_t dim, float eps,
+                                          void* stream) {
+  IFX_REQUIRE(qkv && q_out && wq && rows >= 0 && dim > 0 && dim % 8 == 0 && ld % 8 == 0,
+              "ifx_rmsnorm_rope_kv_append: bad arguments");
+  int head_dim = 128;
+  KvAddr ka{nullptr, 1};
+  unsigned short *kc = nullptr, *vc = nullptr;
+  if (kv) {
+    IFX_REQUIRE(wk && kv->k && kv->v && kv->kv_heads * kv->head_dim == dim,
+                "ifx_rmsnorm_rope_kv_append: kv view (heads %d x head_dim %d) does not match dim %d",
+                kv->kv_heads, kv->head_dim, dim);
+    IFX_REQUIRE(local_start >= 0 && local_start + rows <= kv->num_slots,
+                "ifx_rmsnorm_rope_kv_append: append [%d, %d) exceeds cache capacity %d", local_start,
+                local_start + rows, kv->num_slots);
+    if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_rmsnorm_rope_kv_append: page_size must be > 0");
+    head_dim = kv->head_dim;
+    kc = kv->k;
+    vc = kv->v;
+    ka = KvAddr{kv->page_table, kv->page_size};
+  }
+  RopeArgs ra{};
+  if (rope) {
+    IFX_REQUIRE(rope->freqs && rope->hw_local > 0 && rope->width > 0 && rope->height > 0,
+                "ifx_rmsnorm_rope_kv_append: bad rope grid");
+    IFX_REQUIRE(head_dim % 16 == 0 && dim % head_dim == 0, "ifx_rmsnorm_rope_kv_append: head_dim %d", head_dim);
+    const int frames = (rows + rope->hw_local - 1) / rope->hw_local;
+    IFX_REQUIRE(rope->start_frame + frames <= rope->max_pos && rope->height <= rope->max_pos &&
+                    rope->width <= rope->max_pos,
+                "ifx_rmsnorm_rope_kv_append: positions exceed rope table (%d)", rope->max_pos);
+    ra = RopeArgs{rope->freqs, rope->max_pos, rope->start_frame, rope->height,
+                  rope->width, rope->hw_offset, rope->hw_local};
+  }
+  if (rows == 0) return IFX_OK;
+  return dispatch_nch(dim, [&](auto nch) {
+    hipLaunchKernelGGL((rmsnorm_rope_append_kernel<decltype(nch)::value>), dim3((rows + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, qkv, ld, q_out, wq, wk, ra, rope ? 1 : 0, kc, vc, ka, local_start,
+                       rows, dim, head_dim, eps);
+    return check_launch("ifx_rmsnorm_rope_kv_append");
+  });
+}
+
+extern "C" int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t evicted, int32_t rolled,
+                           ifx_bf16* scratch, void* stream) {
+  IFX_REQUIRE(kv && kv->k && kv->v && scratch, "ifx_kv_roll: null argument");
+  IFX_REQUIRE(sink_tokens >= 0 && evicted >= 0 && rolled >= 0 &&
+                  sink_tokens + evicted + rolled <= kv->num_slots,
+              "ifx_kv_roll: span out of range");
+  if (rolled == 0 || evicted == 0) return IFX_OK;
+  const int row_elems = kv->kv_heads * kv->head_dim;
+  KvAddr ka{kv->page_table, kv->page_size};
+  const int blocks = 1024;
+  // two-pass through scratch: source and destination spans may overlap
+  for (int which = 0; which < 2; ++which) {
+    unsigned short* c = which == 0 ? kv->k : kv->v;
+    hipLaunchKernelGGL(kv_copy_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, scratch, ka,
+                       sink_tokens + evicted, 0, rolled, row_elems, 1, 0);
+    hipLaunchKernelGGL(kv_copy_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, c, ka, 0,
+                       sink_tokens, rolled, row_elems, 0, 1);
+  }
+  return check_launch("ifx_kv_roll");
+}

@@ -1,0 +1,183 @@
+"""Torch-tensor front end of the C-ABI (inferix_amd/_hip.py): pointer/shape marshalling only.
+
+Every function enqueues one HIP kernel of libinferix_hip.so on torch's CURRENT
+stream and returns immediately.  Tensors must live on the GPU; there is no CPU
+path here by design (the CPU restatement lives in oracle/, for tests only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _hip
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=BF16) -> int:
+    if not t.is_cuda:
+        raise _hip.HipKernelError(f"{name}: tensor is on {t.device}; inferix_amd ops run on the GPU only")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
+    """(rows, cols, row_stride) of a tensor viewed as a row-major matrix with uniform row stride."""
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    if t.dim() > 2:
+        t = t.flatten(0, -2) if t.is_contiguous() else t.reshape(-1, t.shape[-1])
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+@dataclass
+class KvCacheView:
+    """One (request, layer) of the paged KV cache: `k`,`v` `[num_slots, heads, head_dim]` bf16 views into
+    the KVCacheManager tensor + optional page table (int32, device) — mirrors `ifx_kv_view`."""
+    k: torch.Tensor
+    v: torch.Tensor
+    page_table: Optional[torch.Tensor] = None
+    page_size: int = 1
+
+    def struct(self) -> _hip.KvView:
+        assert self.k.shape == self.v.shape and self.k.dim() == 3 and self.k.is_contiguous() and self.v.is_contiguous()
+        pt = 0
+        if self.page_table is not None:
+            pt = _dev(self.page_table, "page_table", torch.int32)
+        return _hip.KvView(_dev(self.k, "kv.k"), _dev(self.v, "kv.v"), pt, int(self.page_size),
+                           self.k.shape[0], self.k.shape[1], self.k.shape[2])
+
+    @staticmethod
+    def from_manager_tensor(t: torch.Tensor, page_table=None, page_size=1) -> "KvCacheView":
+        """`t` is the reference-layout manager tensor (2, num_blocks, block_size, kv_heads, head_dim)
+        (kvcache_manager.py:222-244); K and V are zero-copy views of it."""
+        assert t.dim() == 5 and t.shape[0] == 2 and t.is_contiguous()
+        return KvCacheView(t[0].flatten(0, 1), t[1].flatten(0, 1), page_table, page_size)
+
+
+@dataclass
+class RopeGridSpec:
+    freqs: torch.Tensor          # [max_pos, head_dim/2, 2] float64 on device (cos, sin)
+    start_frame: int
+    height: int
+    width: int
+    hw_offset: int = 0
+    hw_local: Optional[int] = None
+
+    def struct(self) -> _hip.RopeGrid:
+        hl = self.hw_local if self.hw_local is not None else self.height * self.width
+        return _hip.RopeGrid(_dev(self.freqs, "rope.freqs", torch.float64), self.freqs.shape[0],
+                             int(self.start_frame), int(self.height), int(self.width), int(self.hw_offset), int(hl))
+
+
+def layernorm(x: torch.Tensor, eps: float, *, gamma=None, beta=None, mod=None, shift_slot=0, scale_slot=1,
+              rows_per_group: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm / affine LayerNorm / AdaLN-modulated LayerNorm over the last dim (ifx_layernorm)."""
+    lib = _hip.load()
+    rows, dim, ld = _rows2d(x, "x")
+    assert ld == dim, "x rows must be dense"
+    out = torch.empty_like(x) if out is None else out
+    if mod is not None:
+        mode = _hip.IFX_LN_MODULATE
+        assert mod.dim() == 3 and mod.shape[-1] == dim and mod.is_contiguous() and rows_per_group
+        assert rows <= mod.shape[0] * rows_per_group
+        args = (None, None, _dev(mod, "mod"), mod.shape[1], shift_slot, scale_slot, rows_per_group)
+    elif gamma is not None:
+        mode = _hip.IFX_LN_AFFINE
+        args = (_dev(gamma, "gamma"), _dev(beta, "beta"), None, 0, 0, 0, 1)
+    else:
+        mode = _hip.IFX_LN_PLAIN
+        args = (None, None, None, 0, 0, 0, 1)
+    _hip.check(lib.ifx_layernorm(_dev(x, "x"), _dev(out, "out"), rows, dim, eps, mode, *args, _stream()),
+               "ifx_layernorm")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _hip.load()
+    rows, dim, ldx = _rows2d(x, "x")
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
+    _, _, ldy = _rows2d(out, "out")
+    _hip.check(lib.ifx_rmsnorm(_dev(x, "x"), ldx, _dev(out, "out"), ldy, _dev(w, "w"), rows, dim, eps, _stream()),
+               "ifx_rmsnorm")
+    return out
+
+
+def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[torch.Tensor], eps: float,
+                           rope: Optional[RopeGridSpec], kv: Optional[KvCacheView], local_start: int,
+                           dim: int, q_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q_out = RoPE(RMSNorm(q)*wq); cache[local_start + r] <- (RoPE(RMSNorm(k)*wk), v)."""
+    lib = _hip.load()
+    rows, _, ld = _rows2d(qkv, "qkv")
+    q_out = torch.empty(rows, dim, dtype=BF16, device=qkv.device) if q_out is None else q_out
+    rs = rope.struct() if rope is not None else None
+    ks = kv.struct() if kv is not None else None
+    _hip.check(lib.ifx_rmsnorm_rope_kv_append(
+        _dev(qkv, "qkv"), ld, _dev(q_out, "q_out"), _dev(wq, "wq"), _dev(wk, "wk") if wk is not None else None,
+        C.byref(rs) if rs is not None else None, C.byref(ks) if ks is not None else None,
+        int(local_start), rows, dim, eps, _stream()), "ifx_rmsnorm_rope_kv_append")
+    return q_out
+
+
+def attention(q: torch.Tensor, kv: KvCacheView, kv_len: int, scale: float = 0.0,
+              out: Optional[torch.Tensor] = None, return_lse: bool = False):
+    """softmax(q K^T * scale) V over cache slots [0, kv_len) read in place. q `[rows, heads, 128]`."""
+    lib = _hip.load()
+    assert q.dim() == 3 and q.is_contiguous()
+    rows, heads, hd = q.shape
+    out = torch.empty_like(q) if out is None else out
+    lse = torch.empty(heads, rows, dtype=torch.float32, device=q.device) if return_lse else None
+    ks = kv.struct()
+    _hip.check(lib.ifx_attn_fwd_paged(_dev(q, "q"), _dev(out, "out"),
+                                      _dev(lse, "lse", torch.float32) if lse is not None else None,
+                                      C.byref(ks), rows, heads, int(kv_len), float(scale), _stream()),
+               "ifx_attn_fwd_paged")
+    return (out, lse) if return_lse else out
+
+
+def lse_merge(out_a: torch.Tensor, lse_a: torch.Tensor, out_b: torch.Tensor, lse_b: torch.Tensor) -> None:
+    lib = _hip.load()
+    rows, heads, _ = out_a.shape
+    _hip.check(lib.ifx_lse_merge(_dev(out_a, "out_a"), _dev(lse_a, "lse_a", torch.float32), _dev(out_b, "out_b"),
+                                 _dev(lse_b, "lse_b", torch.float32), rows, heads, _stream()), "ifx_lse_merge")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = _hip.IFX_EPI_BIAS,
+           residual: Optional[torch.Tensor] = None, mod: Optional[torch.Tensor] = None, gate_slot: int = 0,
+           rows_per_group: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epilogue(x @ w.T + bias) on MFMA (ifx_gemm_bf16). x `[..., K]`, w `[N, K]`."""
+    lib = _hip.load()
+    M, K, ldx = _rows2d(x, "x")
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous()
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+    _, _, ldy = _rows2d(out, "out")
+    epi = _hip.Epilogue(epilogue, None, 0, None, 1, 0, 1)
+    if residual is not None:
+        _, _, ldr = _rows2d(residual, "residual")
+        epi.residual, epi.ld_res = _dev(residual, "residual"), ldr
+    if mod is not None:
+        assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
+        epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
+    _hip.check(lib.ifx_gemm_bf16(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
+                                 _dev(out, "out"), ldy, M, N, K, C.byref(epi), _stream()), "ifx_gemm_bf16")
+    return out
+
+
+def kv_roll(kv: KvCacheView, sink_tokens: int, evicted: int, rolled: int, scratch: torch.Tensor) -> None:
+    lib = _hip.load()
+    ks = kv.struct()
+    assert scratch.numel() >= rolled * kv.k.shape[1] * kv.k.shape[2]
+    _hip.check(lib.ifx_kv_roll(C.byref(ks), sink_tokens, evicted, rolled, _dev(scratch, "scratch"), _stream()),
+               "ifx_kv_roll")

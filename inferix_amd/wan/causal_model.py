@@ -1,0 +1,362 @@
+"""HipCausalWanModel — the causal Wan DiT denoise-step forward on MI355X.
+
+Drop-in for the inference path of the reference's `CausalWanModel`
+(inferix/models/self_forcing/causal_model.py:518-1026): same constructor arguments,
+same `state_dict` key names, same `forward(x, t, context, seq_len, kv_cache_meta=...,
+crossattn_cache_meta=..., current_start=..., kv_cache_manager=..., kv_cache_requests=...)`
+call and the same mutation contract on the KV cache and on `kv_cache_meta`
+(`global_end_index` / `local_end_index`, causal_model.py:277-329).
+
+Host code only orchestrates: every per-token op of the 30-layer stack is one of the
+hand-written gfx950 kernels behind the C-ABI (`inferix_amd.hip_ops`):
+
+    AdaLN-LN -> fused QKV GEMM -> fused RMSNorm+RoPE+KV-append -> paged flash attention
+    -> O GEMM (+gate+residual) -> affine LN -> q GEMM -> RMSNorm -> cross attention
+    -> O GEMM (+residual) -> AdaLN-LN -> FFN GEMM (+GELU) -> FFN GEMM (+gate+residual)
+
+13 launches per layer, the activation is updated in place, the KV cache is read in
+place through the manager's tensors (no per-layer fetch/stack/copy-back as in
+causal_model.py:416-441).  PyTorch is used for allocation, streams and the O(frames)
+glue: timestep embedding MLP (M = frames), modulation table add, patchify /
+unpatchify index permutes.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import _hip, hip_ops as ops
+from ..kvcache_manager import KVCacheManager, KVCacheRequest
+from ..kvcache_manager.model import SelfForcingKVCacheManagerFactory
+from . import components as C
+
+BF16 = torch.bfloat16
+
+
+class ParallelConfig:
+    """Mirror of inferix/models/wan_base/utils/parallel_config.py:3-30.  The reference raises when no
+    flash-attn wheel is importable; here the (only) backend is the in-tree HIP kernel."""
+
+    def __init__(self, ulysses_size=1, ring_size=1, local_rank=0, rank=0, world_size=1,
+                 ring_strategy="pass-kv", attn_backend=None):
+        from ..attention import collect_supported_attn
+        self.ulysses_size, self.ring_size = ulysses_size, ring_size
+        self.local_rank, self.rank, self.world_size = local_rank, rank, world_size
+        self.ring_strategy = ring_strategy
+        supported = collect_supported_attn()
+        if attn_backend is None:
+            attn_backend = "HipPagedFA"
+        if attn_backend not in supported:
+            raise ValueError(f"Specified attention backend '{attn_backend}' is not available. "
+                             f"Available backends: {list(supported)}")
+        self.attn_backend = attn_backend
+
+
+@dataclass
+class KVIndexStep:
+    local_start: int
+    local_end: int
+    global_end: int
+    evicted: int
+    rolled: int
+    sink_tokens: int
+
+
+def kv_index_update(global_end: int, local_end: int, current_start: int, num_new: int, cache_size: int,
+                    local_attn_size: int, sink_tokens: int) -> KVIndexStep:
+    """Integer slot arithmetic of one cache append (causal_model.py:277-300,328-329), host side, no
+    device sync.  Rolling branch iff a NEW block (current_end > global_end) does not fit."""
+    current_end = current_start + num_new
+    evicted = rolled = 0
+    if local_attn_size != -1 and current_end > global_end and num_new + local_end > cache_size:
+        evicted = num_new + local_end - cache_size
+        rolled = local_end - evicted - sink_tokens
+    new_local_end = local_end + current_end - global_end - evicted
+    return KVIndexStep(new_local_end - num_new, new_local_end, current_end, evicted, rolled, sink_tokens)
+
+
+class _Block:
+    """Per-layer handle: weights + the reference-named `kv_cache_manager` adapter attribute that the
+    pipeline uses (`generator.model.blocks[i].kv_cache_manager`, CausalInferencePipeline.py:463,485,500)."""
+
+    def __init__(self, layer_idx: int, num_heads: int, head_dim: int, enable_kv_offload: bool):
+        self.layer_idx = layer_idx
+        self.kv_cache_manager = SelfForcingKVCacheManagerFactory.create_manager(
+            layer_idx, num_heads, head_dim, enable_kv_offload=enable_kv_offload)
+        self.w: Dict[str, torch.Tensor] = {}
+
+
+class HipCausalWanModel(torch.nn.Module):
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, local_attn_size=-1,
+                 sink_size=0, qk_norm=True, cross_attn_norm=True, eps=1e-6, enable_kv_offload=False,
+                 parallel_config: Optional[ParallelConfig] = None, device="cuda"):
+        super().__init__()
+        if model_type != "t2v":
+            raise NotImplementedError("HipCausalWanModel: only the t2v cross-attention path is built")
+        if not (qk_norm and cross_attn_norm):
+            raise NotImplementedError("HipCausalWanModel: qk_norm and cross_attn_norm are always on (Wan2.1 config)")
+        if dim % num_heads or dim // num_heads != 128:
+            raise NotImplementedError("HipCausalWanModel: kernels are built for head_dim 128")
+        _hip.load()                                   # fail loudly if the HIP library is missing
+        self.model_type, self.patch_size, self.text_len = model_type, tuple(patch_size), text_len
+        self.in_dim, self.dim, self.ffn_dim, self.freq_dim = in_dim, dim, ffn_dim, freq_dim
+        self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
+        self.head_dim = dim // num_heads
+        self.local_attn_size, self.sink_size, self.eps = local_attn_size, sink_size, eps
+        self.qk_norm, self.cross_attn_norm = qk_norm, cross_attn_norm
+        self.enable_kv_offload = enable_kv_offload
+        self.parallel_config = parallel_config if parallel_config is not None else ParallelConfig()
+        self.num_frame_per_block = 1
+        self.independent_first_frame = False
+        self.device_ = torch.device(device)
+        self.blocks: List[_Block] = [_Block(i, num_heads, self.head_dim, enable_kv_offload) for i in range(num_layers)]
+        self.g: Dict[str, torch.Tensor] = {}         # non-block weights
+        self.mod_all: Optional[torch.Tensor] = None  # [L, 1, 6, dim]
+        self.freqs = C.rope_table(self.head_dim).to(self.device_)     # [1024, 64, 2] fp64
+        self._scratch: Dict[Tuple, torch.Tensor] = {}
+        self._roll_scratch: Optional[torch.Tensor] = None
+        self.cp = None                                # set by inferix_amd.sequence_parallel when world_size > 1
+
+    # ------------------------------------------------------------------ weights
+    def parameters(self, recurse: bool = True):       # `next(generator.parameters())` is used by the pipeline
+        for t in self.g.values():
+            yield t
+        for b in self.blocks:
+            yield from b.w.values()
+
+    def state_dict_keys(self) -> List[str]:
+        keys = ["patch_embedding.weight", "patch_embedding.bias"]
+        for n in ("text_embedding.0", "text_embedding.2", "time_embedding.0", "time_embedding.2", "time_projection.1"):
+            keys += [n + ".weight", n + ".bias"]
+        for i in range(self.num_layers):
+            p = f"blocks.{i}."
+            keys += [p + "modulation", p + "norm3.weight", p + "norm3.bias"]
+            for a in ("self_attn", "cross_attn"):
+                for n in ("q", "k", "v", "o"):
+                    keys += [p + f"{a}.{n}.weight", p + f"{a}.{n}.bias"]
+                keys += [p + f"{a}.norm_q.weight", p + f"{a}.norm_k.weight"]
+            keys += [p + "ffn.0.weight", p + "ffn.0.bias", p + "ffn.2.weight", p + "ffn.2.bias"]
+        keys += ["head.modulation", "head.head.weight", "head.head.bias"]
+        return keys
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
+        """Takes the reference's CausalWanModel state_dict (same key names) and packs it for the kernels:
+        bf16 on the GPU, q|k|v weights fused to one [3*dim, dim] matrix."""
+        missing = [k for k in self.state_dict_keys() if k not in sd]
+        if missing and strict:
+            raise KeyError(f"missing keys in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        dev = self.device_
+
+        def t(name):
+            return sd[name].detach().to(device=dev, dtype=BF16).contiguous()
+
+        g = self.g
+        g["patch_w"] = t("patch_embedding.weight").flatten(1).contiguous()       # [dim, C*pt*ph*pw]
+        g["patch_b"] = t("patch_embedding.bias")
+        for short, n in (("text0", "text_embedding.0"), ("text2", "text_embedding.2"), ("time0", "time_embedding.0"),
+                         ("time2", "time_embedding.2"), ("tproj", "time_projection.1"), ("head", "head.head")):
+            g[short + "_w"], g[short + "_b"] = t(n + ".weight"), t(n + ".bias")
+        g["head_mod"] = t("head.modulation")                                      # [1, 2, dim]
+        mods = []
+        for i, blk in enumerate(self.blocks):
+            p = f"blocks.{i}."
+            w = blk.w
+            w["qkv_w"] = torch.cat([t(p + f"self_attn.{n}.weight") for n in "qkv"], dim=0).contiguous()
+            w["qkv_b"] = torch.cat([t(p + f"self_attn.{n}.bias") for n in "qkv"], dim=0).contiguous()
+            w["nq"], w["nk"] = t(p + "self_attn.norm_q.weight"), t(p + "self_attn.norm_k.weight")
+            w["o_w"], w["o_b"] = t(p + "self_attn.o.weight"), t(p + "self_attn.o.bias")
+            w["n3_w"], w["n3_b"] = t(p + "norm3.weight"), t(p + "norm3.bias")
+            for n in "qkvo":
+                w[f"c{n}_w"], w[f"c{n}_b"] = t(p + f"cross_attn.{n}.weight"), t(p + f"cross_attn.{n}.bias")
+            w["cnq"], w["cnk"] = t(p + "cross_attn.norm_q.weight"), t(p + "cross_attn.norm_k.weight")
+            w["f0_w"], w["f0_b"] = t(p + "ffn.0.weight"), t(p + "ffn.0.bias")
+            w["f2_w"], w["f2_b"] = t(p + "ffn.2.weight"), t(p + "ffn.2.bias")
+            mods.append(t(p + "modulation"))
+        self.mod_all = torch.stack(mods, dim=0).contiguous()                      # [L, 1, 6, dim]
+        return self
+
+    # ------------------------------------------------------------------ helpers
+    def _buf(self, name: str, *shape) -> torch.Tensor:
+        key = (name, shape)
+        b = self._scratch.get(key)
+        if b is None:
+            b = torch.empty(*shape, dtype=BF16, device=self.device_)
+            self._scratch[key] = b
+        return b
+
+    @staticmethod
+    def _meta_int(v) -> int:
+        return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
+
+    @staticmethod
+    def _meta_set(meta: dict, key: str, value: int) -> None:
+        cur = meta.get(key)
+        if isinstance(cur, torch.Tensor):
+            cur.fill_(value)
+        else:
+            meta[key] = value
+
+    def _kv_view(self, mgr: KVCacheManager, req: KVCacheRequest, name: str) -> ops.KvCacheView:
+        t = mgr.get_raw(req, name)
+        if not t.is_cuda:
+            raise _hip.HipKernelError(
+                f"KV cache '{name}' lives on {t.device}: the HIP path reads pages in place from HBM "
+                "(create the model with enable_kv_offload=False)")
+        pt = mgr.page_table(req, name) if hasattr(mgr, "page_table") else None
+        if pt is not None:
+            return ops.KvCacheView.from_manager_tensor(t, pt.device, pt.page_size)
+        return ops.KvCacheView.from_manager_tensor(t)
+
+    def _evict(self, mgr, req, name: str, view: ops.KvCacheView, step: KVIndexStep) -> None:
+        """Sink + rolling eviction (causal_model.py:287-292): page-table rotation when the spans are page
+        aligned, otherwise the physical shift kernel."""
+        pt = mgr.page_table(req, name) if hasattr(mgr, "page_table") else None
+        if pt is not None and step.sink_tokens % pt.page_size == 0 and step.evicted % pt.page_size == 0 \
+                and step.rolled % pt.page_size == 0:
+            mgr.rotate_pages(req, name, step.sink_tokens // pt.page_size, step.evicted // pt.page_size,
+                             step.rolled // pt.page_size)
+            return
+        need = step.rolled * self.dim
+        if self._roll_scratch is None or self._roll_scratch.numel() < need:
+            self._roll_scratch = torch.empty(need, dtype=BF16, device=self.device_)
+        ops.kv_roll(view, step.sink_tokens, step.evicted, step.rolled, self._roll_scratch)
+
+    def _run_block(self, l: int, xact: torch.Tensor, El: torch.Tensor, st: dict, meta: dict, cmeta: dict,
+                   kv_cache_manager, kv_cache_requests) -> None:
+        """One CausalWanAttentionBlock (causal_model.py:384-484) on the in-place activation `xact` [B*N, dim];
+        `El` = (modulation + e0) of this layer, [B*Ft, 6, dim]."""
+        blk = self.blocks[l]
+        w = blk.w
+        d, H, hd = self.dim, self.num_heads, self.head_dim
+        B, N, rows_per_group, rope = st["B"], st["N"], st["rows_per_group"], st["rope"]
+        sink_tokens, current_start, ctx = st["sink_tokens"], st["current_start"], st["ctx"]
+        h = self._buf("h", B * N, d)
+        qkv = self._buf("qkv", B * N, 3 * d)
+        qb = self._buf("q", B * N, d)
+        ab = self._buf("a", B * N, d)
+        ub = self._buf("u", B * N, self.ffn_dim)
+        # ---------------- self attention ----------------
+        ops.layernorm(xact, self.eps, mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
+        ops.linear(h, w["qkv_w"], w["qkv_b"], out=qkv)
+        g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
+        step = None
+        for b, req in enumerate(kv_cache_requests):
+            name = blk.kv_cache_manager.self_name
+            view = self._kv_view(kv_cache_manager, req, name)
+            if self.cp is not None:
+                step = self.cp.self_attention(self, l, b, view, qkv[b * N:(b + 1) * N], qb[b * N:(b + 1) * N],
+                                              ab[b * N:(b + 1) * N], w, rope, current_start, g_end, l_end,
+                                              sink_tokens, kv_cache_manager, req, name)
+                continue
+            step = kv_index_update(g_end, l_end, current_start, N, view.k.shape[0], self.local_attn_size, sink_tokens)
+            if step.local_start < 0 or step.local_end > view.k.shape[0]:
+                raise _hip.HipKernelError(f"KV cache overflow: slots [{step.local_start}, {step.local_end}) of "
+                                          f"{view.k.shape[0]} (layer {l})")
+            if step.evicted:
+                self._evict(kv_cache_manager, req, name, view, step)
+                view = self._kv_view(kv_cache_manager, req, name)
+            ops.rmsnorm_rope_kv_append(qkv[b * N:(b + 1) * N], w["nq"], w["nk"], self.eps, rope, view,
+                                       step.local_start, d, q_out=qb[b * N:(b + 1) * N])
+            ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end,
+                          out=ab[b * N:(b + 1) * N].view(N, H, hd))
+        self._meta_set(meta, "global_end_index", step.global_end)
+        self._meta_set(meta, "local_end_index", step.local_end)
+        ops.linear(ab, w["o_w"], w["o_b"], epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
+                   rows_per_group=rows_per_group, out=xact)
+        # ---------------- cross attention ----------------
+        ops.layernorm(xact, self.eps, gamma=w["n3_w"], beta=w["n3_b"], out=h)
+        ops.linear(h, w["cq_w"], w["cq_b"], out=qb)
+        ops.rmsnorm(qb, w["cnq"], self.eps, out=qb)
+        for b, req in enumerate(kv_cache_requests):
+            cview = self._kv_view(kv_cache_manager, req, blk.kv_cache_manager.cross_name)
+            if not cmeta["is_init"]:
+                cb = ctx[b * self.text_len:(b + 1) * self.text_len]
+                kx = ops.linear(cb, w["ck_w"], w["ck_b"])
+                ops.rmsnorm(kx, w["cnk"], self.eps, out=cview.k.view(self.text_len, d))
+                ops.linear(cb, w["cv_w"], w["cv_b"], out=cview.v.view(self.text_len, d))
+            ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), cview, self.text_len,
+                          out=ab[b * N:(b + 1) * N].view(N, H, hd))
+        cmeta["is_init"] = True
+        ops.linear(ab, w["co_w"], w["co_b"], epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
+        # ---------------- feed forward ----------------
+        ops.layernorm(xact, self.eps, mod=El, shift_slot=3, scale_slot=4, rows_per_group=rows_per_group, out=h)
+        ops.linear(h, w["f0_w"], w["f0_b"], epilogue=_hip.IFX_EPI_GELU_TANH, out=ub)
+        ops.linear(ub, w["f2_w"], w["f2_b"], epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=5,
+                   rows_per_group=rows_per_group, out=xact)
+
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, t, context, seq_len=None, clip_fea=None, y=None, kv_cache_meta=None,
+                crossattn_cache_meta=None, current_start: int = 0, cache_start=None,
+                kv_cache_manager: Optional[KVCacheManager] = None,
+                kv_cache_requests: Optional[Sequence[KVCacheRequest]] = None) -> torch.Tensor:
+        """x: [B, C, F, H, W] tensor (or list of [C, F, H, W]); t: [B, F]; context: [B, L, text_dim] tensor or
+        list of [L_i, text_dim].  Returns the flow prediction [B, C_out, F, H, W] (bf16)."""
+        if kv_cache_meta is None:
+            raise NotImplementedError("HipCausalWanModel implements the KV-cached inference path only")
+        assert kv_cache_manager is not None and kv_cache_requests is not None
+        if self.mod_all is None:
+            raise RuntimeError("HipCausalWanModel: weights not loaded (call load_state_dict first)")
+        dev, d, L = self.device_, self.dim, self.num_layers
+        lat = torch.stack(list(x)) if not isinstance(x, torch.Tensor) else x
+        lat = lat.to(device=dev, dtype=BF16)
+        B, _, nf, hh, ww = lat.shape
+        pt_, ph, pw = self.patch_size
+        grid = (nf // pt_, hh // ph, ww // pw)
+        F_, fs = grid[0], grid[1] * grid[2]
+        cp_ws = self.parallel_config.world_size
+        cp_rank = self.parallel_config.rank
+        hw_local = fs // cp_ws
+        fs_l = hw_local                               # tokens per frame on this rank
+        N = F_ * fs_l                                 # tokens per sample on this rank
+        assert len(kv_cache_requests) == B
+
+        # ---- embeddings ------------------------------------------------------------------
+        patches = C.patchify(lat, self.patch_size)                               # [B*F*fs, 64]
+        if cp_ws > 1:                                                            # keep hw-slice `rank` of every frame
+            patches = patches.view(B * F_, fs, -1)[:, cp_rank * hw_local:(cp_rank + 1) * hw_local].reshape(B * N, -1)
+        xact = ops.linear(patches.contiguous(), self.g["patch_w"], self.g["patch_b"], out=self._buf("x", B * N, d))
+        t = t.to(dev)
+        emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]
+        e = F.linear(F.silu(F.linear(emb, self.g["time0_w"], self.g["time0_b"])), self.g["time2_w"], self.g["time2_b"])
+        e0 = F.linear(F.silu(e), self.g["tproj_w"], self.g["tproj_b"]).unflatten(1, (6, d))   # [B*Ft, 6, d]
+        Ft = t.shape[1]                                                          # frames carrying a timestep (F or 1)
+        rows_per_group = (F_ // Ft) * fs_l
+        E = (self.mod_all + e0.unsqueeze(0)).contiguous()                        # [L, B*Ft, 6, d] bf16
+        eh = (self.g["head_mod"] + e.unsqueeze(1)).contiguous()                  # [B*Ft, 2, d]
+
+        need_ctx = any(not m["is_init"] for m in crossattn_cache_meta)
+        ctx = None
+        if need_ctx:
+            if isinstance(context, torch.Tensor):
+                context = list(context)
+            padded = torch.stack([torch.cat([u.to(dev, BF16), torch.zeros(self.text_len - u.size(0), u.size(1),
+                                                                       device=dev, dtype=BF16)]) for u in context])
+            c0 = ops.linear(padded.view(B * self.text_len, -1), self.g["text0_w"], self.g["text0_b"],
+                            epilogue=_hip.IFX_EPI_GELU_TANH)
+            ctx = ops.linear(c0, self.g["text2_w"], self.g["text2_b"])           # [B*text_len, d]
+
+        # ---- scratch ---------------------------------------------------------------------
+        h = self._buf("h", B * N, d)
+        start_frame = current_start // fs
+        rope = ops.RopeGridSpec(self.freqs, start_frame, grid[1], grid[2], cp_rank * hw_local, hw_local)
+        sink_tokens = self.sink_size * fs
+
+        st = dict(B=B, N=N, F_=F_, fs=fs, rows_per_group=rows_per_group, rope=rope, sink_tokens=sink_tokens,
+                  current_start=current_start, ctx=ctx)
+        for l in range(L):
+            self._run_block(l, xact, E[l], st, kv_cache_meta[l], crossattn_cache_meta[l], kv_cache_manager,
+                            kv_cache_requests)
+
+        # ---- head -------------------------------------------------------------------------
+        ops.layernorm(xact, self.eps, mod=eh, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
+        yv = ops.linear(h, self.g["head_w"], self.g["head_b"])                   # [B*N, out*prod(patch)]
+        if self.cp is not None:
+            yv = self.cp.gather_head(yv, B, F_)
+        return C.unpatchify(yv, B, grid, self.patch_size, self.out_dim)

@@ -1,0 +1,89 @@
+"""HipWanDiffusionWrapper — one denoise step = model forward + flow->x0.
+
+Mirror of `WanDiffusionWrapper` (inferix/models/self_forcing/wrapper.py:171-398): the generator object that
+`CausalInferencePipeline(..., generator=...)` accepts.  Same `forward` keyword signature and return
+`(flow_pred, pred_x0)` `[B, F, C, H, W]`; `.model`, `.get_scheduler()`, `.parameters()` as the pipeline uses."""
+from __future__ import annotations
+
+import json
+import os
+from typing import List, Optional
+
+import torch
+
+from ..kvcache_manager import KVCacheManager, KVCacheRequest
+from ..schedulers import FlowMatchScheduler
+from .causal_model import HipCausalWanModel, ParallelConfig
+
+
+class HipWanDiffusionWrapper(torch.nn.Module):
+    def __init__(self, model: Optional[HipCausalWanModel] = None, model_path: Optional[str] = None,
+                 model_name: str = "Wan2.1-T2V-1.3B", timestep_shift: float = 8.0, is_causal: bool = True,
+                 local_attn_size: int = -1, sink_size: int = 0, enable_kv_offload: bool = False,
+                 parallel_config: Optional[ParallelConfig] = None, device="cuda"):
+        super().__init__()
+        if not is_causal:
+            raise NotImplementedError("only the causal (KV-cached) generator is built")
+        self.parallel_config = parallel_config if parallel_config is not None else ParallelConfig()
+        self.enable_kv_offload = enable_kv_offload
+        if model is None:
+            if model_path is None or not os.path.exists(model_path):
+                raise FileNotFoundError(f"Model path not found: {model_path}")
+            model = self.load_pretrained(model_path, local_attn_size=local_attn_size, sink_size=sink_size,
+                                         parallel_config=self.parallel_config, device=device)
+        self.model = model
+        self.uniform_timestep = False
+        self.scheduler = FlowMatchScheduler(shift=timestep_shift, sigma_min=0.0, extra_one_step=True)
+        self.scheduler.set_timesteps(1000, training=True)
+        self.seq_len = 32760
+        self._sig64 = None
+
+    @staticmethod
+    def load_pretrained(model_path: str, **kw) -> HipCausalWanModel:
+        """diffusers-style directory: config.json + *.safetensors with the reference's key names."""
+        from safetensors.torch import load_file
+        with open(os.path.join(model_path, "config.json")) as f:
+            cfg = json.load(f)
+        keys = ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim",
+                "out_dim", "num_heads", "num_layers", "eps")
+        model = HipCausalWanModel(**{k: cfg[k] for k in keys if k in cfg}, **kw)
+        sd = {}
+        for fn in sorted(os.listdir(model_path)):
+            if fn.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(model_path, fn)))
+        return model.load_state_dict(sd)
+
+    def parameters(self, recurse: bool = True):
+        return self.model.parameters()
+
+    def get_scheduler(self) -> FlowMatchScheduler:
+        return self.scheduler
+
+    def _convert_flow_pred_to_x0(self, flow_pred: torch.Tensor, xt: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+        """x0 = x_t - sigma_t * flow in fp64, sigma picked by nearest timestep (wrapper.py:259-283)."""
+        dev = flow_pred.device
+        if self._sig64 is None or self._sig64[0].device != dev:
+            self._sig64 = (self.scheduler.sigmas.double().to(dev), self.scheduler.timesteps.double().to(dev))
+        sig, ts = self._sig64
+        idx = torch.argmin((ts.unsqueeze(0) - timestep.to(dev).double().unsqueeze(1)).abs(), dim=1)
+        return (xt.double() - sig[idx].reshape(-1, 1, 1, 1) * flow_pred.double()).to(flow_pred.dtype)
+
+    @torch.no_grad()
+    def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
+                kv_cache_meta: Optional[List[dict]] = None, crossattn_cache_meta: Optional[List[dict]] = None,
+                current_start: Optional[int] = None, classify_mode: Optional[bool] = False,
+                concat_time_embeddings: Optional[bool] = False, clean_x: Optional[torch.Tensor] = None,
+                aug_t: Optional[torch.Tensor] = None, cache_start: Optional[int] = None,
+                kv_cache_manager: Optional[KVCacheManager] = None,
+                kv_cache_requests: Optional[List[KVCacheRequest]] = None):
+        if kv_cache_meta is None or classify_mode or clean_x is not None:
+            raise NotImplementedError("HipWanDiffusionWrapper implements the KV-cached inference call only")
+        flow = self.model(noisy_image_or_video.permute(0, 2, 1, 3, 4), t=timestep,
+                          context=conditional_dict["prompt_embeds"], seq_len=self.seq_len,
+                          kv_cache_meta=kv_cache_meta, crossattn_cache_meta=crossattn_cache_meta,
+                          current_start=current_start, cache_start=cache_start,
+                          kv_cache_manager=kv_cache_manager, kv_cache_requests=kv_cache_requests
+                          ).permute(0, 2, 1, 3, 4)
+        x0 = self._convert_flow_pred_to_x0(flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1).to(flow.device),
+                                           timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])
+        return flow, x0

@@ -1,0 +1,297 @@
+"""GPU parity tests: every C-ABI kernel of libinferix_hip.so against the CPU oracle on identical
+seeded inputs (teacher-forced per op).  Run on the MI355X box: pytest -m gpu."""
+import math
+
+import pytest
+import torch
+
+import wan_oracle as O
+from util import assert_bf16_parity, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from inferix_amd import hip_ops
+    return hip_ops
+
+
+def gpu(t):
+    return t.cuda()
+
+
+def rnd(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("rows,dim,fs", [(72, 256, 24), (4680, 1536, 1560), (77, 1536, 77), (9, 2048, 3)])
+def test_layernorm_modes(ops, rows, dim, fs):
+    g = torch.Generator().manual_seed(rows + dim)
+    x = rnd(g, 1, rows, dim, scale=2.0)
+    groups = (rows + fs - 1) // fs
+    # plain
+    got = ops.layernorm(gpu(x), 1e-6)
+    assert_bf16_parity(got, O.layer_norm(x, 1e-6), what="LN plain")
+    # affine (norm3)
+    w, b = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF), (0.1 * torch.randn(dim, generator=g)).to(BF)
+    got = ops.layernorm(gpu(x), 1e-6, gamma=gpu(w), beta=gpu(b))
+    assert_bf16_parity(got, O.layer_norm(x, 1e-6, w, b), what="LN affine")
+    # AdaLN modulate with per-frame rows of (modulation + e0)
+    if rows % fs == 0:
+        mod = rnd(g, groups, 6, dim, scale=0.5)
+        e = mod.unsqueeze(0).chunk(6, dim=2)            # [1, groups, 1, dim] each
+        for shift_slot, scale_slot in ((0, 1), (3, 4)):
+            ref = O.modulate(O.layer_norm(x, 1e-6), e[scale_slot], e[shift_slot], groups)
+            got = ops.layernorm(gpu(x), 1e-6, mod=gpu(mod), shift_slot=shift_slot, scale_slot=scale_slot,
+                                rows_per_group=fs)
+            assert_bf16_parity(got, ref, max_ulp=2, floor=1.0, what=f"AdaLN slots {shift_slot},{scale_slot}")
+
+
+def test_layernorm_golden(ops):
+    from fixture_io import golden
+    fx = golden("ops.npz")
+    xn = fx["norm_x"]
+    assert_bf16_parity(ops.layernorm(gpu(xn), 1e-6), fx["ln_out"], what="golden LN")
+    assert_bf16_parity(ops.layernorm(gpu(xn), 1e-6, gamma=gpu(fx["rms_w"]), beta=gpu(fx["ln_b"])),
+                       fx["ln_affine_out"], what="golden LN affine")
+    mod = (fx["mod"].unsqueeze(1) + fx["e0"]).flatten(0, 1)          # [B*F, 6, dim]
+    got = ops.layernorm(gpu(xn), 1e-6, mod=gpu(mod.contiguous()), shift_slot=0, scale_slot=1, rows_per_group=16)
+    assert_bf16_parity(got, fx["modulate_out"], floor=1.0, what="golden modulate")
+    assert_bf16_parity(ops.rmsnorm(gpu(xn), gpu(fx["rms_w"]), 1e-6), fx["rms_out"], what="golden RMSNorm")
+
+
+@pytest.mark.parametrize("rows,dim", [(72, 256), (4680, 1536), (513, 1536)])
+def test_rmsnorm(ops, rows, dim):
+    g = torch.Generator().manual_seed(rows)
+    x = rnd(g, rows, dim, scale=3.0)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    assert_bf16_parity(ops.rmsnorm(gpu(x), gpu(w), 1e-6), O.rms_norm(x, w, 1e-6), what="RMSNorm")
+
+
+@pytest.mark.parametrize("heads,grid,start_frame,ws,rank", [
+    (2, (3, 4, 6), 0, 1, 0), (2, (3, 4, 6), 5, 1, 0), (12, (3, 4, 6), 2, 1, 0),
+    (2, (3, 4, 6), 3, 2, 1), (2, (3, 4, 6), 3, 4, 3), (12, (3, 30, 52), 18, 1, 0)])
+def test_rmsnorm_rope_kv_append(ops, heads, grid, start_frame, ws, rank):
+    hd = 128
+    dim = heads * hd
+    f, h, w = grid
+    hw_local = h * w // ws
+    rows = f * hw_local
+    g = torch.Generator().manual_seed(heads * 100 + start_frame + ws)
+    qkv = rnd(g, rows, 3 * dim, scale=2.0)
+    wq = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    wk = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    freqs = O.rope_freqs(hd)
+    q, k, v = qkv.split(dim, dim=1)
+    rq = O.causal_rope_apply(O.rms_norm(q, wq, 1e-6).view(1, rows, heads, hd), grid, freqs, start_frame, ws, rank)
+    rk = O.causal_rope_apply(O.rms_norm(k, wk, 1e-6).view(1, rows, heads, hd), grid, freqs, start_frame, ws, rank)
+    cap = rows * 2 + 5
+    local_start = rows // 2 + 3
+    kc = torch.zeros(cap, heads, hd, dtype=BF, device="cuda")
+    vc = torch.zeros(cap, heads, hd, dtype=BF, device="cuda")
+    rope = ops.RopeGridSpec(torch.view_as_real(freqs).contiguous().cuda(), start_frame, h, w, rank * hw_local, hw_local)
+    qo = ops.rmsnorm_rope_kv_append(gpu(qkv), gpu(wq), gpu(wk), 1e-6, rope, ops.KvCacheView(kc, vc), local_start, dim)
+    assert_bf16_parity(qo.view(rows, heads, hd), rq[0], max_ulp=2, floor=1.0, what="roped q")
+    assert_bf16_parity(kc[local_start:local_start + rows], rk[0], max_ulp=2, floor=1.0, what="cache K")
+    assert torch.equal(vc[local_start:local_start + rows].cpu(), v.reshape(rows, heads, hd)), "cache V must be bit-exact"
+    # slots outside [local_start, local_start+rows) untouched
+    assert float(kc[:local_start].abs().max()) == 0 and float(kc[local_start + rows:].abs().max()) == 0
+    # no-rope / no-append mode (cross-attention query)
+    qn = ops.rmsnorm_rope_kv_append(gpu(qkv), gpu(wq), None, 1e-6, None, None, 0, dim)
+    assert_bf16_parity(qn, O.rms_norm(q, wq, 1e-6), what="rmsnorm-only q")
+
+
+def test_rope_golden(ops):
+    """RoPE against the reference-generated vectors (identity RMSNorm: weight 1 and pre-normalised rows
+    cannot be arranged, so compare through the oracle-equal path on the same inputs instead)."""
+    from fixture_io import golden
+    fx = golden("ops.npz")
+    x = fx["rope_x"]                      # [2, 72, 2, 128]
+    freqs = O.rope_freqs(128)
+    dim = 256
+    ones = torch.ones(dim, dtype=BF)
+    for sf in (0, 5):
+        for b in range(2):
+            xb = x[b].reshape(72, dim)
+            qkv = torch.cat([xb, xb, xb], dim=1)
+            ref = O.causal_rope_apply(O.rms_norm(xb, ones, 1e-6).view(1, 72, 2, 128), (3, 4, 6), freqs, sf)
+            rope = ops.RopeGridSpec(torch.view_as_real(freqs).contiguous().cuda(), sf, 4, 6)
+            qo = ops.rmsnorm_rope_kv_append(gpu(qkv), gpu(ones), None, 1e-6, rope, None, 0, dim)
+            assert_bf16_parity(qo.view(72, 2, 128), ref[0], floor=1.0, what="rope golden path")
+
+
+def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None):
+    g = torch.Generator().manual_seed(seed + rows + kv_len)
+    hd = 128
+    q = rnd(g, rows, heads, hd)
+    k = rnd(g, kv_len, heads, hd)
+    v = rnd(g, kv_len, heads, hd)
+    cap = cap or kv_len
+    if page is None:
+        kc = torch.full((cap, heads, hd), float("nan"), dtype=BF)     # garbage beyond kv_len must not leak
+        vc = torch.full((cap, heads, hd), float("nan"), dtype=BF)
+        kc[:kv_len], vc[:kv_len] = k, v
+        view = ops.KvCacheView(gpu(kc), gpu(vc))
+    else:
+        ps = page
+        npg = (cap + ps - 1) // ps
+        perm = torch.randperm(npg, generator=g)
+        kc = torch.zeros(npg * ps, heads, hd, dtype=BF)
+        vc = torch.zeros(npg * ps, heads, hd, dtype=BF)
+        t = torch.arange(kv_len)
+        slot = perm[t // ps] * ps + t % ps
+        kc[slot], vc[slot] = k, v
+        view = ops.KvCacheView(gpu(kc), gpu(vc), gpu(perm.to(torch.int32)), ps)
+    out, lse = ops.attention(gpu(q), view, kv_len, return_lse=True)
+    torch.cuda.synchronize()
+    ref64, lse64 = O.attention_with_lse(q[None], k[None], v[None])
+    ref_bf = O.attention(q[None], k[None], v[None])            # the reference's CPU path (SDPA bf16)
+    err_gpu = (out.cpu().double() - ref64[0]).abs().max().item()
+    err_ref = (ref_bf[0].double() - ref64[0]).abs().max().item()
+    # stated tolerance: the HIP kernel is as close to exact (fp64) attention as the reference's own
+    # bf16 SDPA path is (x2 slack + 1 bf16 ulp of the output scale), and within 1e-3 rel-L2 of it... 
+    assert err_gpu <= 2 * err_ref + 4e-3, (err_gpu, err_ref)
+    assert rel_l2(out.cpu(), ref64[0]) <= max(1.5 * rel_l2(ref_bf[0], ref64[0]), 3e-3)
+    assert (lse.cpu().double() - lse64[0]).abs().max().item() < 2e-3
+    return out
+
+
+@pytest.mark.parametrize("rows,heads,kv_len", [(40, 2, 100), (128, 2, 64), (129, 2, 65), (72, 2, 216),
+                                                (32, 12, 1), (200, 12, 513), (72, 2, 63)])
+def test_attention_small(ops, rows, heads, kv_len):
+    _attn_case(ops, rows, heads, kv_len, cap=kv_len + 7)
+
+
+def test_attention_golden(ops):
+    from fixture_io import golden
+    fx = golden("ops.npz")
+    q, k, v = fx["attn_q"][0], fx["attn_k"][0], fx["attn_v"][0]
+    out = ops.attention(gpu(q), ops.KvCacheView(gpu(k), gpu(v)), k.shape[0])
+    ref64 = O.attention(q[None], k[None], v[None], impl="math")[0]
+    e_gpu = (out.cpu().double() - ref64).abs().max().item()
+    e_ref = (fx["attn_out"][0].double() - ref64).abs().max().item()
+    assert e_gpu <= 2 * e_ref + 4e-3
+    # two bf16-P flash-attention implementations differ by the rounding of P (2^-9 rel per probability):
+    # ~1.5e-3 rel-L2 on random data, the noise floor of the reference's own SDPA/FA path vs exact attention
+    assert_bf16_parity(out, fx["attn_out"][0], max_ulp=4, max_mismatch_frac=0.5, rel=3e-3, floor=1.0, what="attention vs reference SDPA")
+
+
+def test_attention_paged(ops):
+    _attn_case(ops, 72, 2, 200, cap=240, page=24)
+    _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
+
+
+def test_attention_480p_block_shapes(ops):
+    """Real tile geometry: 4680 queries x 12 heads over 1 and 2 cached blocks (CPU fp64 reference on a
+    row subset keeps this in seconds)."""
+    g = torch.Generator().manual_seed(1)
+    rows, heads, hd = 4680, 12, 128
+    for kv_len in (4680, 9360):
+        q = rnd(g, rows, heads, hd)
+        k = rnd(g, kv_len, heads, hd)
+        v = rnd(g, kv_len, heads, hd)
+        out = ops.attention(gpu(q), ops.KvCacheView(gpu(k), gpu(v)), kv_len)
+        sel = torch.cat([torch.arange(0, 64), torch.arange(2300, 2364), torch.arange(4616, 4680)])
+        ref64 = O.attention(q[sel][None], k[None], v[None], impl="math")[0]
+        ref_bf = O.attention(q[sel][None], k[None], v[None])[0]
+        e_gpu = (out[sel.cuda()].cpu().double() - ref64).abs().max().item()
+        e_ref = (ref_bf.double() - ref64).abs().max().item()
+        assert e_gpu <= 2 * e_ref + 2e-3, (kv_len, e_gpu, e_ref)
+
+
+def test_attention_softmax_spike(ops):
+    """Online-softmax rescale path: one key dominates late in the sequence (guide §5.4 rule 26)."""
+    g = torch.Generator().manual_seed(3)
+    rows, heads, kv_len, hd = 64, 2, 640, 128
+    q = rnd(g, rows, heads, hd)
+    k = rnd(g, kv_len, heads, hd)
+    v = rnd(g, kv_len, heads, hd)
+    k[500] = (q[5] * 4).to(BF)                 # huge score for query 5 at tile 7
+    k[10] = (q[40] * 6).to(BF)
+    out = ops.attention(gpu(q), ops.KvCacheView(gpu(k), gpu(v)), kv_len)
+    ref64 = O.attention(q[None], k[None], v[None], impl="math")[0]
+    assert (out.cpu().double() - ref64).abs().max().item() < 3e-2
+    assert rel_l2(out.cpu(), ref64) < 5e-3
+
+
+def test_lse_merge_split_kv_equals_full(ops):
+    g = torch.Generator().manual_seed(4)
+    rows, heads, kv_len, hd = 100, 2, 300, 128
+    q, k, v = rnd(g, rows, heads, hd), rnd(g, kv_len, heads, hd), rnd(g, kv_len, heads, hd)
+    full = ops.attention(gpu(q), ops.KvCacheView(gpu(k), gpu(v)), kv_len)
+    o1, l1 = ops.attention(gpu(q), ops.KvCacheView(gpu(k[:130].contiguous()), gpu(v[:130].contiguous())), 130, return_lse=True)
+    o2, l2 = ops.attention(gpu(q), ops.KvCacheView(gpu(k[130:].contiguous()), gpu(v[130:].contiguous())), 170, return_lse=True)
+    ops.lse_merge(o1, l1, o2, l2)
+    assert rel_l2(o1.cpu(), full.cpu()) < 4e-3
+    _, lse64 = O.attention_with_lse(q[None], k[None], v[None])
+    assert (l1.cpu().double() - lse64[0]).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(72, 256, 256), (77, 64, 64), (4680, 1536, 1536), (300, 640, 256),
+                                   (130, 256, 640), (4680, 64, 1536)])
+def test_gemm_bias(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+    got = ops.linear(gpu(x), gpu(w), gpu(b))
+    assert_bf16_parity(got, torch.nn.functional.linear(x, w, b), what=f"linear {M}x{N}x{K}")
+    got = ops.linear(gpu(x), gpu(w), None)
+    assert_bf16_parity(got, torch.nn.functional.linear(x, w), what="linear no bias")
+
+
+def test_gemm_epilogues(ops):
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(9)
+    M, N, K, fs = 144, 256, 640, 48
+    x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+    res = rnd(g, M, N)
+    mod = rnd(g, M // fs, 6, N, scale=0.5)
+    y = torch.nn.functional.linear(x, w, b)
+    got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_GELU_TANH)
+    assert_bf16_parity(got, torch.nn.functional.gelu(y, approximate="tanh"), floor=1.0, what="gelu epilogue")
+    got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_RESIDUAL, residual=gpu(res))
+    assert_bf16_parity(got, res + y, floor=1.0, what="residual epilogue")
+    for slot in (2, 5):
+        gate = mod[:, slot].unsqueeze(0).unsqueeze(2)           # [1, F, 1, N]
+        ref = O.gated_residual(res[None], y[None], gate, M // fs)[0]
+        got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_GATE_RES, residual=gpu(res), mod=gpu(mod),
+                         gate_slot=slot, rows_per_group=fs)
+        assert_bf16_parity(got, ref, floor=1.0, what=f"gate+residual epilogue slot {slot}")
+
+
+def test_gemm_ffn_real_shapes(ops):
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(10)
+    M, d, f = 1560, 1536, 8960
+    x, w1, b1 = rnd(g, M, d), rnd(g, f, d, scale=d ** -0.5), rnd(g, f, scale=0.1)
+    w2, b2 = rnd(g, d, f, scale=f ** -0.5), rnd(g, d, scale=0.1)
+    u = ops.linear(gpu(x), gpu(w1), gpu(b1), epilogue=_hip.IFX_EPI_GELU_TANH)
+    u_ref = torch.nn.functional.gelu(torch.nn.functional.linear(x, w1, b1), approximate="tanh")
+    assert_bf16_parity(u, u_ref, max_ulp=2, floor=1.0, what="ffn.0+gelu 1536->8960")
+    y = ops.linear(gpu(u_ref), gpu(w2), gpu(b2))
+    assert_bf16_parity(y, torch.nn.functional.linear(u_ref, w2, b2), what="ffn.2 8960->1536")
+
+
+def test_kv_roll(ops):
+    g = torch.Generator().manual_seed(12)
+    cap, heads, hd = 144, 2, 128
+    k, v = rnd(g, cap, heads, hd), rnd(g, cap, heads, hd)
+    sink, ev, rolled = 24, 72, 48
+    kk, vv = k.clone(), v.clone()
+    kk[sink:sink + rolled] = k[sink + ev:sink + ev + rolled]
+    vv[sink:sink + rolled] = v[sink + ev:sink + ev + rolled]
+    kg, vg = gpu(k), gpu(v)
+    ops.kv_roll(ops.KvCacheView(kg, vg), sink, ev, rolled, torch.empty(rolled * heads * hd, dtype=BF, device="cuda"))
+    assert torch.equal(kg.cpu(), kk) and torch.equal(vg.cpu(), vv)
+
+
+def test_errors_are_loud(ops):
+    from inferix_amd import _hip
+    x = torch.zeros(4, 100, dtype=BF, device="cuda")          # dim % 8 != 0
+    with pytest.raises(_hip.HipKernelError):
+        ops.layernorm(x, 1e-6)
+    with pytest.raises(_hip.HipKernelError):
+        ops.layernorm(torch.zeros(4, 128, dtype=BF), 1e-6)    # CPU tensor: refuse, no fallback
+    with pytest.raises(_hip.HipKernelError):
+        ops.linear(torch.zeros(4, 100, dtype=BF, device="cuda"), torch.zeros(8, 100, dtype=BF, device="cuda"), None)

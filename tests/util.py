@@ -1,0 +1,41 @@
+"""Comparison helpers shared by the parity tests."""
+import torch
+
+
+def bf16_ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Distance in bf16 ULPs (monotone integer mapping of the bit patterns)."""
+    def key(t):
+        i = t.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(i >= 0x8000, 0x8000 - i, i)
+    return (key(a.to(torch.bfloat16)) - key(b.to(torch.bfloat16))).abs()
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def assert_bf16_parity(got: torch.Tensor, ref: torch.Tensor, *, max_ulp=1, max_mismatch_frac=0.02, rel=1e-3,
+                       floor=0.05, what=""):
+    """The parity bar for one fused op on identical inputs (the stated bf16 tolerance of north_star):
+      * every element within `max_ulp` bf16 ULPs of the reference, where the ULP is taken at
+        max(|ref|, floor * tensor RMS) — fp32 reduction-order noise can flip one bf16 rounding of an
+        intermediate, and results of cancellations (x - mean, a*cos - b*sin, x + y*g, GELU tails) carry
+        that flip at the scale of their operands, so ops with such a stage are compared with floor=1
+        (one ULP of a typical element) and pure normalisations / dot products with floor=0.05;
+      * at most `max_mismatch_frac` of the elements differ at all;
+      * tensor-level relative L2 error <= `rel` (1e-3)."""
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
+    g, r0 = got.double(), ref.double()
+    rms = float(r0.pow(2).mean().sqrt())
+    tol = max_ulp * 2.0 ** -7 * torch.maximum(r0.abs(), torch.tensor(floor * rms, dtype=torch.float64))
+    diff = (g - r0).abs()
+    frac = float((diff > 0).double().mean())
+    r = rel_l2(got, ref)
+    worst = float((diff / tol).max())
+    assert worst <= 1.0, f"{what}: element error {worst:.2f}x the {max_ulp}-ulp bound (frac {frac:.4f}, rel {r:.2e})"
+    assert frac <= max_mismatch_frac, f"{what}: {frac:.4f} of elements differ (> {max_mismatch_frac})"
+    assert r <= rel, f"{what}: rel L2 {r:.3e} > {rel}"
+    return frac, r
