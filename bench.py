@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — Self-Forcing 480p block-diffusion denoising throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch of synthetic input: a 21-latent-frame clip
+(1 x 21 x 16 x 60 x 104), block_size 3 -> 7 blocks x (4 denoise steps + 1 clean-context re-run) = 35
+generator forwards of the 30-layer Wan2.1-1.3B causal DiT with a growing paged KV prefix
+(4680 ... 32760 keys).  Text encoder and VAE are outside the path (prompt embeddings are synthetic,
+decode_mode = NO_DECODE; the per-block callback receives latents).  Inputs/weights are resident in HBM
+before the timed region.
+
+N > 1: the clip is sharded along the per-frame spatial token axis (sequence/context parallel, RCCL K/V
+all-gather per layer) -> fixed total work, "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (driver contract) carrying `roofline` (block-causal attention kernel,
+MFMA-bound) and `cpu_baseline` (CPU oracle timed on the host cores, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# gfx950 peaks (MI355X_MICROARCH.md): dense bf16 MFMA ~2.5 PFLOP/s, HBM3E 8 TB/s
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBPS = 8000.0
+
+WAN_1_3B = dict(patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=1536, ffn_dim=8960, freq_dim=256,
+                text_dim=4096, out_dim=16, num_heads=12, num_layers=30, eps=1e-6)
+LATENT = (16, 60, 104)         # 480p: 480x832 pixels / 8
+FRAMES, BLOCK = 21, 3
+STEPS_LIST = [1000, 750, 500, 250]
+
+
+def build_pipeline(device, parallel_config=None, num_layers=None):
+    from inferix_amd.pipeline import CausalInferencePipeline
+    from inferix_amd.wan import HipCausalWanModel, HipWanDiffusionWrapper
+    from inferix_amd.wan.synthetic import synthetic_state_dict
+    cfg = dict(WAN_1_3B)
+    if num_layers:
+        cfg["num_layers"] = num_layers
+    model = HipCausalWanModel(**cfg, parallel_config=parallel_config, device=device)
+    model.load_state_dict(synthetic_state_dict(model, seed=0))
+    gen = HipWanDiffusionWrapper(model=model, timestep_shift=5.0, parallel_config=parallel_config)
+    args = SimpleNamespace(denoising_step_list=STEPS_LIST, warp_denoising_step=True, num_frame_per_block=BLOCK,
+                           independent_first_frame=False, context_noise=0, frame_seq_length=1560,
+                           kv_cache_tokens=32760)
+    g = torch.Generator().manual_seed(1)
+    pe = torch.zeros(1, 512, 4096)
+    pe[:, :40] = torch.randn(1, 40, 4096, generator=g)
+    pe = pe.to(torch.bfloat16).to(device)
+    pipe = CausalInferencePipeline(args, device, generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe},
+                                   vae=None, parallel_config=parallel_config)
+    return model, gen, pipe
+
+
+def cpu_baseline(budget_layers: int = 2):
+    """The CPU oracle (port of the reference's CPU/PyTorch path, parity-pinned to it) on this box's host
+    cores: `budget_layers` real-size layers of one block-0 forward (N = L_kv = 4680), extrapolated linearly to
+    30 layers x 35 forwards.  Attention cost growth with the prefix is ignored, which FAVOURS the CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import wan_oracle as O
+    cfg = O.WanConfig(num_layers=budget_layers)
+    W = O.init_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    fs = cfg.frame_seqlen
+    n = BLOCK * fs
+    x = torch.randn(1, n, cfg.dim, generator=g).to(torch.bfloat16)
+    e0 = (torch.randn(1, BLOCK, 6, cfg.dim, generator=g) * 0.5).to(torch.bfloat16)
+    ctx = torch.randn(1, cfg.text_len, cfg.dim, generator=g).to(torch.bfloat16)
+    state = O.CacheState.allocate(cfg, 1, torch.bfloat16, cache_tokens=n)
+    freqs = O.rope_freqs(cfg.head_dim)
+    grid = (BLOCK, 30, 52)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(budget_layers):
+            x = O.block_forward(x, e0, ctx, W, i, cfg, grid, freqs, state, 0)
+    dt = time.perf_counter() - t0
+    per_layer = dt / budget_layers
+    clip_s = per_layer * 30 * 35
+    return {"value": FRAMES / clip_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{budget_layers} of 30 layers of one block-0 denoise forward (N=L_kv=4680, real Wan-1.3B dims, "
+                      f"bf16 CPU oracle), {dt:.1f} s measured, x(30/{budget_layers}) layers x35 forwards; "
+                      "prefix growth ignored (favours CPU)",
+            "ms_per_layer_forward": per_layer * 1e3, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=0, help="debug: fewer layers (makes the result INVALID)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed clip with every kernel timed")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    pc = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        from inferix_amd.sequence_parallel import attach_sequence_parallel
+        from inferix_amd.wan import ParallelConfig
+        pc = ParallelConfig(rank=rank, world_size=world, local_rank=local_rank)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    model, gen, pipe = build_pipeline(device, pc, a.layers or None)
+    if world > 1:
+        attach_sequence_parallel(model, dist.group.WORLD)
+    g = torch.Generator().manual_seed(0)
+    noise = torch.randn(1, FRAMES, *LATENT, generator=g).to(torch.bfloat16).to(device)
+    kvm = KVCacheManager(device)
+    reqs = [KVCacheRequest("bench")]
+    fwd_ms = []                    # per generator forward, filled only when asked
+
+    def clip():
+        return pipe.inference(noise=noise, text_prompts=["synthetic"], kv_cache_manager=kvm, kv_cache_requests=reqs,
+                              decode_mode=DecodeMode.NO_DECODE, free_cache_before_vae=False)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        clip()
+    timer = ops.KernelTimer(names=("attn_self",))
+    ops.set_kernel_timer(timer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = clip()
+    sync()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out.float()).all()
+
+    ks = timer.summary().get("attn_self", dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+    attn_tflops = ks["flops"] / (ks["ms"] * 1e-3) / 1e12 if ks["ms"] else 0.0
+    forwards = a.steps * (FRAMES // BLOCK) * (len(STEPS_LIST) + 1)
+
+    # per-forward latency by block index (one extra untimed clip, events around each generator call)
+    per_block_ms = []
+    evs = []
+    orig = gen.forward
+
+    def timed_forward(**kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig(**kw)
+        e.record()
+        evs.append((kw["current_start"] // (BLOCK * 1560), s, e))
+        return r
+    gen.forward = timed_forward
+    breakdown = None
+    if a.kernel_breakdown:
+        allt = ops.KernelTimer(names=("attn_self", "attn_cross", "gemm", "layernorm", "rmsnorm_rope_append"))
+        ops.set_kernel_timer(allt)
+    clip()
+    torch.cuda.synchronize()
+    if a.kernel_breakdown:
+        ops.set_kernel_timer(None)
+        breakdown = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] and v["flops"] else None,
+                         "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] else None}
+                     for k, v in allt.summary().items()}
+    gen.forward = orig
+    nblk = FRAMES // BLOCK
+    for b in range(nblk):
+        ms = [s.elapsed_time(e) for (bi, s, e) in evs if bi == b]
+        per_block_ms.append(round(sum(ms) / len(ms), 3))
+    denoise_ms = [s.elapsed_time(e) for i, (bi, s, e) in enumerate(evs) if i % (len(STEPS_LIST) + 1) != len(STEPS_LIST)]
+
+    if rank == 0:
+        res = {
+            "metric": "latent_frames_per_sec",
+            "value": round(FRAMES * a.steps / dt, 4),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "Self-Forcing 480p bf16 (Wan2.1-T2V-1.3B causal DiT, 30 layers), block_size=3, "
+                                   "21 latent frames = 7 blocks x (4 denoise + 1 context) generator forwards, paged KV "
+                                   "prefix 4680..32760 keys, NO_DECODE (text encoder / VAE outside the path)",
+                       "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
+                       "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
+                       "layers": model.num_layers},
+            "ms_per_denoise_step": round(sum(denoise_ms) / len(denoise_ms), 3),
+            "ms_per_forward_by_block": per_block_ms,
+            "generator_forwards_timed": forwards,
+            "roofline": {"kernel": "ifx::attn_fwd_kernel (block-causal paged flash attention)", "bound": "mfma",
+                         "achieved": round(attn_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(attn_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / max(ks["launches"], 1), 4),
+                         "algorithmic_flops_per_launch": "4*N*L*d, N=4680/n_gpus, d=1536, L=(b+1)*4680",
+                         "algorithmic_gbps": round(ks["bytes"] / (ks["ms"] * 1e-3) / 1e9, 1) if ks["ms"] else None},
+        }
+        if a.layers:
+            res["config"]["INVALID"] = "debug run with fewer layers"
+        if breakdown:
+            res["kernel_breakdown"] = breakdown
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,7 +67,9 @@ typedef struct {
 
 /* ------------------------------------------------------------------------
  * Block-causal flash-attention forward over the cached prefix, KV read in place.
- *   out[r,h,:] = softmax_j(q[r,h,:]·K[j,h,:] * scale) · V[j,h,:],  j in [0, kv_len)
+ *   out[r,h,:] = softmax_j(q[r,h,:]·K[j,h,:] * scale) · V[j,h,:],  j in [kv_start, kv_len)
+ * (logical cache tokens; kv_start > 0 is the split-KV / sequence-parallel case whose partial results
+ * are combined with ifx_lse_merge)
  * No mask: block causality is realised by what is in the cache
  * (causal_model.py:307-315).  Replaces `attention()` / `flash_attention()`
  * (inferix/models/attention/flash_attention.py:42-200) and the registry backends'
@@ -78,7 +80,8 @@ typedef struct {
  * bf16 in, fp32 softmax/accumulate, P rounded to bf16 for the PV product, bf16 out.
  * ---------------------------------------------------------------------- */
 int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
-                       int32_t q_rows, int32_t heads, int32_t kv_len, float scale, void* stream);
+                       int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
+                       void* stream);
 
 /* Merge two partial attention results over disjoint key sets (split-KV / context
  * parallel).  Replaces update_out_and_lse_pass_q

@@ -9,6 +9,10 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch bundles its own libamdhip64: it MUST be in the process before libinferix_hip.so is dlopen'ed so
+# that both share one HIP runtime (loading /opt/rocm's copy first leaves torch without a device).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinferix_hip.so")
 
@@ -51,7 +55,7 @@ SIGNATURES = {
     "ifx_version": (C.c_int, []),
     "ifx_last_error": (C.c_char_p, []),
     "ifx_arch": (C.c_char_p, []),
-    "ifx_attn_fwd_paged": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _f32, _vp]),
+    "ifx_attn_fwd_paged": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _vp]),
     "ifx_lse_merge": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ifx_rmsnorm_rope_kv_append": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.POINTER(RopeGrid), C.POINTER(KvView),
                                              _i32, _i32, _i32, _f32, _vp]),

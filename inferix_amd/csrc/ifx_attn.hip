@@ -42,11 +42,13 @@ struct AttnArgs {
   const unsigned short* k;
   const unsigned short* v;
   KvAddr ka;
-  int q_rows, heads, kv_len, q_tiles, per_xcd, total;
+  int q_rows, heads, kv_start, kv_len, q_tiles, per_xcd, total;   // keys [kv_start, kv_len)
   float scale, scale_log2;
 };
 
-template <bool PAGED>
+// SHORT = cross-attention specialisation (kv_len <= 1024: the 512 cached text keys).  Same algorithm today;
+// a separate instantiation so that profiles separate it from the block-causal self-attention launches.
+template <bool PAGED, bool SHORT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[65536];   // [buf][K 16K | V 16K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   auto gload = [&](int t) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int key = t * KT + st_row + 16 * p;
+      const int key = A.kv_start + t * KT + st_row + 16 * p;
       if (key < A.kv_len) {
         const size_t off = (size_t)(PAGED ? A.ka.slot(key) : key) * row_stride;
         rk[p] = *reinterpret_cast<const u32x4*>(kbase + off);
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const int v_rowq = vi >> 2;                                  // == (row & 3) since key0 % 4 == 0
   const int v_in = (vg1 << 5) | ((vi & 3) << 3);               // byte offset inside the 64-byte chunk
 
-  const int NT = (A.kv_len + KT - 1) / KT;
+  const int nkeys = A.kv_len - A.kv_start;
+  const int NT = (nkeys + KT - 1) / KT;
   gload(0);
   lstore(0);
   __syncthreads();
@@ -146,13 +149,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
         s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[b], 0, 0, 0);
       }
     }
-    if (t == NT - 1 && (A.kv_len & (KT - 1))) {   // ragged last tile: keys >= kv_len get -inf
+    if (t == NT - 1 && (nkeys & (KT - 1))) {   // ragged last tile: keys >= kv_len get -inf
       const int kbase_idx = t * KT + 4 * hi;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kbase_idx + 32 * b + (r & 3) + 8 * (r >> 2) >= A.kv_len) s[b][r] = -INFINITY;
+          if (kbase_idx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) s[b][r] = -INFINITY;
     }
 
     // ---------------- online softmax (one query per lane column) ----------------
@@ -257,13 +260,14 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
 using namespace ifx;
 
 extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
-                                  int32_t q_rows, int32_t heads, int32_t kv_len, float scale, void* stream) {
+                                  int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
+                                  void* stream) {
   IFX_REQUIRE(q && out && kv && kv->k && kv->v, "ifx_attn_fwd_paged: null argument");
   IFX_REQUIRE(kv->head_dim == HD, "ifx_attn_fwd_paged: head_dim %d not built (128 only)", kv->head_dim);
   IFX_REQUIRE(heads > 0 && kv->kv_heads == heads, "ifx_attn_fwd_paged: heads %d vs kv_heads %d", heads,
               kv->kv_heads);
-  IFX_REQUIRE(q_rows >= 0 && kv_len > 0 && kv_len <= kv->num_slots,
-              "ifx_attn_fwd_paged: kv_len %d out of range (capacity %d)", kv_len, kv->num_slots);
+  IFX_REQUIRE(q_rows >= 0 && kv_start >= 0 && kv_len > kv_start && kv_len <= kv->num_slots,
+              "ifx_attn_fwd_paged: key range [%d, %d) out of range (capacity %d)", kv_start, kv_len, kv->num_slots);
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_paged: page_size must be > 0");
   if (q_rows == 0) return IFX_OK;
   AttnArgs a;
@@ -275,6 +279,7 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
   a.ka = KvAddr{kv->page_table, kv->page_size};
   a.q_rows = q_rows;
   a.heads = heads;
+  a.kv_start = kv_start;
   a.kv_len = kv_len;
   a.q_tiles = (q_rows + QT - 1) / QT;
   a.total = a.q_tiles * heads;
@@ -282,10 +287,14 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
   a.scale = scale > 0.f ? scale : 0.08838834764831845f;   // 1/sqrt(128)
   a.scale_log2 = a.scale * 1.4426950408889634f;
   const dim3 grid(a.per_xcd * 8), block(256);
-  if (kv->page_table)
-    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
+  const bool short_kv = kv_len - kv_start <= 1024;
+  if (kv->page_table) {
+    if (short_kv) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    if (short_kv) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
+  }
   return check_launch("ifx_attn_fwd_paged");
 }
 

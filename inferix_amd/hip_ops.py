@@ -17,6 +17,54 @@ from . import _hip
 BF16 = torch.bfloat16
 
 
+class KernelTimer:
+    """Optional per-launch timing with events recorded on the launch stream (torch's current stream, the one
+    every kernel here is enqueued on).  Used by bench.py for the roofline figures; off by default."""
+
+    def __init__(self, names=("attn_self",)):
+        self.names = set(names)
+        self.records = []            # (name, start_event, end_event, flops, bytes)
+
+    def wants(self, name: str) -> bool:
+        return name in self.names
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, fl, by in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = t
+
+
+class _timed:
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.on = _timer is not None and _timer.wants(name)
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if self.on:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record()
+            _timer.records.append((self.name, self.s, self.e, self.flops, self.nbytes))
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -98,8 +146,9 @@ def layernorm(x: torch.Tensor, eps: float, *, gamma=None, beta=None, mod=None, s
     else:
         mode = _hip.IFX_LN_PLAIN
         args = (None, None, None, 0, 0, 0, 1)
-    _hip.check(lib.ifx_layernorm(_dev(x, "x"), _dev(out, "out"), rows, dim, eps, mode, *args, _stream()),
-               "ifx_layernorm")
+    with _timed("layernorm", 0.0, 4.0 * rows * dim):
+        _hip.check(lib.ifx_layernorm(_dev(x, "x"), _dev(out, "out"), rows, dim, eps, mode, *args, _stream()),
+                   "ifx_layernorm")
     return out
 
 
@@ -122,26 +171,31 @@ def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[tor
     q_out = torch.empty(rows, dim, dtype=BF16, device=qkv.device) if q_out is None else q_out
     rs = rope.struct() if rope is not None else None
     ks = kv.struct() if kv is not None else None
-    _hip.check(lib.ifx_rmsnorm_rope_kv_append(
-        _dev(qkv, "qkv"), ld, _dev(q_out, "q_out"), _dev(wq, "wq"), _dev(wk, "wk") if wk is not None else None,
-        C.byref(rs) if rs is not None else None, C.byref(ks) if ks is not None else None,
-        int(local_start), rows, dim, eps, _stream()), "ifx_rmsnorm_rope_kv_append")
+    nb = 2.0 * rows * dim * (6 if kv is not None else 2)      # read q,k,v + write q,K,V  |  read q + write q
+    with _timed("rmsnorm_rope_append", 0.0, nb):
+        _hip.check(lib.ifx_rmsnorm_rope_kv_append(
+            _dev(qkv, "qkv"), ld, _dev(q_out, "q_out"), _dev(wq, "wq"), _dev(wk, "wk") if wk is not None else None,
+            C.byref(rs) if rs is not None else None, C.byref(ks) if ks is not None else None,
+            int(local_start), rows, dim, eps, _stream()), "ifx_rmsnorm_rope_kv_append")
     return q_out
 
 
 def attention(q: torch.Tensor, kv: KvCacheView, kv_len: int, scale: float = 0.0,
-              out: Optional[torch.Tensor] = None, return_lse: bool = False):
-    """softmax(q K^T * scale) V over cache slots [0, kv_len) read in place. q `[rows, heads, 128]`."""
+              out: Optional[torch.Tensor] = None, return_lse: bool = False, tag: str = "attn", kv_start: int = 0):
+    """softmax(q K^T * scale) V over logical cache tokens [kv_start, kv_len) read in place. q `[rows, heads, 128]`."""
     lib = _hip.load()
     assert q.dim() == 3 and q.is_contiguous()
     rows, heads, hd = q.shape
     out = torch.empty_like(q) if out is None else out
     lse = torch.empty(heads, rows, dtype=torch.float32, device=q.device) if return_lse else None
     ks = kv.struct()
-    _hip.check(lib.ifx_attn_fwd_paged(_dev(q, "q"), _dev(out, "out"),
-                                      _dev(lse, "lse", torch.float32) if lse is not None else None,
-                                      C.byref(ks), rows, heads, int(kv_len), float(scale), _stream()),
-               "ifx_attn_fwd_paged")
+    d = heads * hd
+    nk = kv_len - kv_start
+    with _timed(tag, 4.0 * rows * nk * d, 2.0 * (2 * rows * d + 2 * nk * d)):
+        _hip.check(lib.ifx_attn_fwd_paged(_dev(q, "q"), _dev(out, "out"),
+                                          _dev(lse, "lse", torch.float32) if lse is not None else None,
+                                          C.byref(ks), rows, heads, int(kv_start), int(kv_len), float(scale), _stream()),
+                   "ifx_attn_fwd_paged")
     return (out, lse) if return_lse else out
 
 
@@ -170,8 +224,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
     if mod is not None:
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
-    _hip.check(lib.ifx_gemm_bf16(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
-                                 _dev(out, "out"), ldy, M, N, K, C.byref(epi), _stream()), "ifx_gemm_bf16")
+    with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+        _hip.check(lib.ifx_gemm_bf16(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
+                                     _dev(out, "out"), ldy, M, N, K, C.byref(epi), _stream()), "ifx_gemm_bf16")
     return out
 
 

@@ -263,7 +263,7 @@ class HipCausalWanModel(torch.nn.Module):
             ops.rmsnorm_rope_kv_append(qkv[b * N:(b + 1) * N], w["nq"], w["nk"], self.eps, rope, view,
                                        step.local_start, d, q_out=qb[b * N:(b + 1) * N])
             ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end,
-                          out=ab[b * N:(b + 1) * N].view(N, H, hd))
+                          out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_self")
         self._meta_set(meta, "global_end_index", step.global_end)
         self._meta_set(meta, "local_end_index", step.local_end)
         ops.linear(ab, w["o_w"], w["o_b"], epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
@@ -280,7 +280,7 @@ class HipCausalWanModel(torch.nn.Module):
                 ops.rmsnorm(kx, w["cnk"], self.eps, out=cview.k.view(self.text_len, d))
                 ops.linear(cb, w["cv_w"], w["cv_b"], out=cview.v.view(self.text_len, d))
             ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), cview, self.text_len,
-                          out=ab[b * N:(b + 1) * N].view(N, H, hd))
+                          out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
         cmeta["is_init"] = True
         ops.linear(ab, w["co_w"], w["co_b"], epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
         # ---------------- feed forward ----------------

@@ -16,13 +16,16 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 def assert_bf16_parity(got: torch.Tensor, ref: torch.Tensor, *, max_ulp=1, max_mismatch_frac=0.02, rel=1e-3,
-                       floor=0.05, what=""):
+                       floor=0.05, scale=None, what=""):
     """The parity bar for one fused op on identical inputs (the stated bf16 tolerance of north_star):
       * every element within `max_ulp` bf16 ULPs of the reference, where the ULP is taken at
         max(|ref|, floor * tensor RMS) — fp32 reduction-order noise can flip one bf16 rounding of an
         intermediate, and results of cancellations (x - mean, a*cos - b*sin, x + y*g, GELU tails) carry
         that flip at the scale of their operands, so ops with such a stage are compared with floor=1
         (one ULP of a typical element) and pure normalisations / dot products with floor=0.05;
+        `scale` (optional, same shape) raises the per-element magnitude at which the ULP is taken to that of
+        the op's OPERANDS (e.g. the modulus of the rotated pair for RoPE: a rotation preserves it, so a one-ULP
+        flip of an operand shows up at that magnitude whatever the size of the individual output component);
       * at most `max_mismatch_frac` of the elements differ at all;
       * tensor-level relative L2 error <= `rel` (1e-3)."""
     got, ref = got.detach().cpu(), ref.detach().cpu()
@@ -30,7 +33,8 @@ def assert_bf16_parity(got: torch.Tensor, ref: torch.Tensor, *, max_ulp=1, max_m
     assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
     g, r0 = got.double(), ref.double()
     rms = float(r0.pow(2).mean().sqrt())
-    tol = max_ulp * 2.0 ** -7 * torch.maximum(r0.abs(), torch.tensor(floor * rms, dtype=torch.float64))
+    mag = r0.abs() if scale is None else torch.maximum(r0.abs(), scale.detach().cpu().double())
+    tol = max_ulp * 2.0 ** -7 * torch.maximum(mag, torch.tensor(floor * rms, dtype=torch.float64))
     diff = (g - r0).abs()
     frac = float((diff > 0).double().mean())
     r = rel_l2(got, ref)
@@ -39,3 +43,9 @@ def assert_bf16_parity(got: torch.Tensor, ref: torch.Tensor, *, max_ulp=1, max_m
     assert frac <= max_mismatch_frac, f"{what}: {frac:.4f} of elements differ (> {max_mismatch_frac})"
     assert r <= rel, f"{what}: rel L2 {r:.3e} > {rel}"
     return frac, r
+
+
+def pair_modulus(t: torch.Tensor) -> torch.Tensor:
+    """|(t[2i], t[2i+1])| broadcast back to both components (RoPE operand scale)."""
+    p = t.double().unflatten(-1, (-1, 2))
+    return p.norm(dim=-1, keepdim=True).expand_as(p).flatten(-2)
