@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Micro workload for PMC passes: the self-attention kernel and the block's GEMMs at the real 480p shapes
+(N=4680, d=1536, ffn=8960, 12 heads; prefix L = 4 blocks = 18720 keys), a few launches each."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from inferix_amd import _hip, hip_ops as ops  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "attn,gemm"
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 18720
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+N, H, D, d, f = 4680, 12, 128, 1536, 8960
+rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+if "attn" in which:
+    q, k, v = rnd(N, H, D), rnd(L, H, D), rnd(L, H, D)
+    for _ in range(reps):
+        ops.attention(q, ops.KvCacheView(k, v), L)
+if "gemm" in which:
+    x = rnd(N, d)
+    wqkv, wo, w1, w2 = rnd(3 * d, d), rnd(d, d), rnd(f, d), rnd(d, f)
+    b3, b1, bf_ = rnd(3 * d), rnd(d), rnd(f)
+    for _ in range(reps):
+        ops.linear(x, wqkv, b3)
+        ops.linear(x, wo, b1, epilogue=_hip.IFX_EPI_RESIDUAL, residual=x)
+        u = ops.linear(x, w1, bf_, epilogue=_hip.IFX_EPI_GELU_TANH)
+        ops.linear(u, w2, b1)
+if "norm" in which:
+    x = rnd(N, d)
+    mod = rnd(3, 6, d)
+    for _ in range(reps):
+        ops.layernorm(x, 1e-6, mod=mod, rows_per_group=1560)
+torch.cuda.synchronize()
+print("pmc_micro done", which, L)
