@@ -15,6 +15,8 @@
 // tile t+1 issued before the MFMAs of tile t); LDS rows are 128 B with the 16-byte
 // chunk index XOR-swizzled by (row & 7) so ds_read_b128 fragment reads are
 // bank-conflict free.  64 KiB LDS -> 2 workgroups per CU.
+#include <stdlib.h>
+
 #include "ifx_common.h"
 
 namespace ifx {
@@ -39,12 +41,22 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
                                                            const unsigned short* __restrict__ w,
                                                            unsigned short* __restrict__ y, int ldy, int M, int N,
-                                                           int K, int tiles_m, EpiArgs ea) {
+                                                           int K, int tiles_m, int tiles_n, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [buf][X|W][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  // XCD-aware grouped raster (see ifx_gemm_glds.hip): XCD (bid & 7) owns a contiguous id range; ids walk
+  // GM token-tiles then the next channel-tile, so co-resident workgroups share operand panels in L2.
+  constexpr int GM = 8;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const int t_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || t_id >= total) return;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
   const int m_base = tile_m * BM, n_base = tile_n * BN;
 
   // staging assignment: 4 chunks of 16 B per matrix per thread
@@ -159,6 +171,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
   }
 }
 
+int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
+                     int N, int K, int mode, const unsigned short* bias, const unsigned short* residual, int ld_res,
+                     const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group, hipStream_t s);
+
+// kernel selection: 0 = auto (LDS-DMA 256x128 kernel for M >= 1024, else the 128x128 kernel), 1 = force v1, 2 = force glds
+static int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("IFX_GEMM_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 }  // namespace ifx
 
 using namespace ifx;
@@ -184,8 +210,13 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
     ea.rows_per_group = epi->rows_per_group;
   }
   if (M == 0) return IFX_OK;
+  const int variant = gemm_variant();
+  const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0);
+  if (wide_ok && (variant == 2 || (variant == 0 && M >= 1024)))
+    return launch_gemm_glds(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots,
+                            ea.gate_slot, ea.rows_per_group, (hipStream_t)stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const dim3 grid(tiles_m * tiles_n), block(256);
+  const dim3 grid(((tiles_m * tiles_n + 7) / 8) * 8), block(256);
   const size_t lds = 65536;
   hipStream_t s = (hipStream_t)stream;
 #define IFX_LAUNCH_GEMM(E)                                                                                    \
@@ -196,7 +227,7 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
                                 (int)lds);                                                                    \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, ea);  \
+    hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, tiles_n, ea);  \
   } while (0)
   switch (mode) {
     case IFX_EPI_BIAS: IFX_LAUNCH_GEMM(IFX_EPI_BIAS); break;

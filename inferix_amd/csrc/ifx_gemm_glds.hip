@@ -1,0 +1,295 @@
+// bf16 linear layer, large-shape kernel (gfx950): 256(tokens) x 128(channels) x 64(K) tiles, 8 waves,
+// LDS-DMA staging (global_load_lds, 16 B/lane) into a 3-stage LDS ring with COUNTED vmcnt so that two
+// K-tiles stay in flight across the (single) barrier per K-tile.
+//
+//   y[M,N] = epilogue( x[M,K] @ W[N,K]^T + bias[N] )            (same contract as ifx_gemm.hip)
+//
+// Why this shape: the v1 kernel (128^2, register staging, 2 buffers) spends 39 % of its wave cycles in
+// s_waitcnt/s_barrier (profiles/r1_pmc_attn_gemm.md) because a register-staged double buffer must drain
+// its loads before every barrier.  Here:
+//   * LDS-DMA needs no staging VGPRs and no ds_write pass, so a third stage costs only LDS (3 x 48 KiB =
+//     144 of the CU's 160 KiB -> one 8-wave workgroup per CU, 2 waves per SIMD);
+//   * per K-tile: s_waitcnt vmcnt(6) [tile kt landed, tile kt+1 still in flight] -> s_barrier -> issue
+//     tile kt+2 -> 16 x ds_read_b128 + 16 x v_mfma_f32_32x32x16_bf16 per wave;
+//   * the DMA writes LDS lane-linearly (wave-uniform base + lane*16), so the bank-conflict swizzle is
+//     applied on the per-lane SOURCE address and on the fragment reads (same involution both sides):
+//     128-byte rows, 16-byte chunk index XOR ((row >> 1) & 7): conflict free for the 32-row fragments;
+//   * transposed tile (A-operand = W rows, B-operand = x rows): each lane owns 4 consecutive output
+//     channels of one token -> 8-byte epilogue accesses for bias / gate / residual / store;
+//   * XCD-aware tile order: each XCD works a contiguous token-fastest range so concurrently resident
+//     workgroups share W panels and walk x once per range in its L2.
+#include <stdlib.h>
+
+#include "ifx_common.h"
+
+namespace ifx {
+
+namespace g2 {
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int STAGE = (BM + BN) * BK * 2;   // 49152 B
+constexpr int NSTAGE = 3;
+constexpr int A_OFF = 0;                    // x tile  [256][128 B]
+constexpr int B_OFF = BM * BK * 2;          // W tile  [128][128 B]
+}  // namespace g2
+
+struct EpiArgs2 {
+  const unsigned short* bias;
+  const unsigned short* residual;
+  int ld_res;
+  const unsigned short* mod;
+  int mod_slots, gate_slot, rows_per_group;
+};
+
+__device__ __forceinline__ float gelu_tanh_f2(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                           const unsigned short* __restrict__ w,
+                                                           unsigned short* __restrict__ y, int ldy, int M, int N,
+                                                           int K, int tiles_m, int total, int per_xcd, EpiArgs2 ea, int ablate) {
+  using namespace g2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware order: XCD (bid & 7) owns tiles [xcd*per, (xcd+1)*per), token(m)-fastest
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int t_id = xcd * per_xcd + slot_i;
+  if (slot_i >= per_xcd || t_id >= total) return;
+  // grouped raster: consecutive ids walk GM token-tiles, then the next channel-tile -> the ~32 workgroups
+  // resident on one XCD form a GM x (32/GM) block of tiles sharing GM x-panels and 32/GM W-panels in its L2
+  // (v1's id = m-fastest order made every XCD touch every panel: 0.9-1.2 GB of memory-side fetches per GEMM).
+  constexpr int GM = 4;
+  const int tiles_n = total / tiles_m;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int wm = wave & 3, wn = wave >> 2;     // 4 x 2 waves, 64 x 64 each
+
+  // ---- LDS-DMA source addressing: one wave-instruction = 8 rows x 128 B; lane l -> row l>>3, physical
+  //      chunk l&7, which must hold LOGICAL chunk (l&7) ^ ((row>>1)&7)
+  const int r8 = lane >> 3, pc = lane & 7;
+  const unsigned short* src_a[4];
+  const unsigned short* src_b[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = (r * 8 + wave) * 8 + r8;                 // 0..255
+    const int lc = pc ^ ((row >> 1) & 7);
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + lc * 8;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = (r * 8 + wave) * 8 + r8;                 // 0..127
+    const int lc = pc ^ ((row >> 1) & 7);
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + lc * 8;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % NSTAGE) * STAGE;
+    const size_t ko = (size_t)kt * BK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko),
+                                       (lds_ptr_t)(st + A_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko),
+                                       (lds_ptr_t)(st + B_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = K / BK;
+  issue(0);
+  if (KT > 1) issue(1);
+
+  // fragment read addressing: row = base + (lane & 31), logical chunk 2*ks + (lane >> 5)
+  const int l31 = lane & 31, hi = lane >> 5;
+  int a_row_off[2], b_row_off[2], a_swz[2], b_swz[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wm * 64 + j * 32 + l31;
+    a_row_off[j] = A_OFF + row * 128;
+    a_swz[j] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wn * 64 + i * 32 + l31;
+    b_row_off[i] = B_OFF + row * 128;
+    b_swz[i] = (row >> 1) & 7;
+  }
+
+  // Ping-pong schedule: the two waves that share a SIMD (wave w and w+4) alternate roles every phase —
+  // one streams its 16 fragment reads of a K-tile from LDS into registers while the other runs its 16 MFMAs
+  // back to back from registers — so the matrix pipe of every SIMD always has a wave in its math phase.
+  //   barrier 2kt   : G0 issues DMA(kt+2), load(kt)   | G1 math(kt-1)
+  //   barrier 2kt+1 : G0 math(kt)                     | G1 issues DMA(kt+2), load(kt)
+  // Tile kt is read between barriers 2kt..2kt+2 and its ring slot is refilled (tile kt+3) after barrier
+  // 2kt+2 at the earliest; every LDS read is retired (lgkmcnt(0)) before the reading wave reaches a barrier.
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);       // 0: waves 0-3, 1: waves 4-7
+  bf16x8 fa[4][2], fb[4][2];
+  auto load_frags = [&](int kt) {
+    const unsigned char* st = smem + (kt % NSTAGE) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fb[ks][i] = *reinterpret_cast<const bf16x8*>(st + b_row_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fa[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_row_off[j] + ((c ^ a_swz[j]) << 4));
+    }
+  };
+  auto math = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // Both groups run the SAME straight-line loop; group 1 is shifted by one barrier (one phase), which is what
+  // makes the roles alternate.  Each wave waits for its own DMA pieces of the NEXT needed tile before every
+  // barrier (counted vmcnt: one tile stays in flight), so after a barrier the tile is complete for everyone.
+  // vmcnt discipline: tile kt is first read after barrier 2kt (by G0).  G0 retires its own pieces of tile kt
+  // just before that barrier (top of its iteration kt), G1 just before the same barrier (middle of ITS
+  // iteration kt-1) — one counted wait per wave per K-tile, issued 4 (G0) / 3 (G1) phases after the DMA.
+  if (grp == 1) {
+    if (KT > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // own pieces of tile 0 landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    if (grp == 0) {
+      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile kt landed (kt+1 in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < KT && !(ablate & 1)) issue(kt + 2);
+    if (!(ablate & 2)) load_frags(kt);
+    if (grp == 1) {
+      if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile kt+1 landed (kt+2 in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!(ablate & 4)) math();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue.  The MFMA layout gives each lane 4 consecutive channels of ONE token (32 tokens per
+  // instruction): stored directly that is 32 partial cache lines per store instruction (measured: ~40 us of
+  // a 117 us QKV GEMM).  Instead every wave transposes its 64x64 tile of v = bf16(acc + bias) through LDS
+  // (8 KiB per wave in the now idle ring; 16-byte chunk index XOR (token & 7): conflict-free b128 reads) and
+  // then reads/writes 8 tokens x 128 contiguous bytes per instruction: residual / gate loads and the output
+  // store are full 128-byte lines.  Rounding is unchanged (v is the bf16 Linear output in every epilogue).
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // every wave is done reading the ring
+  unsigned char* tw = smem + wave * 8192;                // [64 tokens][128 B]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int mrow = j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = i * 32 + g * 8 + hi * 4;           // channel within the wave tile (multiple of 4)
+        const int n = n_base + wn * 64 + nl;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (ea.bias && n < N) {
+          const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        const int chunk = (nl >> 3) ^ (mrow & 7);
+        *reinterpret_cast<u16x4*>(tw + mrow * 128 + chunk * 16 + (nl & 4) * 2) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private region: no barrier needed
+  {
+    const int rr = lane >> 3, cc = lane & 7;               // 8 tokens x 8 chunks of 16 B per instruction
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int mrow = p * 8 + rr;
+      const int m = m_base + wm * 64 + mrow;
+      const int n = n_base + wn * 64 + cc * 8;
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * 128 + ((cc ^ (mrow & 7)) << 4));
+      if (m >= M || n >= N) continue;
+      u16x8 o;
+      if (EPI == IFX_EPI_BIAS) {
+        o = vv;
+      } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+      } else {
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
+        if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + bf2f(vv[e]));
+        } else {
+          const u16x8 gv = *reinterpret_cast<const u16x8*>(
+              ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+        }
+      }
+      *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+    }
+  }
+}
+
+// host launcher used by ifx_gemm_bf16 (ifx_gemm.hip) for large shapes
+int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
+                     int N, int K, int mode, const unsigned short* bias, const unsigned short* residual, int ld_res,
+                     const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group, hipStream_t s) {
+  using namespace g2;
+  EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const dim3 grid(per_xcd * 8), block(512);
+  const size_t lds = (size_t)NSTAGE * STAGE;
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("IFX_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+#define IFX_LAUNCH_G2(E)                                                                                      \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                    \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_glds_kernel<E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
+                       per_xcd, ea, ablate);                                                                  \
+  } while (0)
+  switch (mode) {
+    case IFX_EPI_BIAS: IFX_LAUNCH_G2(IFX_EPI_BIAS); break;
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_G2(IFX_EPI_GELU_TANH); break;
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_G2(IFX_EPI_RESIDUAL); break;
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_G2(IFX_EPI_GATE_RES); break;
+    default: return IFX_EINVAL;
+  }
+#undef IFX_LAUNCH_G2
+  return check_launch("ifx_gemm_bf16(glds)");
+}
+
+}  // namespace ifx
