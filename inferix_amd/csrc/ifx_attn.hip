@@ -27,6 +27,9 @@
 //    256-byte layout, 64-byte chunk index XOR (row & 3): conflict free).
 //  * fp32 softmax with exp2 and the log2(e)-folded scale; P rounded to bf16 for PV
 //    (same as FA2 / SDPA); O normalised once at the end; optional LSE for split-KV merges.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "ifx_common.h"
 
 namespace ifx {
@@ -46,12 +49,42 @@ struct AttnArgs {
   float scale, scale_log2;
 };
 
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* attn_gbl_ptr_t;
+
+// single-instruction 3-input max (plain fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max per input)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max over the two half-waves that share a query column (lane, lane^32) without touching LDS:
+// v_permlane32_swap exchanges vdst[32..63] with src[0..31] (verified by tools/probe_layouts).  Done in asm:
+// the builtin called with two copies of one value is folded to a no-op by the optimiser.
+__device__ __forceinline__ float half_swap_max(float x) {
+  float a = x, b = x, r;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %2, %0, %1"
+               : "+v"(a), "+v"(b), "=v"(r));
+  return r;
+}
+
 // SHORT = cross-attention specialisation (kv_len <= 1024: the 512 cached text keys).  Same algorithm today;
 // a separate instantiation so that profiles separate it from the block-causal self-attention launches.
+//
+// v2 structure (round 1, second pass — v1 measured 34 % MFMA utilisation, profiles/r1_pmc_attn_gemm.md):
+//  * K/V tiles go global -> LDS by LDS-DMA (global_load_lds, 16 B/lane, 8 per wave per tile): no staging
+//    VGPRs, no ds_write pass; the XOR swizzles are applied on the per-lane SOURCE address (the DMA writes
+//    LDS lane-linearly) and on the fragment reads.  Tile t+1 is in flight during all of tile t.
+//  * the ragged last tile is peeled out of the main loop (no masking selects in the steady state);
+//  * O is rescaled only in tiles where some row's running max actually grows (exact: alpha == 1 otherwise);
+//  * K fragments of a 32-key block are fetched as one batch before its 8 MFMAs, V^T fragments 8 reads per
+//    4 MFMAs, so the LDS latency is paid once per batch and the MFMAs of a batch issue back to back
+//    (s_setprio 1 around them so the partner wave's VALU work does not starve the matrix pipe).
 template <bool PAGED, bool SHORT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[65536];   // [buf][K 16K | V 16K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
 
   // XCD-aware work mapping (speed only): XCD x owns work items [x*per, (x+1)*per), head-major
@@ -71,39 +104,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
 
-  // ---- staging map: 4 x 16-byte chunks of K and of V per thread per tile
-  const int st_row = tid >> 4, st_c = tid & 15;        // rows st_row + 16p, chunk st_c
-  int k_off[4], v_off[4];
+  // ---- LDS-DMA map: one wave instruction = 1 KiB = 4 key rows x 256 B; lane -> row (lane >> 4) of the
+  //      group, PHYSICAL 16-byte chunk pc = lane & 15.  K: physical chunk pc holds logical chunk
+  //      pc ^ (row & 15);  V: 64-byte chunk (pc >> 2) holds logical 64-byte chunk (pc >> 2) ^ (row & 3).
+  const int d_row = lane >> 4, d_pc = lane & 15;
+  int k_src_c[4], v_src_c[4], d_rowi[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int row = st_row + 16 * p;
-    k_off[p] = row * 256 + ((st_c ^ (row & 15)) << 4);
-    v_off[p] = row * 256 + ((((st_c >> 2) ^ (row & 3)) << 6) | ((st_c & 3) << 4));
+  for (int r = 0; r < 4; ++r) {
+    const int row = (r * 4 + wave) * 4 + d_row;           // 0..63 within the tile
+    d_rowi[r] = row;
+    k_src_c[r] = (d_pc ^ (row & 15)) * 8;                  // element offset inside the 128-element head row
+    v_src_c[r] = ((((d_pc >> 2) ^ (row & 3)) << 2) | (d_pc & 3)) * 8;
   }
-  const unsigned short* kbase = A.k + head * HD + st_c * 8;
-  const unsigned short* vbase = A.v + head * HD + st_c * 8;
-  u32x4 rk[4], rv[4];
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int key = A.kv_start + t * KT + st_row + 16 * p;
-      if (key < A.kv_len) {
-        const size_t off = (size_t)(PAGED ? A.ka.slot(key) : key) * row_stride;
-        rk[p] = *reinterpret_cast<const u32x4*>(kbase + off);
-        rv[p] = *reinterpret_cast<const u32x4*>(vbase + off);
-      } else {
-        rk[p] = u32x4{0, 0, 0, 0};
-        rv[p] = u32x4{0, 0, 0, 0};
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
+  const unsigned short* kbase = A.k + head * HD;
+  const unsigned short* vbase = A.v + head * HD;
+  const int last_key = A.kv_len - 1;
+  // issue<CLAMP=false>: steady-state tiles (all 64 keys valid) use one 64-bit add per piece
+  auto issue = [&](int t, int buf, auto clamp_tag) {
+    constexpr bool CLAMP = decltype(clamp_tag)::value;
     unsigned char* kb = smem + buf * 32768;
-    unsigned char* vb = kb + 16384;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<u32x4*>(kb + k_off[p]) = rk[p];
-      *reinterpret_cast<u32x4*>(vb + v_off[p]) = rv[p];
+    for (int r = 0; r < 4; ++r) {
+      int key = A.kv_start + t * KT + d_rowi[r];
+      if (CLAMP) key = min(key, last_key);                                 // ragged tail: re-read a valid row
+      const size_t off = (size_t)(PAGED ? A.ka.slot(key) : key) * row_stride;
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)(kbase + off + k_src_c[r]),
+                                       (attn_lds_ptr_t)(kb + (r * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)(vbase + off + v_src_c[r]),
+                                       (attn_lds_ptr_t)(kb + 16384 + (r * 4 + wave) * 1024), 16, 0, 0);
     }
   };
 
@@ -116,98 +144,155 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const float c2 = A.scale_log2;
 
   // per-lane LDS read bases
-  //  K A-operand: row = 32*blk + l31, 16-byte chunk (2*ks + hi) ^ (row & 15)   [(32*blk + l31) & 15 == l31 & 15]
   const int kswz = l31 & 15;
-  //  V^T A-operand (transpose read): in 16-lane group g = lane>>4, lane i = lane&15 supplies
-  //  row key0 + (i>>2), cols 32*db + 16*(g&1) + 4*(i&3);  key0 = 32*blk + 16*s + 4*hi (+8)
   const int vi = lane & 15, vg1 = (lane >> 4) & 1;
   const int v_rowq = vi >> 2;                                  // == (row & 3) since key0 % 4 == 0
   const int v_in = (vg1 << 5) | ((vi & 3) << 3);               // byte offset inside the 64-byte chunk
 
   const int nkeys = A.kv_len - A.kv_start;
   const int NT = (nkeys + KT - 1) / KT;
-  gload(0);
-  lstore(0);
-  __syncthreads();
 
-  for (int t = 0; t < NT; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < NT) gload(t + 1);
+  // ------------------------------------------------------------------------------------------------
+  // One 64-key tile = two 32-key blocks, software pipelined so that in every stage the wave has MFMAs
+  // AND independent VALU / LDS work to issue in their shadow:
+  //   stage A : S0 = K0 Q^T                       (K fragment batches double buffered: reads of batch i+1
+  //                                                 are in flight while the MFMAs of batch i run)
+  //   stage B : S1 = K1 Q^T   ||  softmax(block 0) + V^T fragment reads of block 0
+  //   stage C : O += V0^T P0^T || softmax(block 1) + V^T fragment reads of block 1
+  //   stage D : O += V1^T P1^T
+  // Online softmax runs per 32-key block; O is rescaled (in place) only when some row's max grew.
+  auto tile = [&](int t, int buf, auto ragged_tag) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     const unsigned char* kb = smem + buf * 32768;
     const unsigned char* vb = kb + 16384;
-
-    // ---------------- S^T = K Q^T ----------------
-    f32x16 s[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+    bf16x8 kA[4], kB[4], vA[4], vB[4];
+    auto ldK = [&](bf16x8(&f)[4], int b, int kh) {
       const unsigned char* krow = kb + (32 * b + l31) * 256;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hi) ^ kswz) << 4));
-        s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[b], 0, 0, 0);
-      }
-    }
-    if (t == NT - 1 && (nkeys & (KT - 1))) {   // ragged last tile: keys >= kv_len get -inf
-      const int kbase_idx = t * KT + 4 * hi;
+      for (int k4 = 0; k4 < 4; ++k4)
+        f[k4] = *reinterpret_cast<const bf16x8*>(krow + (((2 * (4 * kh + k4) + hi) ^ kswz) << 4));
+    };
+    auto mmaK = [&](f32x16& acc, bf16x8(&f)[4], int kh) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[k4], qf[4 * kh + k4], acc, 0, 0, 0);
+    };
+    auto ldV = [&](bf16x8(&f)[4], int b, int s2) {
+      const unsigned char* vr0 = vb + (32 * b + 16 * s2 + 4 * hi + v_rowq) * 256 + v_in;
+      const unsigned char* vr1 = vr0 + 8 * 256;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int ch = (d ^ v_rowq) << 6;
+        const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr0 + ch));
+        const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr1 + ch));
+        f[d] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    auto mmaV = [&](bf16x8(&f)[4], const bf16x8& p) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[d], p, o[d], 0, 0, 0);
+    };
+    // softmax of one 32-key block: returns alpha (1 when the running max did not move)
+    auto softmax_block = [&](f32x16& sb, int b, bf16x8(&pb)[2]) -> float {
+      if (RAGGED) {
+        const int kidx = t * KT + 32 * b + 4 * hi;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kbase_idx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) s[b][r] = -INFINITY;
-    }
-
-    // ---------------- online softmax (one query per lane column) ----------------
-    float mx = s[0][0];
+          if (kidx + (r & 3) + 8 * (r >> 2) >= nkeys) sb[r] = -INFINITY;
+      }
+      float mx = max3f(sb[0], sb[1], sb[2]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-    const float mc = m_new * c2;
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int r = 3; r < 15; r += 2) mx = max3f(mx, sb[r], sb[r + 1]);
+      mx = max3f(mx, sb[15], m_run);                    // m_new candidate for this half-wave
+      const float m_new = half_swap_max(mx);             // >= m_run, identical in lane and lane^32
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);   // exp2(-inf)=0 on the first block
+      m_run = m_new;
+      const float mc = m_new * c2;
+      float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[b][r] * c2 - mc);
-        psum += p;
-        pb[b][r >> 3][r & 7] = static_cast<__bf16>(p);
+        const float p = __builtin_amdgcn_exp2f(sb[r] * c2 - mc);
+        ps += p;
+        pb[r >> 3][r & 7] = static_cast<__bf16>(p);
       }
-    l_run = l_run * alpha + psum;
+      l_run = l_run * alpha + ps;
+      return alpha;
+    };
+    auto rescale_o = [&](float alpha) {
+      asm volatile("" : "+v"(alpha));       // pin the (rare) branch at the stage boundary: the test must not
+                                            // be hoisted into the stage and split its MFMA || VALU region
+      if (__any(alpha != 1.0f)) {          // wave-uniform branch; in-place so the common path moves nothing
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
-    // ---------------- O^T += V^T P^T ----------------
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int key0 = 32 * b + 16 * s2 + 4 * hi;
-        const unsigned char* vr0 = vb + (key0 + v_rowq) * 256 + v_in;
-        const unsigned char* vr1 = vr0 + 8 * 256;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int ch = (d ^ v_rowq) << 6;
-          const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (bf16x4 __attribute__((address_space(3)))*)(vr0 + ch));
-          const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (bf16x4 __attribute__((address_space(3)))*)(vr1 + ch));
-          const bf16x8 a = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[b][s2], o[d], 0, 0, 0);
-        }
+          for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[d][r]) : "v"(alpha));
       }
+    };
 
-    if (t + 1 < NT) lstore(buf ^ 1);
-    __syncthreads();
+    f32x16 s0, s1;
+    bf16x8 p0[2], p1[2];
+    // ---- stage A
+    ldK(kA, 0, 0);
+    ldK(kB, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
+    mmaK(s0, kA, 0);
+    ldK(kA, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mmaK(s0, kB, 1);
+    ldK(kB, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage B: QK(block 1) || softmax(block 0) ; V fragments of block 0 fetched underneath
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+    mmaK(s1, kA, 0);
+    ldV(vA, 0, 0);
+    mmaK(s1, kB, 1);
+    ldV(vB, 0, 1);
+    const float a0 = softmax_block(s0, 0, p0);
+    // shape the stage: each MFMA is followed by the VALU / LDS work that fits in its 32-cycle shadow
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // 10 VALU
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rescale_o(a0);
+    // ---- stage C: PV(block 0) || softmax(block 1) ; V fragments of block 1
+    mmaV(vA, p0[0]);
+    ldV(vA, 1, 0);
+    mmaV(vB, p0[1]);
+    ldV(vB, 1, 1);
+    const float a1 = softmax_block(s1, 1, p1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rescale_o(a1);
+    // ---- stage D
+    mmaV(vA, p1[0]);
+    mmaV(vB, p1[1]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  issue(0, 0, std::true_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < NT - 1; ++t) {
+    const int buf = t & 1;
+    if (t + 2 < NT) issue(t + 1, buf ^ 1, std::false_type{});   // slot buf^1 was last read in iteration t-1
+    else issue(t + 1, buf ^ 1, std::true_type{});               // the last tile may be ragged
+    tile(t, buf, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
+  if (nkeys & (KT - 1)) tile(NT - 1, (NT - 1) & 1, std::true_type{});
+  else tile(NT - 1, (NT - 1) & 1, std::false_type{});
 
   // ---------------- epilogue ----------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -286,6 +371,7 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
   a.per_xcd = (a.total + 7) / 8;
   a.scale = scale > 0.f ? scale : 0.08838834764831845f;   // 1/sqrt(128)
   a.scale_log2 = a.scale * 1.4426950408889634f;
+
   const dim3 grid(a.per_xcd * 8), block(256);
   const bool short_kv = kv_len - kv_start <= 1024;
   if (kv->page_table) {

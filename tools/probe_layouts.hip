@@ -12,8 +12,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__global__ void probe(float* o32a, float* o32b, float* o16a, float* o16b, short* otr_lin, short* otr_v) {
+__global__ void probe(float* o32a, float* o32b, float* o16a, float* o16b, short* otr_lin, short* otr_v, unsigned* osw) {
   const int lane = threadIdx.x;
+  {
+    // (4) v_permlane32_swap: vdst = lane, src = 100 + lane (distinct), and the x,x form used for a half-wave max
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)lane, (unsigned)(100 + lane), false, false);
+    osw[lane * 4 + 0] = r[0]; osw[lane * 4 + 1] = r[1];
+    unsigned u = 1000u + lane;
+    auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    osw[lane * 4 + 2] = q[0]; osw[lane * 4 + 3] = q[1];
+  }
   __shared__ __attribute__((aligned(16))) short lds[64 * 128];
   // ---- (1) 32x32x16: A[i][k] = i for all k ; B[k][n] = (k == 0 slot: lane>>5==0 && j==0) ? 1 : 0
   {
@@ -72,10 +80,10 @@ __global__ void probe(float* o32a, float* o32b, float* o16a, float* o16b, short*
 }
 
 int main() {
-  float *a, *b, *c, *d; short *e, *f;
+  float *a, *b, *c, *d; short *e, *f; unsigned* gsw; hipMalloc(&gsw, 64 * 4 * 4);
   hipMalloc(&a, 64 * 16 * 4); hipMalloc(&b, 64 * 16 * 4); hipMalloc(&c, 64 * 4 * 4); hipMalloc(&d, 64 * 4 * 4);
   hipMalloc(&e, 64 * 4 * 2); hipMalloc(&f, 32 * 64 * 4 * 2);
-  hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, a, b, c, d, e, f);
+  hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, a, b, c, d, e, f, gsw);
   if (hipDeviceSynchronize() != hipSuccess) { printf("probe: kernel failed\n"); return 2; }
   std::vector<float> ha(1024), hb(1024), hc(256), hd(256); std::vector<short> he(256), hf(32 * 256);
   hipMemcpy(ha.data(), a, 4096, hipMemcpyDeviceToHost); hipMemcpy(hb.data(), b, 4096, hipMemcpyDeviceToHost);
@@ -107,6 +115,9 @@ int main() {
     ++n;
   }
   printf("ds_read_tr16_b64 V-tile addressing: %s (%d bad)\n", bad ? "FAIL" : "ok", bad); fails += bad != 0;
+  { std::vector<unsigned> hs(256); hipMemcpy(hs.data(), gsw, 1024, hipMemcpyDeviceToHost);
+    printf("permlane32_swap(vdst=lane, src=100+lane): lane0 -> (%u,%u) lane1 -> (%u,%u) lane32 -> (%u,%u) lane33 -> (%u,%u)\n", hs[0], hs[1], hs[4], hs[5], hs[128], hs[129], hs[132], hs[133]);
+    printf("permlane32_swap(x,x) x=1000+lane: lane0 -> (%u,%u) lane32 -> (%u,%u)\n", hs[2], hs[3], hs[130], hs[131]); }
   printf("PROBE %s\n", fails ? "FAILED" : "PASSED");
   return fails ? 1 : 0;
 }
