@@ -14,7 +14,7 @@ from typing import Optional
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinferix_hip.so")
+LIB_PATH = os.environ.get("IFX_HIP_LIB", os.path.join(_HERE, "libinferix_hip.so"))   # override: kernel studies only
 
 IFX_LN_PLAIN, IFX_LN_AFFINE, IFX_LN_MODULATE = 0, 1, 2
 IFX_EPI_BIAS, IFX_EPI_GELU_TANH, IFX_EPI_RESIDUAL, IFX_EPI_GATE_RES = 0, 1, 2, 3

@@ -340,6 +340,19 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
   }
 }
 
+int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
+                   int heads, int kv_start, int kv_len, float scale, hipStream_t stream);
+
+// 0 = auto (ping-pong 8-wave kernel for the large self-attention launches), 1 = force the 4-wave kernel, 2 = force ping-pong
+static int attn_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("IFX_ATTN_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 }  // namespace ifx
 
 using namespace ifx;
@@ -355,6 +368,9 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
               "ifx_attn_fwd_paged: key range [%d, %d) out of range (capacity %d)", kv_start, kv_len, kv->num_slots);
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_paged: page_size must be > 0");
   if (q_rows == 0) return IFX_OK;
+  const int variant = attn_variant();
+  if (variant == 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, (hipStream_t)stream);
   AttnArgs a;
   a.q = q;
   a.out = out;

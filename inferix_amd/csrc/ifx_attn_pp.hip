@@ -1,0 +1,381 @@
+// Block-causal flash-attention forward, PING-PONG structure (gfx950, head_dim 128).
+//
+// Why: profiles of the 4-wave kernel (ifx_attn.hip) show MFMA utilisation 34-40 % although its loop is lean
+// (32 MFMA + ~200 VALU + 48 LDS reads per 64-key tile per wave): per tile a wave needs ~1024 cycles of matrix
+// pipe and ~1000 cycles of VALU issue, the two waves that share a SIMD belong to unrelated workgroups, and
+// nothing makes one of them sit in its VALU part while the other owns the matrix pipe.
+//
+// Here the two waves of a SIMD are in the SAME 8-wave workgroup and alternate roles under workgroup barriers:
+//
+//   step M(t) : O^T += V(t-1)^T P(t-1)^T   then   S(t)^T = K(t) Q^T        32 MFMAs, 48 LDS fragment reads,
+//                                                                           DMA issue of tile t+2 in the shadows
+//   step V(t) : online softmax of S(t) -> P(t) (bf16), running max / sum, conditional in-place rescale of O
+//
+//   barrier index :   2t            2t+1          2t+2          2t+3
+//   waves 0-3 (G0):   M(t)          V(t)          M(t+1)        V(t+1)
+//   waves 4-7 (G1):   V(t-1)        M(t)          V(t)          M(t+1)
+//
+// so in every phase each SIMD has exactly one wave feeding the matrix pipe and one wave doing VALU work.
+// K/V tiles (64 keys) arrive by LDS-DMA into rings (K: 3 slots, V: 4 slots, 16 KiB each = 112 KiB): tile t is
+// issued two tiles ahead; one counted s_waitcnt vmcnt(4) per wave per tile retires exactly the tile that the
+// next barrier publishes.  Layouts, swizzles, MFMA operand mapping and the k-slot relabelling that feeds P
+// straight from the S accumulators are those of ifx_attn.hip.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "ifx_common.h"
+
+// compile-time ablation for bottleneck studies (tools/ablate_attn.sh): 1 no DMA, 2 no softmax step,
+// 4 no LDS fragment reads, 8 no MFMA.  0 in the shipped library.
+#ifndef PP_ABLATE
+#define PP_ABLATE 0
+#endif
+#ifndef PP_PRIO
+#define PP_PRIO 1      // 1: s_setprio(1) around the MFMA step (+4 % measured), 2: around the softmax step (+1 %)
+#endif
+#ifndef PP_GROUP
+#define PP_GROUP 0     // 0: groups = waves 0-3 / 4-7 (waves w, w+4 share a SIMD); 1: even / odd waves
+#endif
+
+namespace ifx {
+
+namespace pp {
+constexpr int QT = 256;   // query rows per workgroup (8 waves x 32)
+constexpr int KT = 64;
+constexpr int HD = 128;
+#ifndef PP_PD
+#define PP_PD 2        // DMA prefetch distance in tiles (issued from the softmax step); 3 measured slower
+#endif
+constexpr int PD = PP_PD;
+constexpr int RK = PD + 1, RV = PD + 2;
+constexpr int K_OFF = 0, V_OFF = RK * 16384;
+constexpr int LDS_BYTES = (RK + RV) * 16384;   // 114688
+}  // namespace pp
+
+struct AttnArgsPP {
+  const unsigned short* q;
+  unsigned short* out;
+  float* lse;
+  const unsigned short* k;
+  const unsigned short* v;
+  KvAddr ka;
+  int q_rows, heads, kv_start, kv_len, num_slots, q_tiles, per_xcd, total;
+  float scale, scale_log2;
+};
+
+typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* pp_gbl_ptr_t;
+
+__device__ __forceinline__ float pp_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float pp_half_max(float x) {   // max over lane and lane^32 (see ifx_attn.hip)
+  float a = x, b = x, r;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %2, %0, %1" : "+v"(a), "+v"(b), "=v"(r));
+  return r;
+}
+
+// wait until at most `tiles` DMA tile-groups (4 pieces each) of this wave are still in flight
+__device__ __forceinline__ void pp_wait_tiles(int tiles) {
+  if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (tiles == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (tiles == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (tiles == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+template <bool PAGED>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
+  using namespace pp;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = PP_GROUP ? (wave & 1) : (wave >> 2);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int wi = xcd * A.per_xcd + slot_i;
+  if (slot_i >= A.per_xcd || wi >= A.total) return;
+  const int head = wi / A.q_tiles, qt = wi - head * A.q_tiles;
+  const int row_stride = A.heads * HD;
+
+  const int qrow = qt * QT + wave * 32 + l31;
+  const int qrow_c = min(qrow, A.q_rows - 1);
+  bf16x8 qf[8];
+  {
+    const unsigned short* qp = A.q + (size_t)qrow_c * row_stride + head * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+
+  // ---- LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): a tile is 16 K pieces + 16 V pieces of
+  //      1 KiB (4 key rows x 256 B); wave w moves pieces w and w+8.  Per lane only a 32-bit voffset per piece is
+  //      live (row * row_bytes + swizzled source chunk); the tile offset is a scalar soffset.  Rows beyond the
+  //      descriptor's range (keys >= kv_len in the ragged last tile) read as ZERO by the hardware bounds check.
+  const int d_row = lane >> 4, d_pc = lane & 15;
+  const int row_bytes = row_stride * 2;
+  int k_voff[2], v_voff[2], d_rowi[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = (r * 8 + wave) * 4 + d_row;
+    d_rowi[r] = row;
+    k_voff[r] = row * row_bytes + ((d_pc ^ (row & 15)) << 4);
+    v_voff[r] = row * row_bytes + (((((d_pc >> 2) ^ (row & 3)) << 2) | (d_pc & 3)) << 4);
+  }
+  const int nkeys = A.kv_len - A.kv_start;
+  const int NT = (nkeys + KT - 1) / KT;
+  // identity page map: descriptor covers logical tokens [0, kv_len); paged: whole cache, keys clamped by hand
+  const unsigned valid_rows = PAGED ? (unsigned)A.num_slots : (unsigned)A.kv_len;
+  const unsigned nrec = (valid_rows - 1) * (unsigned)row_bytes + 256u;
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.k + head * HD), 0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.v + head * HD), 0, nrec, 0x00020000);
+  const int last_key = A.kv_len - 1;
+  auto issue = [&](int t) {
+    unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
+    unsigned char* vb = smem + V_OFF + (t % RV) * 16384;
+    if (!PAGED) {
+      const int soff = (A.kv_start + t * KT) * row_bytes;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (pp_lds_ptr_t)(kb + (r * 8 + wave) * 1024), 16, k_voff[r], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (pp_lds_ptr_t)(vb + (r * 8 + wave) * 1024), 16, v_voff[r], soff, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int key = min(A.kv_start + t * KT + d_rowi[r], last_key);
+        const int delta = (A.ka.slot(key) - d_rowi[r]) * row_bytes;      // physical row instead of tile row
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (pp_lds_ptr_t)(kb + (r * 8 + wave) * 1024), 16, k_voff[r] + delta, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (pp_lds_ptr_t)(vb + (r * 8 + wave) * 1024), 16, v_voff[r] + delta, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c2 = A.scale_log2;
+  const int kswz = l31 & 15;
+  const int vi = lane & 15, vg1 = (lane >> 4) & 1;
+  const int v_rowq = vi >> 2;
+  const int v_in = (vg1 << 5) | ((vi & 3) << 3);
+
+  f32x16 s[2];
+  bf16x8 pb[2][2];
+  bf16x8 fA[4], fB[4];
+  if (PP_ABLATE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fA[i] = fB[i] = bf16x8{};
+    pb[0][0] = pb[0][1] = pb[1][0] = pb[1][1] = bf16x8{};
+    s[0] = s[1] = f32x16{};
+  }
+
+  auto ldK = [&](bf16x8(&f)[4], const unsigned char* kb, int b, int kh) {
+    if (PP_ABLATE & 4) return;
+    const unsigned char* krow = kb + (32 * b + l31) * 256;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+      f[k4] = *reinterpret_cast<const bf16x8*>(krow + (((2 * (4 * kh + k4) + hi) ^ kswz) << 4));
+  };
+  auto ldV = [&](bf16x8(&f)[4], const unsigned char* vb, int b, int s2) {
+    if (PP_ABLATE & 4) return;
+    const unsigned char* vr0 = vb + (32 * b + 16 * s2 + 4 * hi + v_rowq) * 256 + v_in;
+    const unsigned char* vr1 = vr0 + 8 * 256;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int ch = (d ^ v_rowq) << 6;
+      const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr0 + ch));
+      const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr1 + ch));
+      f[d] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto mmaK = [&](f32x16& acc, bf16x8(&f)[4], int kh) {
+    if (PP_ABLATE & 8) return;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[k4], qf[4 * kh + k4], acc, 0, 0, 0);
+  };
+  auto mmaV = [&](bf16x8(&f)[4], const bf16x8& p) {
+    if (PP_ABLATE & 8) return;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[d], p, o[d], 0, 0, 0);
+  };
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+
+  // ---- step M(t): PV(t-1) then QK(t); fragment batches double buffered through fA / fB
+  auto stepM = [&](int t) {
+    const unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
+    if (t > 0) {
+      const unsigned char* vb = smem + V_OFF + ((t - 1) % RV) * 16384;
+      ldV(fA, vb, 0, 0);
+      ldV(fB, vb, 0, 1);
+      PP_SB();
+      mmaV(fA, pb[0][0]);
+      ldV(fA, vb, 1, 0);
+      PP_SB();
+      mmaV(fB, pb[0][1]);
+      ldV(fB, vb, 1, 1);
+      PP_SB();
+      mmaV(fA, pb[1][0]);
+      ldK(fA, kb, 0, 0);
+      PP_SB();
+      mmaV(fB, pb[1][1]);
+      ldK(fB, kb, 0, 1);
+      PP_SB();
+    } else {
+      ldK(fA, kb, 0, 0);
+      ldK(fB, kb, 0, 1);
+      PP_SB();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[0][r] = 0.f;
+      s[1][r] = 0.f;
+    }
+    mmaK(s[0], fA, 0);
+    ldK(fA, kb, 1, 0);
+    PP_SB();
+    mmaK(s[0], fB, 1);
+    ldK(fB, kb, 1, 1);
+    PP_SB();
+    mmaK(s[1], fA, 0);
+    mmaK(s[1], fB, 1);
+  };
+
+  // ---- step V(t): online softmax of the 64-key tile; P -> pb (bf16), in-place rescale of O when a max grew
+  auto stepV = [&](int t) {
+    // DMA of tile t+PD is issued HERE: an LDS-DMA instruction costs its issuing wave ~100+ cycles, which the
+    // VALU step can afford (it is shorter than the partner's MFMA step) and the MFMA step cannot
+    if (t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+    if (t == NT - 1 && (nkeys & (KT - 1))) {     // ragged last tile (wave-uniform, executed once)
+      const int kidx = t * KT + 4 * hi;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kidx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) s[b][r] = -INFINITY;
+    }
+    float mx = pp_max3(s[0][0], s[1][0], m_run);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = pp_max3(mx, s[0][r], s[1][r]);
+    const float m_new = pp_half_max(mx);
+    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+    m_run = m_new;
+    const float mc = m_new * c2;
+    float ps = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[b][r] * c2 - mc);
+        ps += p;
+        pb[b][r >> 3][r & 7] = static_cast<__bf16>(p);
+      }
+    l_run = l_run * alpha + ps;
+    asm volatile("" : "+v"(alpha));
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[d][r]) : "v"(alpha));
+    }
+  };
+
+  // ---- prologue: tiles 0 and 1 in flight
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (i < NT) issue(i);
+  if (grp == 1) {                                   // phase shift: G1 runs one barrier behind G0
+    pp_wait_tiles(min(NT, PD) - 1);
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int t = 0; t < NT; ++t) {
+    if (grp == 0) {                                  // own pieces of tile t landed (tile t+1 may stay in flight)
+      pp_wait_tiles(min(NT - 1 - t, PD - 1));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    stepM(t);
+    if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (grp == 1 && t + 1 < NT) {                    // own pieces of tile t+1 landed before G0 starts M(t+1)
+      pp_wait_tiles(max(min(NT - 2 - t, PD - 2), 0));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);   // VALU step wins issue arbitration; MFMAs fill the gaps
+    if (!(PP_ABLATE & 2)) stepV(t);
+    if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the phase shift
+  // ---- drain: PV of the last tile
+  {
+    const unsigned char* vb = smem + V_OFF + ((NT - 1) % RV) * 16384;
+    ldV(fA, vb, 0, 0);
+    ldV(fB, vb, 0, 1);
+    PP_SB();
+    mmaV(fA, pb[0][0]);
+    ldV(fA, vb, 1, 0);
+    PP_SB();
+    mmaV(fB, pb[0][1]);
+    ldV(fB, vb, 1, 1);
+    PP_SB();
+    mmaV(fA, pb[1][0]);
+    mmaV(fB, pb[1][1]);
+  }
+#undef PP_SB
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < A.q_rows) {
+    unsigned short* op = A.out + (size_t)qrow * row_stride + head * HD + 4 * hi;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = f2bf(o[d][4 * g + e] * inv);
+        *reinterpret_cast<u16x4*>(op + 32 * d + 8 * g) = w;
+      }
+    if (A.lse != nullptr && hi == 0) A.lse[(size_t)head * A.q_rows + qrow] = m_run * A.scale + __logf(l_tot);
+  }
+}
+
+int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
+                   int heads, int kv_start, int kv_len, float scale, hipStream_t stream) {
+  using namespace pp;
+  AttnArgsPP a;
+  a.q = q;
+  a.out = out;
+  a.lse = lse;
+  a.k = kv->k;
+  a.v = kv->v;
+  a.ka = KvAddr{kv->page_table, kv->page_size};
+  a.q_rows = q_rows;
+  a.heads = heads;
+  a.kv_start = kv_start;
+  a.kv_len = kv_len;
+  a.num_slots = kv->num_slots;
+  a.q_tiles = (q_rows + QT - 1) / QT;
+  a.total = a.q_tiles * heads;
+  a.per_xcd = (a.total + 7) / 8;
+  a.scale = scale > 0.f ? scale : 0.08838834764831845f;
+  a.scale_log2 = a.scale * 1.4426950408889634f;
+  const dim3 grid(a.per_xcd * 8), block(512);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  if (kv->page_table) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, block, LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid, block, LDS_BYTES, stream, a);
+  return check_launch("ifx_attn_fwd_paged(pp)");
+}
+
+}  // namespace ifx
