@@ -109,13 +109,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    # IFX_BENCH_SHARE_GPU=1 (test only): all ranks on cuda:0 over gloo, to exercise the N>1 code path on a 1-GPU box
+    share = os.environ.get("IFX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     pc = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
         from inferix_amd.sequence_parallel import attach_sequence_parallel
         from inferix_amd.wan import ParallelConfig
         pc = ParallelConfig(rank=rank, world_size=world, local_rank=local_rank)

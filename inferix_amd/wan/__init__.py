@@ -1,4 +1,4 @@
 from .causal_model import HipCausalWanModel, ParallelConfig
-from .wrapper import HipWanDiffusionWrapper
+from .wrapper import HipCausVidDiffusionWrapper, HipWanDiffusionWrapper
 
-__all__ = ["HipCausalWanModel", "HipWanDiffusionWrapper", "ParallelConfig"]
+__all__ = ["HipCausalWanModel", "HipCausVidDiffusionWrapper", "HipWanDiffusionWrapper", "ParallelConfig"]

@@ -88,6 +88,15 @@ class _Block:
         self.kv_cache_manager = SelfForcingKVCacheManagerFactory.create_manager(
             layer_idx, num_heads, head_dim, enable_kv_offload=enable_kv_offload)
         self.w: Dict[str, torch.Tensor] = {}
+        self.cross_meta = {"is_init": False}       # CausVid keeps this flag on the block (causal_model.py:227)
+
+    @property
+    def is_cross_attn_init(self) -> bool:
+        return self.cross_meta["is_init"]
+
+    @is_cross_attn_init.setter
+    def is_cross_attn_init(self, v: bool) -> None:
+        self.cross_meta["is_init"] = bool(v)
 
 
 class HipCausalWanModel(torch.nn.Module):
@@ -243,7 +252,11 @@ class HipCausalWanModel(torch.nn.Module):
         # ---------------- self attention ----------------
         ops.layernorm(xact, self.eps, mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
         ops.linear(h, w["qkv_w"], w["qkv_b"], out=qkv)
-        g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
+        explicit = st.get("explicit_slots")          # CausVid: (kv_start, kv_end) given by the caller
+        if explicit is None:
+            g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
+        else:
+            g_end = l_end = 0
         step = None
         for b, req in enumerate(kv_cache_requests):
             name = blk.kv_cache_manager.self_name
@@ -253,7 +266,11 @@ class HipCausalWanModel(torch.nn.Module):
                                               ab[b * N:(b + 1) * N], w, rope, current_start, g_end, l_end,
                                               sink_tokens, kv_cache_manager, req, name)
                 continue
-            step = kv_index_update(g_end, l_end, current_start, N, view.k.shape[0], self.local_attn_size, sink_tokens)
+            if explicit is not None:
+                step = KVIndexStep(explicit[0], explicit[1], explicit[1], 0, 0, 0)
+            else:
+                step = kv_index_update(g_end, l_end, current_start, N, view.k.shape[0], self.local_attn_size,
+                                       sink_tokens)
             if step.local_start < 0 or step.local_end > view.k.shape[0]:
                 raise _hip.HipKernelError(f"KV cache overflow: slots [{step.local_start}, {step.local_end}) of "
                                           f"{view.k.shape[0]} (layer {l})")
@@ -264,8 +281,9 @@ class HipCausalWanModel(torch.nn.Module):
                                        step.local_start, d, q_out=qb[b * N:(b + 1) * N])
             ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end,
                           out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_self")
-        self._meta_set(meta, "global_end_index", step.global_end)
-        self._meta_set(meta, "local_end_index", step.local_end)
+        if explicit is None:
+            self._meta_set(meta, "global_end_index", step.global_end)
+            self._meta_set(meta, "local_end_index", step.local_end)
         ops.linear(ab, w["o_w"], w["o_b"], epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
                    rows_per_group=rows_per_group, out=xact)
         # ---------------- cross attention ----------------
@@ -295,9 +313,18 @@ class HipCausalWanModel(torch.nn.Module):
     def forward(self, x, t, context, seq_len=None, clip_fea=None, y=None, kv_cache_meta=None,
                 crossattn_cache_meta=None, current_start: int = 0, cache_start=None,
                 kv_cache_manager: Optional[KVCacheManager] = None,
-                kv_cache_requests: Optional[Sequence[KVCacheRequest]] = None) -> torch.Tensor:
+                kv_cache_requests: Optional[Sequence[KVCacheRequest]] = None,
+                kv_start: Optional[int] = None, kv_end: Optional[int] = None,
+                current_end: Optional[int] = None) -> torch.Tensor:
         """x: [B, C, F, H, W] tensor (or list of [C, F, H, W]); t: [B, F]; context: [B, L, text_dim] tensor or
         list of [L_i, text_dim].  Returns the flow prediction [B, C_out, F, H, W] (bf16)."""
+        explicit = None
+        if kv_start is not None and kv_end is not None:
+            # CausVid addressing (models/causvid/causal_model.py:128-179,258-277): the caller names the cache
+            # slots of this block; the cross-attention init flag lives on the block (`is_cross_attn_init`)
+            explicit = (int(kv_start), int(kv_end))
+            kv_cache_meta = [dict() for _ in range(self.num_layers)]
+            crossattn_cache_meta = [b.cross_meta for b in self.blocks]
         if kv_cache_meta is None:
             raise NotImplementedError("HipCausalWanModel implements the KV-cached inference path only")
         assert kv_cache_manager is not None and kv_cache_requests is not None
@@ -349,7 +376,7 @@ class HipCausalWanModel(torch.nn.Module):
         sink_tokens = self.sink_size * fs
 
         st = dict(B=B, N=N, F_=F_, fs=fs, rows_per_group=rows_per_group, rope=rope, sink_tokens=sink_tokens,
-                  current_start=current_start, ctx=ctx)
+                  current_start=current_start, ctx=ctx, explicit_slots=explicit)
         for l in range(L):
             self._run_block(l, xact, E[l], st, kv_cache_meta[l], crossattn_cache_meta[l], kv_cache_manager,
                             kv_cache_requests)

@@ -87,3 +87,23 @@ class HipWanDiffusionWrapper(torch.nn.Module):
         x0 = self._convert_flow_pred_to_x0(flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1).to(flow.device),
                                            timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])
         return flow, x0
+
+
+class HipCausVidDiffusionWrapper(HipWanDiffusionWrapper):
+    """CausVid generator (inferix/models/causvid/wrapper.py:269-304): explicit `kv_start/kv_end` cache slots per
+    call, returns `pred_x0` only.  Same kernels as Self-Forcing; the default timestep shift is 8.0."""
+
+    @torch.no_grad()
+    def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
+                kv_start: Optional[int] = None, kv_end: Optional[int] = None, current_start: Optional[int] = None,
+                current_end: Optional[int] = None, kv_cache_manager: Optional[KVCacheManager] = None,
+                kv_cache_requests: Optional[List[KVCacheRequest]] = None) -> torch.Tensor:
+        if kv_start is None or kv_end is None:
+            raise ValueError("CausVid generator needs explicit kv_start / kv_end")
+        flow = self.model(noisy_image_or_video.permute(0, 2, 1, 3, 4), t=timestep,
+                          context=conditional_dict["prompt_embeds"], seq_len=self.seq_len, kv_start=kv_start,
+                          kv_end=kv_end, current_start=current_start, current_end=current_end,
+                          kv_cache_manager=kv_cache_manager, kv_cache_requests=kv_cache_requests
+                          ).permute(0, 2, 1, 3, 4)
+        return self._convert_flow_pred_to_x0(flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1).to(flow.device),
+                                             timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])

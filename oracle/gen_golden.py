@@ -377,6 +377,100 @@ def gen_rollout(cm, name, cfg, num_blocks, steps, shift, batch=1, with_initial=F
     save_npz(os.path.join(GOLDEN_DIR, name), fx)
 
 
+def gen_causvid():
+    """CausVid twin: the reference's own CausVid model + inner pipeline (explicit kv_start/kv_end slots,
+    x0-only generator, last denoising step dropped), two segments: fresh start and start_latents prefill."""
+    print("causvid_tiny.npz")
+    import importlib
+    from inferix.kvcache_manager.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix.models.schedulers.flow_match import FlowMatchScheduler
+    cvm = importlib.import_module("inferix.models.causvid.causal_model")
+    cvw = importlib.import_module("inferix.models.causvid.wrapper")
+    cvp = importlib.import_module("inferix.pipeline.causvid.CausalInferencePipeline")
+    # text_len 512: the reference allocates a 512-token cross cache (`:79`) and re-reads ALL of it on every forward
+    cfg = O.tiny_config(text_len=512)
+    W = O.init_weights(cfg, seed=0)
+    m = cvm.CausalWanModel(model_type="t2v", patch_size=cfg.patch_size, text_len=cfg.text_len, in_dim=cfg.in_dim,
+                           dim=cfg.dim, ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim,
+                           out_dim=cfg.out_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers, qk_norm=True,
+                           cross_attn_norm=True, eps=cfg.eps, enable_kv_offload=False, parallel_config=_pc()).eval()
+    m.load_state_dict({k: v.float() for k, v in W.items()}, strict=True)
+    m = m.to(BF)
+    w = cvw.WanDiffusionWrapper.__new__(cvw.WanDiffusionWrapper)
+    torch.nn.Module.__init__(w)
+    w.model, w.uniform_timestep, w.seq_len = m, False, 32760
+    w.scheduler = FlowMatchScheduler(shift=8.0, sigma_min=0.0, extra_one_step=True)
+    w.scheduler.set_timesteps(1000, training=True)
+    steps = [1000, 757, 522]
+    g = torch.Generator().manual_seed(21)
+    nfb = 3
+    pe = torch.zeros(1, cfg.text_len, cfg.text_dim)
+    pe[:, :10] = torch.randn(1, 10, cfg.text_dim, generator=g)
+    pe = pe.to(BF)
+
+    class _Vae:
+        def decode_to_pixel(self, x, use_cache=True, chunk_size=2):
+            return torch.zeros(1)
+    pipe = cvp.CausalInferencePipeline.__new__(cvp.CausalInferencePipeline)
+    torch.nn.Module.__init__(pipe)
+    pipe.parallel_config = _pc()
+    pipe.generator, pipe.text_encoder, pipe.vae = w, _FakeTextEncoder(pe), _Vae()
+    pipe.scheduler = w.scheduler
+    ts = torch.cat((w.scheduler.timesteps.cpu(), torch.tensor([0], dtype=torch.float32)))
+    pipe.denoising_step_list = ts[1000 - torch.tensor(steps, dtype=torch.long)[:-1]]
+    pipe.num_transformer_blocks, pipe.frame_seq_length = cfg.num_layers, cfg.frame_seqlen
+    pipe.per_rank_frame_seq_length = cfg.frame_seqlen
+    pipe.is_kv_cache_initialized, pipe.args, pipe.num_frame_per_block = False, None, nfb
+    fx = dict(prompt_embeds=pe, steps=torch.tensor(steps), weights_checksum=torch.tensor(weights_checksum(W)))
+    real_randn_like = torch.randn_like
+    start = None
+    for seg in range(2):
+        noise = torch.randn(1, 2 * nfb if seg == 0 else 3 * nfb, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF)
+        drawn, calls = [], []
+
+        def rec(t, *a, **k):
+            r = real_randn_like(t, *a, **k)
+            drawn.append(r.clone())
+            return r
+
+        def hook(mod, a, kw, out):
+            calls.append(dict(x_in=kw["noisy_image_or_video"].clone(), t=kw["timestep"].clone(),
+                              kv_start=kw["kv_start"], kv_end=kw["kv_end"], x0=out.clone()))
+        h = w.register_forward_hook(hook, with_kwargs=True)
+        torch.manual_seed(99 + seg)
+        torch.randn_like = rec
+        kvm = KVCacheManager(device="cpu")
+        reqs = [KVCacheRequest(f"seg{seg}")]
+        for blk in m.blocks:
+            blk.is_cross_attn_init = False      # what a fresh process would have (see the rollover note in DESIGN.md)
+        try:
+            _, lat = pipe.inference(noise=noise, text_prompts=["x"], start_latents=start, return_latents=True,
+                                    kv_cache_manager=kvm, kv_cache_requests=reqs)
+        finally:
+            torch.randn_like = real_randn_like
+            h.remove()
+        mine, st = O.causvid_inference(W, cfg, noise, list(pe), steps, renoise=drawn, shift=8.0,
+                                       num_frame_per_block=nfb, start_latents=start,
+                                       state=O.CacheState.allocate(cfg, 1, BF, cache_tokens=32760))
+        check(f"causvid segment {seg} latents", lat, mine)
+        raw = kvm.get_raw(reqs[0], "layer_0")
+        n_tok = noise.shape[1] * cfg.frame_seqlen
+        check(f"causvid segment {seg} cache K", raw[0, :n_tok, 0], st.layers[0].k[0, :n_tok])
+        fx[f"seg{seg}_noise"], fx[f"seg{seg}_out"] = noise, lat
+        fx[f"seg{seg}_cache_k"], fx[f"seg{seg}_cache_v"] = raw[0, :n_tok, 0], raw[1, :n_tok, 0]
+        fx[f"seg{seg}_slots"] = torch.tensor([[c["kv_start"], c["kv_end"]] for c in calls])
+        fx[f"seg{seg}_t"] = torch.stack([c["t"].flatten()[0].float() for c in calls])
+        fx[f"seg{seg}_num_renoise"] = torch.tensor(len(drawn))
+        for i, d in enumerate(drawn):
+            fx[f"seg{seg}_renoise_{i}"] = d
+        if start is not None:
+            fx[f"seg{seg}_start"] = start
+        print(f"   segment {seg}: {len(calls)} generator forwards, slots {fx[f'seg{seg}_slots'].tolist()[:4]}...")
+        pipe.clear_cache(kvm, reqs)
+        start = lat[:, -nfb:].clone()              # overlap = one block of latents (VAE re-encode is outside the path)
+    save_npz(os.path.join(GOLDEN_DIR, "causvid_tiny.npz"), fx)
+
+
 def gen_block(cm):
     """One CausalWanAttentionBlock forward at the REAL channel geometry (dim 1536, 12 heads,
     ffn 8960) on a small token grid, two consecutive blocks of frames (prefix growth)."""
@@ -430,6 +524,7 @@ def main():
     gen_scheduler()
     gen_kv_manager()
     gen_block(cm)
+    gen_causvid()
     gen_rollout(cm, "rollout_tiny.npz", O.tiny_config(), num_blocks=3, steps=[1000, 750, 500, 250], shift=5.0)
     gen_rollout(cm, "rollout_tiny_local.npz", O.tiny_config(local_attn_size=6, sink_size=1), num_blocks=4,
                 steps=[1000, 500], shift=5.0)

@@ -195,3 +195,52 @@ def test_attention_registry_contract():
     assert torch.equal(attention(q, k, v), out)
     with pytest.raises(NotImplementedError):
         fn(q, k, v, causal=True)
+
+
+def test_causvid_rollover_vs_reference_golden():
+    """CausVid (BASELINE config 3 mechanics): explicit slot addressing, dropped last step, start_latents prefill and
+    the per-segment request swap, against latents/caches generated by the reference's own CausVid pipeline."""
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausVidInferencePipeline
+    from inferix_amd.wan import HipCausVidDiffusionWrapper
+    fx = golden("causvid_tiny.npz")
+    cfg = O.tiny_config(text_len=512)
+    m = build(cfg, O.init_weights(cfg, seed=0))
+    gen = HipCausVidDiffusionWrapper(model=m, timestep_shift=8.0)
+    args = SimpleNamespace(denoising_step_list=fx["steps"].tolist(), warp_denoising_step=True, num_frame_per_block=3,
+                           frame_seq_length=cfg.frame_seqlen, kv_cache_tokens=600)
+    pe = fx["prompt_embeds"].cuda()
+    pipe = CausVidInferencePipeline(args, device="cuda", generator=gen,
+                                    text_encoder=lambda text_prompts: {"prompt_embeds": pe}, vae=None)
+    kvm = KVCacheManager("cuda")
+    slots = []
+    orig = gen.forward
+
+    def rec(**kw):
+        slots.append([kw["kv_start"], kw["kv_end"]])
+        return orig(**kw)
+    gen.forward = rec
+    renoise = [[fx[f"seg{s}_renoise_{i}"] for i in range(int(fx[f"seg{s}_num_renoise"]))] for s in range(2)]
+    # segment 1 of the golden starts from the reference's own segment-0 tail (teacher forced): run segments one by one
+    start = None
+    for seg in range(2):
+        req = [KVCacheRequest(f"seg{seg}")]
+        slots.clear()
+        lat = pipe.inference(fx[f"seg{seg}_noise"].cuda(), ["x"], start, return_latents=False, kv_cache_manager=kvm,
+                             kv_cache_requests=req, decode=False, renoise=renoise[seg])
+        torch.cuda.synchronize()
+        assert slots == fx[f"seg{seg}_slots"].tolist(), "cache slot schedule differs from the reference"
+        assert rel_l2(lat.cpu(), fx[f"seg{seg}_out"]) < 1e-2
+        n = fx[f"seg{seg}_cache_k"].shape[0]
+        raw = kvm.get_raw(req[0], "layer_0")
+        assert rel_l2(raw[0, :n, 0].cpu(), fx[f"seg{seg}_cache_k"]) < 1e-2
+        assert rel_l2(raw[1, :n, 0].cpu(), fx[f"seg{seg}_cache_v"]) < 1e-2
+        pipe.clear_cache(kvm, req)
+        kvm.free(req[0])
+        start = fx["seg1_start"].cuda() if seg == 0 else None
+    # and the rollover driver end to end (own tail as overlap): shapes, request lifecycle
+    gen.forward = orig
+    outs = pipe.rollover(["a", "b"], [fx["seg0_noise"].cuda(), fx["seg1_noise"].cuda()], kvm, overlap_frames=3)
+    assert [tuple(o.shape) for o in outs] == [tuple(fx["seg0_noise"].shape), tuple(fx["seg1_noise"].shape)]
+    assert torch.equal(outs[1][:, :3], outs[0][:, -3:])          # prefilled overlap frames are passed through
+    assert list(kvm.request_to_kv_caches) == ["segment_1"]

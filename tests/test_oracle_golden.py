@@ -174,3 +174,25 @@ def test_kv_index_update_properties():
     assert (s.evicted, s.rolled, s.local_start, s.local_end, s.global_end) == (72, 48, 72, 144, 216)
     s = O.kv_index_update(216, 144, 144, 72, 144, 6, 24)   # re-run after eviction: same slots, no second roll
     assert (s.evicted, s.local_start, s.local_end, s.global_end) == (0, 72, 144, 216)
+
+
+def test_causvid_golden():
+    """CausVid twin (explicit kv_start/kv_end slots, x0-only generator, last step dropped), two segments with
+    start_latents prefill: oracle == reference bit for bit."""
+    fx = golden("causvid_tiny.npz")
+    cfg = O.tiny_config(text_len=512)
+    W = O.init_weights(cfg, seed=0)
+    assert weights_checksum(W) == int(fx["weights_checksum"])
+    for seg in range(2):
+        renoise = [fx[f"seg{seg}_renoise_{i}"] for i in range(int(fx[f"seg{seg}_num_renoise"]))]
+        rec = []
+        out, st = O.causvid_inference(W, cfg, fx[f"seg{seg}_noise"], list(fx["prompt_embeds"]), fx["steps"].tolist(),
+                                      renoise=renoise, shift=8.0, start_latents=fx.get(f"seg{seg}_start"),
+                                      state=O.CacheState.allocate(cfg, 1, BF, cache_tokens=600), record=rec)
+        same(fx[f"seg{seg}_out"], out)
+        n = fx[f"seg{seg}_cache_k"].shape[0]
+        same(fx[f"seg{seg}_cache_k"], st.layers[0].k[0, :n])
+        same(fx[f"seg{seg}_cache_v"], st.layers[0].v[0, :n])
+        n_tok = 3 * cfg.frame_seqlen
+        assert [[r["block"] * n_tok, (r["block"] + 1) * n_tok] for r in rec] == fx[f"seg{seg}_slots"].tolist()
+        assert [round(float(r["timestep"].flatten()[0]), 3) for r in rec] == [round(float(t), 3) for t in fx[f"seg{seg}_t"]]
