@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=0, help="debug: fewer layers (makes the result INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quant", choices=["none", "fp8", "int8"], default="none",
+                    help="BASELINE config 4: dynamic per-token x per-channel 8-bit linears (not the headline dtype)")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed clip with every kernel timed")
     a = ap.parse_args()
 
@@ -134,6 +136,11 @@ def main():
     model, gen, pipe = build_pipeline(device, pc, a.layers or None)
     if world > 1:
         attach_sequence_parallel(model, dist.group.WORLD)
+    if a.quant != "none":
+        from inferix_amd import quant as Qz
+        qc = (Qz.get_dynamic_fp8_per_token_act_per_channel_weight_qconfig() if a.quant == "fp8"
+              else Qz.get_dynamic_int8_per_token_act_per_channel_weight_qconfig())
+        Qz.quantize_dynamic(gen, {"": qc, "text_embedding": None, "proj_out": None, "head": None})
     g = torch.Generator().manual_seed(0)
     noise = torch.randn(1, FRAMES, *LATENT, generator=g).to(torch.bfloat16).to(device)
     kvm = KVCacheManager(device)
@@ -185,7 +192,8 @@ def main():
     gen.forward = timed_forward
     breakdown = None
     if a.kernel_breakdown:
-        allt = ops.KernelTimer(names=("attn_self", "attn_cross", "gemm", "layernorm", "rmsnorm_rope_append"))
+        allt = ops.KernelTimer(names=("attn_self", "attn_cross", "gemm", "gemm_q8", "quant_per_token", "layernorm",
+                                      "rmsnorm_rope_append"))
         ops.set_kernel_timer(allt)
     clip()
     torch.cuda.synchronize()
@@ -214,7 +222,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16" if a.quant == "none" else f"{a.quant} linears (per-token x per-channel) + bf16 attention",
             "data": "synthetic",
             "config": {"workload": "Self-Forcing 480p bf16 (Wan2.1-T2V-1.3B causal DiT, 30 layers), block_size=3, "
                                    "21 latent frames = 7 blocks x (4 denoise + 1 context) generator forwards, paged KV "

@@ -174,6 +174,27 @@ int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_b
                   const ifx_epilogue* epi, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Dynamic 8-bit linear layers: per-token activation x per-channel weight, FP8 (OCP e4m3fn) or INT8.
+ * Replaces the DAX `quantize_dynamic` linears wired in
+ * example/quantization/run_self_forcing_quantized.py:19-23,47-64 (every nn.Linear under generator.model
+ * except text_embedding / proj_out / head).  DAX is un-vendored and unpinned: the arithmetic is defined HERE
+ * (restated in oracle/quant_oracle.py); parity with DAX itself is unpinned.
+ *
+ *   ifx_quant_per_token : s[m] = max_k|x[m,k]| / QMAX (1.0 for a zero row), QMAX = 448 | 127;
+ *                         q[m,k] = cast(clamp(x[m,k] / s[m], +-QMAX)), e4m3: RNE, int8: rint.
+ *                         x [rows, K] bf16 (row stride ldx), q [rows, K] bytes (row stride ldq), scale [rows] fp32.
+ *   ifx_gemm_q8         : y = epilogue(bf16(acc * (x_scale[m] * w_scale[n]) + bias[n])), acc = sum_k xq*wq in
+ *                         fp32 (fp8 MFMA) or exact int32 (int8 MFMA); wq [N, K] bytes, w_scale [N] fp32 from the
+ *                         same rule applied per output channel.  Epilogues as ifx_gemm_bf16.  K % 128 == 0.
+ * ---------------------------------------------------------------------- */
+enum { IFX_Q_FP8_E4M3 = 0, IFX_Q_INT8 = 1 };
+int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int32_t ldq, float* scale, int32_t rows,
+                        int32_t K, int32_t format, void* stream);
+int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t format,
+                const ifx_epilogue* epi, void* stream);
+
+/* ------------------------------------------------------------------------
  * KV cache maintenance.  ifx_kv_roll: the reference's eviction shift
  * cache[sink : sink+rolled] <- cache[sink+evicted : sink+evicted+rolled]
  * (causal_model.py:287-292) as a physical move, for spans that are not page aligned

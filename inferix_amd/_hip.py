@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("IFX_HIP_LIB", os.path.join(_HERE, "libinferix_hip.so"
 
 IFX_LN_PLAIN, IFX_LN_AFFINE, IFX_LN_MODULATE = 0, 1, 2
 IFX_EPI_BIAS, IFX_EPI_GELU_TANH, IFX_EPI_RESIDUAL, IFX_EPI_GATE_RES = 0, 1, 2, 3
+IFX_Q_FP8_E4M3, IFX_Q_INT8 = 0, 1
 
 
 class HipLibraryMissing(RuntimeError):
@@ -63,6 +64,8 @@ SIGNATURES = {
     "ifx_layernorm": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ifx_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
     "ifx_kv_roll": (C.c_int, [C.POINTER(KvView), _i32, _i32, _i32, _vp, _vp]),
+    "ifx_quant_per_token": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "ifx_gemm_q8": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

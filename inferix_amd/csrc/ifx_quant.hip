@@ -1,0 +1,319 @@
+// Dynamic 8-bit linear layers (gfx950): per-token activation quantisation + FP8 (OCP e4m3) / INT8 MFMA GEMM
+// with per-token x per-channel dequantisation and the block's fused epilogues.
+//
+// Replaces the DAX `quantize_dynamic` linears the reference wires in
+// example/quantization/run_self_forcing_quantized.py:19-23,47-64 (dynamic per-token activation x per-channel
+// weight, FP8 or INT8).  DAX is an un-vendored, unpinned dependency: its arithmetic is NOT in the reference tree,
+// so the scheme is defined here (and restated in oracle/quant_oracle.py) — parity with DAX itself is unpinned:
+//
+//   s_a[m] = max_k |x[m,k]| / QMAX          (fp32; 1.0 for an all-zero row)      QMAX = 448 (e4m3) | 127 (int8)
+//   xq[m,k] = cast( clamp(x[m,k] / s_a[m], +-QMAX) )      e4m3: round-to-nearest-even ; int8: rint
+//   s_w[n], wq[n,k] : the same per OUTPUT channel of W, computed once when the module is quantised
+//   y[m,n]  = epilogue( bf16( acc[m,n] * (s_a[m] * s_w[n]) + bias[n] ) )         acc: fp32 (fp8) / exact int32 (int8)
+//
+// Kernels:
+//   quant_rows_kernel : one wavefront per token row, two passes over the row (abs-max, then scale+cast; the second
+//                       pass hits L2), 16-byte loads, 8-byte stores: HBM-bound (reads 2 B, writes 1 B per element).
+//   gemm_q8_kernel    : 128 x 128 x 128(bytes of K) tiles, 4 waves, 2x2 fragments of 32x32 per wave;
+//                       v_mfma_f32_32x32x16_fp8_fp8 (two per 16-byte fragment read) or v_mfma_i32_32x32x32_i8;
+//                       operands staged global -> registers -> LDS (double buffered), 128-byte rows with the
+//                       16-byte chunk index XOR ((row >> 1) & 7): conflict-free ds_read_b128 for 32-row fragments;
+//                       half the operand bytes of the bf16 kernel per FLOP.
+#include <stdlib.h>
+
+#include "ifx_common.h"
+
+namespace ifx {
+
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) long i64x2;
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool FP8>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                         unsigned char* __restrict__ q, int ldq,
+                                                         float* __restrict__ scale, int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const unsigned short* xr = x + (size_t)r * ldx;
+  float amax = 0.f;
+  for (int col = lane * 8; col < K; col += 512) {
+    const u16x8 u = *reinterpret_cast<const u16x8*>(xr + col);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(bf2f(u[i])));
+  }
+  amax = wave_max(amax);
+  constexpr float QMAX = FP8 ? 448.0f : 127.0f;
+  const float s = amax > 0.f ? amax / QMAX : 1.0f;
+  if (lane == 0) scale[r] = s;
+  unsigned char* qr = q + (size_t)r * ldq;
+  for (int col = lane * 8; col < K; col += 512) {
+    const u16x8 u = *reinterpret_cast<const u16x8*>(xr + col);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(bf2f(u[i]) / s, -QMAX), QMAX);
+    u32x2 o;
+    if (FP8) {
+      unsigned w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+      o = u32x2{w0, w1};
+    } else {
+      unsigned w[2] = {0, 0};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i >> 2] |= ((unsigned)(int)rintf(v[i]) & 0xffu) << (8 * (i & 3));
+      o = u32x2{w[0], w[1]};
+    }
+    *reinterpret_cast<u32x2*>(qr + col) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct EpiArgsQ {
+  const float* sa;
+  const float* sw;
+  const unsigned short* bias;
+  const unsigned short* residual;
+  int ld_res;
+  const unsigned short* mod;
+  int mod_slots, gate_slot, rows_per_group;
+};
+
+__device__ __forceinline__ float gelu_tanh_q(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
+template <bool FP8, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_q8_kernel(const unsigned char* __restrict__ x, int ldx,
+                                                         const unsigned char* __restrict__ w,
+                                                         unsigned short* __restrict__ y, int ldy, int M, int N, int K,
+                                                         int tiles_m, int tiles_n, EpiArgsQ ea) {
+  constexpr int BM = 128, BN = 128, BKB = 128;   // K tile = 128 one-byte elements
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  constexpr int GM = 8;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const int t_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || t_id >= total) return;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+
+  const unsigned char* gx[4];
+  const unsigned char* gw[4];
+  int lds_off[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int qi = tid + 256 * p, row = qi >> 3, c = qi & 7;
+    gx[p] = x + (size_t)min(m_base + row, M - 1) * ldx + c * 16;
+    gw[p] = w + (size_t)min(n_base + row, N - 1) * K + c * 16;
+    lds_off[p] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+  }
+  u32x4 rx[4], rw[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      rx[p] = *reinterpret_cast<const u32x4*>(gx[p] + (size_t)kt * BKB);
+      rw[p] = *reinterpret_cast<const u32x4*>(gw[p] + (size_t)kt * BKB);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* bx = smem + buf * 32768;
+    unsigned char* bw = bx + 16384;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<u32x4*>(bx + lds_off[p]) = rx[p];
+      *reinterpret_cast<u32x4*>(bw + lds_off[p]) = rw[p];
+    }
+  };
+
+  f32x16 facc[2][2];
+  i32x16 iacc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        facc[i][j][r] = 0.f;
+        iacc[i][j][r] = 0;
+      }
+
+  const int KT = K / BKB;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int l31 = lane & 31, hi = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    const unsigned char* bx = smem + buf * 32768;
+    const unsigned char* bw = bx + 16384;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = 2 * p + hi;
+      i32x4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wn * 64 + i * 32 + l31;
+        a[i] = *reinterpret_cast<const i32x4*>(bw + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wm * 64 + j * 32 + l31;
+        b[j] = *reinterpret_cast<const i32x4*>(bx + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (FP8) {
+            // one 16-byte fragment = two K=16 steps; the k-slot relabelling is the same for both operands
+            const i64x2 al = __builtin_bit_cast(i64x2, a[i]), bl = __builtin_bit_cast(i64x2, b[j]);
+            facc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[0], bl[0], facc[i][j], 0, 0, 0);
+            facc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[1], bl[1], facc[i][j], 0, 0, 0);
+          } else {
+            iacc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], iacc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds D[n = n0 + 32i + 8g + 4hi + e][m = m0 + 32j + l31]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m_base + wm * 64 + j * 32 + l31;
+    if (m >= M) continue;
+    const float sa = ea.sa[m];
+    const unsigned short* gate_row = nullptr;
+    if (EPI == IFX_EPI_GATE_RES)
+      gate_row = ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n_base + wn * 64 + i * 32 + g * 8 + hi * 4;
+        if (n >= N) continue;
+        const f32x4 swv = *reinterpret_cast<const f32x4*>(ea.sw + n);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float acc = FP8 ? facc[i][j][4 * g + e] : (float)iacc[i][j][4 * g + e];
+          v[e] = acc * (sa * swv[e]);
+        }
+        if (ea.bias) {
+          const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+        }
+        u16x4 o;
+        if (EPI == IFX_EPI_BIAS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_tanh_q(rbf(v[e])));
+        } else {
+          const u16x4 rv = *reinterpret_cast<const u16x4*>(ea.residual + (size_t)m * ea.ld_res + n);
+          if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(v[e]));
+          } else {
+            const u16x4 gv = *reinterpret_cast<const u16x4*>(gate_row + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(rbf(v[e]) * bf2f(gv[e])));
+          }
+        }
+        *reinterpret_cast<u16x4*>(y + (size_t)m * ldy + n) = o;
+      }
+  }
+}
+
+}  // namespace ifx
+
+using namespace ifx;
+
+extern "C" int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int32_t ldq, float* scale, int32_t rows,
+                                   int32_t K, int32_t format, void* stream) {
+  IFX_REQUIRE(x && q && scale && rows >= 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0,
+              "ifx_quant_per_token: bad arguments (K %d)", K);
+  IFX_REQUIRE(format == IFX_Q_FP8_E4M3 || format == IFX_Q_INT8, "ifx_quant_per_token: unknown format %d", format);
+  if (rows == 0) return IFX_OK;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (format == IFX_Q_FP8_E4M3)
+    hipLaunchKernelGGL((quant_rows_kernel<true>), grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned char*)q, ldq,
+                       scale, rows, K);
+  else
+    hipLaunchKernelGGL((quant_rows_kernel<false>), grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned char*)q, ldq,
+                       scale, rows, K);
+  return check_launch("ifx_quant_per_token");
+}
+
+extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                           const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
+                           int32_t format, const ifx_epilogue* epi, void* stream) {
+  IFX_REQUIRE(xq && wq && x_scale && w_scale && y && M >= 0 && N > 0 && K > 0, "ifx_gemm_q8: null/empty operand");
+  IFX_REQUIRE(K % 128 == 0, "ifx_gemm_q8: K (%d) must be a multiple of 128", K);
+  IFX_REQUIRE(N % 4 == 0 && ldx % 16 == 0 && ldy % 4 == 0, "ifx_gemm_q8: N %% 4, ldx %% 16, ldy %% 4 required");
+  IFX_REQUIRE(format == IFX_Q_FP8_E4M3 || format == IFX_Q_INT8, "ifx_gemm_q8: unknown format %d", format);
+  const int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
+  EpiArgsQ ea{x_scale, w_scale, bias, nullptr, 0, nullptr, 1, 0, 1};
+  if (mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES) {
+    IFX_REQUIRE(epi->residual && epi->ld_res % 4 == 0, "ifx_gemm_q8: residual epilogue needs residual/ld_res");
+    ea.residual = epi->residual;
+    ea.ld_res = epi->ld_res;
+  }
+  if (mode == IFX_EPI_GATE_RES) {
+    IFX_REQUIRE(epi->mod && epi->rows_per_group > 0 && epi->gate_slot >= 0 && epi->gate_slot < epi->mod_slots,
+                "ifx_gemm_q8: gate epilogue needs mod/mod_slots/gate_slot/rows_per_group");
+    ea.mod = epi->mod;
+    ea.mod_slots = epi->mod_slots;
+    ea.gate_slot = epi->gate_slot;
+    ea.rows_per_group = epi->rows_per_group;
+  }
+  if (M == 0) return IFX_OK;
+  const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+  const dim3 grid(((tiles_m * tiles_n + 7) / 8) * 8), block(256);
+  const size_t lds = 65536;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned char* xp = (const unsigned char*)xq;
+  const unsigned char* wp = (const unsigned char*)wq;
+#define IFX_LAUNCH_Q8(F, E)                                                                                      \
+  do {                                                                                                           \
+    static bool attr_set = false;                                                                                \
+    if (!attr_set) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)gemm_q8_kernel<F, E>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                                       \
+      attr_set = true;                                                                                           \
+    }                                                                                                            \
+    hipLaunchKernelGGL((gemm_q8_kernel<F, E>), grid, block, lds, s, xp, ldx, wp, y, ldy, M, N, K, tiles_m, tiles_n, \
+                       ea);                                                                                      \
+  } while (0)
+#define IFX_SWITCH_Q8(F)                                                          \
+  switch (mode) {                                                                 \
+    case IFX_EPI_BIAS: IFX_LAUNCH_Q8(F, IFX_EPI_BIAS); break;                     \
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_Q8(F, IFX_EPI_GELU_TANH); break;           \
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_Q8(F, IFX_EPI_RESIDUAL); break;             \
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_Q8(F, IFX_EPI_GATE_RES); break;             \
+    default: set_error("ifx_gemm_q8: unknown epilogue %d", mode); return IFX_EINVAL; \
+  }
+  if (format == IFX_Q_FP8_E4M3) {
+    IFX_SWITCH_Q8(true)
+  } else {
+    IFX_SWITCH_Q8(false)
+  }
+#undef IFX_SWITCH_Q8
+#undef IFX_LAUNCH_Q8
+  return check_launch("ifx_gemm_q8");
+}

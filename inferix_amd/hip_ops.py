@@ -230,6 +230,46 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
     return out
 
 
+def quant_per_token(x: torch.Tensor, fmt: int, q: Optional[torch.Tensor] = None,
+                    scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-token dynamic quantisation of `[rows, K]` bf16 -> (bytes `[rows, K]` uint8, scale `[rows]` fp32)."""
+    lib = _hip.load()
+    rows, K, ldx = _rows2d(x, "x")
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
+    with _timed("quant_per_token", 0.0, 3.0 * rows * K):
+        _hip.check(lib.ifx_quant_per_token(_dev(x, "x"), ldx, _dev(q, "q", torch.uint8), q.stride(0),
+                                           _dev(scale, "scale", torch.float32), rows, K, fmt, _stream()),
+                   "ifx_quant_per_token")
+    return q, scale
+
+
+def linear_q8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+              bias: Optional[torch.Tensor], fmt: int, *, epilogue: int = _hip.IFX_EPI_BIAS,
+              residual: Optional[torch.Tensor] = None, mod: Optional[torch.Tensor] = None, gate_slot: int = 0,
+              rows_per_group: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epilogue(bf16((xq @ wq.T) * (x_scale ⊗ w_scale) + bias)) on fp8 / int8 MFMA (ifx_gemm_q8)."""
+    lib = _hip.load()
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and wq.is_contiguous() and xq.stride(1) == 1
+    out = torch.empty(M, N, dtype=BF16, device=xq.device) if out is None else out
+    _, _, ldy = _rows2d(out, "out")
+    epi = _hip.Epilogue(epilogue, None, 0, None, 1, 0, 1)
+    if residual is not None:
+        _, _, ldr = _rows2d(residual, "residual")
+        epi.residual, epi.ld_res = _dev(residual, "residual"), ldr
+    if mod is not None:
+        assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
+        epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
+    with _timed("gemm_q8", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * N):
+        _hip.check(lib.ifx_gemm_q8(_dev(xq, "xq", torch.uint8), xq.stride(0), _dev(x_scale, "x_scale", torch.float32),
+                                   _dev(wq, "wq", torch.uint8), _dev(w_scale, "w_scale", torch.float32),
+                                   _dev(bias, "bias") if bias is not None else None, _dev(out, "out"), ldy, M, N, K,
+                                   fmt, C.byref(epi), _stream()), "ifx_gemm_q8")
+    return out
+
+
 def kv_roll(kv: KvCacheView, sink_tokens: int, evicted: int, rolled: int, scratch: torch.Tensor) -> None:
     lib = _hip.load()
     ks = kv.struct()

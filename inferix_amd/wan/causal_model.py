@@ -136,7 +136,9 @@ class HipCausalWanModel(torch.nn.Module):
         for t in self.g.values():
             yield t
         for b in self.blocks:
-            yield from b.w.values()
+            for t in b.w.values():
+                if isinstance(t, torch.Tensor):
+                    yield t
 
     def state_dict_keys(self) -> List[str]:
         keys = ["patch_embedding.weight", "patch_embedding.bias"]
@@ -235,6 +237,22 @@ class HipCausalWanModel(torch.nn.Module):
             self._roll_scratch = torch.empty(need, dtype=BF16, device=self.device_)
         ops.kv_roll(view, step.sink_tokens, step.evicted, step.rolled, self._roll_scratch)
 
+    def _lin(self, w: Dict[str, torch.Tensor], key: str, x: torch.Tensor, **kw) -> torch.Tensor:
+        """Linear `key` of a block: bf16 MFMA GEMM, or (after inferix_amd.quant.quantize_dynamic) per-token
+        activation quantisation + fp8 / int8 MFMA GEMM with the same epilogue."""
+        if key + "_q" in w:
+            fmt = w[key + "_fmt"]
+            rows = x.shape[0]
+            xq = self._scratch.get(("xq", rows, x.shape[1]))
+            if xq is None:
+                xq = torch.empty(rows, x.shape[1], dtype=torch.uint8, device=x.device)
+                self._scratch[("xq", rows, x.shape[1])] = xq
+                self._scratch[("xs", rows)] = torch.empty(rows, dtype=torch.float32, device=x.device)
+            xs = self._scratch[("xs", rows)]
+            ops.quant_per_token(x, fmt, q=xq, scale=xs)
+            return ops.linear_q8(xq, xs, w[key + "_q"], w[key + "_s"], w[key + "_b"], fmt, **kw)
+        return ops.linear(x, w[key + "_w"], w[key + "_b"], **kw)
+
     def _run_block(self, l: int, xact: torch.Tensor, El: torch.Tensor, st: dict, meta: dict, cmeta: dict,
                    kv_cache_manager, kv_cache_requests) -> None:
         """One CausalWanAttentionBlock (causal_model.py:384-484) on the in-place activation `xact` [B*N, dim];
@@ -251,7 +269,7 @@ class HipCausalWanModel(torch.nn.Module):
         ub = self._buf("u", B * N, self.ffn_dim)
         # ---------------- self attention ----------------
         ops.layernorm(xact, self.eps, mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
-        ops.linear(h, w["qkv_w"], w["qkv_b"], out=qkv)
+        self._lin(w, "qkv", h, out=qkv)
         explicit = st.get("explicit_slots")          # CausVid: (kv_start, kv_end) given by the caller
         if explicit is None:
             g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
@@ -284,28 +302,28 @@ class HipCausalWanModel(torch.nn.Module):
         if explicit is None:
             self._meta_set(meta, "global_end_index", step.global_end)
             self._meta_set(meta, "local_end_index", step.local_end)
-        ops.linear(ab, w["o_w"], w["o_b"], epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
-                   rows_per_group=rows_per_group, out=xact)
+        self._lin(w, "o", ab, epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
+                  rows_per_group=rows_per_group, out=xact)
         # ---------------- cross attention ----------------
         ops.layernorm(xact, self.eps, gamma=w["n3_w"], beta=w["n3_b"], out=h)
-        ops.linear(h, w["cq_w"], w["cq_b"], out=qb)
+        self._lin(w, "cq", h, out=qb)
         ops.rmsnorm(qb, w["cnq"], self.eps, out=qb)
         for b, req in enumerate(kv_cache_requests):
             cview = self._kv_view(kv_cache_manager, req, blk.kv_cache_manager.cross_name)
             if not cmeta["is_init"]:
                 cb = ctx[b * self.text_len:(b + 1) * self.text_len]
-                kx = ops.linear(cb, w["ck_w"], w["ck_b"])
+                kx = self._lin(w, "ck", cb)
                 ops.rmsnorm(kx, w["cnk"], self.eps, out=cview.k.view(self.text_len, d))
-                ops.linear(cb, w["cv_w"], w["cv_b"], out=cview.v.view(self.text_len, d))
+                self._lin(w, "cv", cb, out=cview.v.view(self.text_len, d))
             ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), cview, self.text_len,
                           out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
         cmeta["is_init"] = True
-        ops.linear(ab, w["co_w"], w["co_b"], epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
+        self._lin(w, "co", ab, epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
         # ---------------- feed forward ----------------
         ops.layernorm(xact, self.eps, mod=El, shift_slot=3, scale_slot=4, rows_per_group=rows_per_group, out=h)
-        ops.linear(h, w["f0_w"], w["f0_b"], epilogue=_hip.IFX_EPI_GELU_TANH, out=ub)
-        ops.linear(ub, w["f2_w"], w["f2_b"], epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=5,
-                   rows_per_group=rows_per_group, out=xact)
+        self._lin(w, "f0", h, epilogue=_hip.IFX_EPI_GELU_TANH, out=ub)
+        self._lin(w, "f2", ub, epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=5,
+                  rows_per_group=rows_per_group, out=xact)
 
 
     # ------------------------------------------------------------------ forward

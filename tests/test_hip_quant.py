@@ -1,0 +1,121 @@
+"""GPU parity tests of the dynamic 8-bit linears (BASELINE config 4 mechanics) against oracle/quant_oracle.py.
+Parity with DAX itself is unpinned (un-vendored dependency); what is checked is the scheme stated in
+include/inferix_hip.h on both sides."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import quant_oracle as Q
+import wan_oracle as O
+from util import assert_bf16_parity, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("fmt", [Q.FP8, Q.INT8])
+@pytest.mark.parametrize("rows,K", [(72, 256), (4680, 1536), (513, 8960), (5, 128)])
+def test_quant_per_token_bit_exact(fmt, rows, K):
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(rows + K + fmt)
+    x = rnd(g, rows, K, scale=3.0)
+    x[1 % rows] = 0                                  # all-zero row -> scale 1, zeros
+    x[2 % rows, 3] = 300.0                           # outlier row
+    q, s = ops.quant_per_token(x.cuda(), fmt)
+    _, s_ref = Q.quantize_rows(x, fmt)
+    assert torch.equal(s.cpu(), s_ref), "per-token scales must be bit-exact (fp32 abs-max / QMAX)"
+    assert torch.equal(q.cpu(), Q.quantized_bytes(x, fmt)), "quantised bytes must be bit-exact"
+
+
+def test_quantize_weight_matches_oracle():
+    from inferix_amd import _hip
+    from inferix_amd.quant import QConfig, quantize_weight
+    g = torch.Generator().manual_seed(1)
+    w = rnd(g, 256, 384, scale=0.05)
+    for fmt in (Q.FP8, Q.INT8):
+        q, s = quantize_weight(w.cuda(), QConfig(fmt, "t"))
+        _, s_ref = Q.quantize_rows(w, fmt)
+        assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu(), Q.quantized_bytes(w, fmt))
+
+
+@pytest.mark.parametrize("fmt", [Q.FP8, Q.INT8])
+@pytest.mark.parametrize("M,N,K", [(72, 256, 256), (300, 640, 256), (4680, 1536, 1536), (130, 256, 640), (77, 64, 128)])
+def test_gemm_q8_vs_oracle(fmt, M, N, K):
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.quant import QConfig, quantize_weight
+    g = torch.Generator().manual_seed(M + N + K + fmt)
+    x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+    wq, sw = quantize_weight(w.cuda(), QConfig(fmt, "t"))
+    xq, sx = ops.quant_per_token(x.cuda(), fmt)
+    got = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt)
+    ref = Q.linear_q8(x, w, b, fmt)
+    assert_bf16_parity(got, ref, what=f"q8 linear fmt={fmt} {M}x{N}x{K}")
+    # and the quantisation error itself is what one expects of 8 bits (sanity vs the bf16 linear)
+    full = torch.nn.functional.linear(x, w, b)
+    assert rel_l2(got.cpu(), full) < (0.06 if fmt == Q.FP8 else 0.03)
+
+
+def test_gemm_q8_epilogues():
+    from inferix_amd import _hip, hip_ops as ops
+    from inferix_amd.quant import QConfig, quantize_weight
+    g = torch.Generator().manual_seed(5)
+    M, N, K, fs = 144, 256, 640 - 0, 48
+    K = 640
+    x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+    res, mod = rnd(g, M, N), rnd(g, M // fs, 6, N, scale=0.5)
+    for fmt in (Q.FP8, Q.INT8):
+        wq, sw = quantize_weight(w.cuda(), QConfig(fmt, "t"))
+        xq, sx = ops.quant_per_token(x.cuda(), fmt)
+        y = Q.linear_q8(x, w, b, fmt)
+        got = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt, epilogue=_hip.IFX_EPI_GELU_TANH)
+        assert_bf16_parity(got, torch.nn.functional.gelu(y, approximate="tanh"), max_ulp=4, max_mismatch_frac=0.05, rel=3e-3,
+                           floor=1.0, what="q8 gelu")   # fp32-accumulated fp8 sums flip more bf16 roundings of y than bf16 GEMMs
+        got = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt, epilogue=_hip.IFX_EPI_RESIDUAL, residual=res.cuda())
+        assert_bf16_parity(got, res + y, max_ulp=2, floor=1.0, what="q8 residual")
+        gate = mod[:, 5].unsqueeze(0).unsqueeze(2)
+        ref = O.gated_residual(res[None], y[None], gate, M // fs)[0]
+        got = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt, epilogue=_hip.IFX_EPI_GATE_RES, residual=res.cuda(),
+                            mod=mod.cuda(), gate_slot=5, rows_per_group=fs)
+        assert_bf16_parity(got, ref, max_ulp=2, floor=1.0, what="q8 gate+residual")
+
+
+@pytest.mark.parametrize("which", ["fp8", "int8"])
+def test_quantize_dynamic_model_rollout(which):
+    """quantize_dynamic on the tiny model with the reference example's exclusion dict: the block linears become
+    8-bit, the rollout stays close to the bf16 rollout (8-bit noise), integer KV trace unchanged."""
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausalInferencePipeline
+    from inferix_amd.quant import (get_dynamic_fp8_per_token_act_per_channel_weight_qconfig,
+                                   get_dynamic_int8_per_token_act_per_channel_weight_qconfig, quantize_dynamic)
+    from inferix_amd.wan import HipCausalWanModel, HipWanDiffusionWrapper
+    from fixture_io import golden
+    fx = golden("rollout_tiny.npz")
+    cfg = O.tiny_config()
+    m = HipCausalWanModel(patch_size=cfg.patch_size, text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
+                          ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
+                          num_heads=cfg.num_heads, num_layers=cfg.num_layers, eps=cfg.eps)
+    m.load_state_dict(O.init_weights(cfg, seed=0))
+    gen = HipWanDiffusionWrapper(model=m, timestep_shift=5.0)
+    qc = (get_dynamic_fp8_per_token_act_per_channel_weight_qconfig() if which == "fp8"
+          else get_dynamic_int8_per_token_act_per_channel_weight_qconfig())
+    quantize_dynamic(gen, {"": qc, "text_embedding": None, "proj_out": None, "head": None})
+    assert m.quantized_linears == cfg.num_layers * 8
+    args = SimpleNamespace(denoising_step_list=fx["steps"].tolist(), warp_denoising_step=True, num_frame_per_block=3,
+                           independent_first_frame=False, context_noise=0, frame_seq_length=cfg.frame_seqlen,
+                           kv_cache_tokens=21 * cfg.frame_seqlen)
+    pe = fx["prompt_embeds"].cuda()
+    pipe = CausalInferencePipeline(args, "cuda", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe},
+                                   vae=None)
+    renoise = [fx[f"renoise_{i}"] for i in range(int(fx["num_renoise"]))]
+    out = pipe.inference(noise=fx["noise"].cuda(), text_prompts=["x"], kv_cache_manager=KVCacheManager("cuda"),
+                         kv_cache_requests=[KVCacheRequest("r")], decode_mode=DecodeMode.NO_DECODE, renoise=renoise)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    r = rel_l2(out.cpu(), fx["out"])
+    assert r < (0.15 if which == "fp8" else 0.08), f"{which} rollout drifted {r:.3f} from the bf16 reference latents"
