@@ -40,6 +40,11 @@ typedef uint16_t ifx_bf16;
 int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */
+/* Kernel-selection override for benchmarking and tests (default 0 = choose by shape):
+ *   "gemm_variant": 1 register-staged 128x128, 2 / 3 / 4 LDS-DMA 256x128 / 128x128 / 64x64 tiles
+ *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong kernel
+ * Results are identical across variants up to fp32 summation order.  Returns IFX_EINVAL for unknown keys. */
+int ifx_set_option(const char* key, int32_t value);
 
 /* ------------------------------------------------------------------------
  * Paged KV cache view (one request, one layer).
@@ -82,6 +87,18 @@ typedef struct {
 int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
                        int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
                        void* stream);
+
+/* Split-KV form of ifx_attn_fwd_paged for launches with few query rows (the sequence-parallel shards of
+ * causal_model.py:939-942: N/P = 585 rows at P = 8, i.e. 36 (tile, head) pairs for 256 CUs).  The key range is cut
+ * into `num_splits` chunks that run as independent workgroups; fp32 partial results go to `workspace` and are
+ * combined with the ifx_lse_merge algebra (distributed.py:30-48) before the single bf16 rounding.  Result: as
+ * ifx_attn_fwd_paged.  ifx_attn_split_plan returns the chunk count that fills the chip for a shape (1 = do not
+ * split) and the workspace size that count needs; no allocation happens inside the library. */
+int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len,
+                            int64_t* workspace_bytes);
+int ifx_attn_fwd_paged_split(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
+                             int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
+                             int32_t num_splits, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Merge two partial attention results over disjoint key sets (split-KV / context
  * parallel).  Replaces update_out_and_lse_pass_q

@@ -56,7 +56,11 @@ SIGNATURES = {
     "ifx_version": (C.c_int, []),
     "ifx_last_error": (C.c_char_p, []),
     "ifx_arch": (C.c_char_p, []),
+    "ifx_set_option": (C.c_int, [C.c_char_p, _i32]),
     "ifx_attn_fwd_paged": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _vp]),
+    "ifx_attn_split_plan": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int64)]),
+    "ifx_attn_fwd_paged_split": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
+                                           C.c_int64, _vp]),
     "ifx_lse_merge": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ifx_rmsnorm_rope_kv_append": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.POINTER(RopeGrid), C.POINTER(KvView),
                                              _i32, _i32, _i32, _f32, _vp]),

@@ -199,10 +199,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
         for (int r = 0; r < 16; ++r)
           if (kidx + (r & 3) + 8 * (r >> 2) >= nkeys) sb[r] = -INFINITY;
       }
-      float mx = max3f(sb[0], sb[1], sb[2]);
+      // The FIRST read of the S accumulators is a compiler-visible instruction: hipcc inserts the MFMA -> VALU
+      // wait states (or useful work) for it, which it does not do for operands of inline asm.  (A v_max3 asm as
+      // first reader was scheduled right behind the last S MFMA and read the accumulators one k-step stale —
+      // still a valid softmax stabiliser, but timing dependent: run-to-run different roundings.)
+      float mx = __builtin_fmaxf(sb[0], sb[1]);
+      mx = max3f(mx, sb[2], m_run);
 #pragma unroll
       for (int r = 3; r < 15; r += 2) mx = max3f(mx, sb[r], sb[r + 1]);
-      mx = max3f(mx, sb[15], m_run);                    // m_new candidate for this half-wave
+      mx = max3f(mx, sb[15], mx);                       // m_new candidate for this half-wave
       const float m_new = half_swap_max(mx);             // >= m_run, identical in lane and lane^32
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);   // exp2(-inf)=0 on the first block
       m_run = m_new;
@@ -221,10 +226,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
       asm volatile("" : "+v"(alpha));       // pin the (rare) branch at the stage boundary: the test must not
                                             // be hoisted into the stage and split its MFMA || VALU region
       if (__any(alpha != 1.0f)) {          // wave-uniform branch; in-place so the common path moves nothing
+        // inline-asm operands are invisible to the hazard recogniser: pad the MFMA -> VALU read (O accumulators
+        // of the PV MFMAs just issued) and the VALU write -> MFMA SrcC read by hand; the branch is rare
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
           for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[d][r]) : "v"(alpha));
+        asm volatile("s_nop 3" ::: "memory");
       }
     };
 
@@ -341,25 +350,17 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
 }
 
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
-                   int heads, int kv_start, int kv_len, float scale, hipStream_t stream);
-
-// 0 = auto (ping-pong 8-wave kernel for the large self-attention launches), 1 = force the 4-wave kernel, 2 = force ping-pong
-static int attn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("IFX_ATTN_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+                   int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, hipStream_t stream);
+size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
+int attn_pp_split_heuristic(int q_rows, int heads, int nkeys);
 
 }  // namespace ifx
 
 using namespace ifx;
 
-extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
-                                  int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
-                                  void* stream) {
+static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv, int32_t q_rows,
+                         int32_t heads, int32_t kv_start, int32_t kv_len, float scale, int32_t splits, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
   IFX_REQUIRE(q && out && kv && kv->k && kv->v, "ifx_attn_fwd_paged: null argument");
   IFX_REQUIRE(kv->head_dim == HD, "ifx_attn_fwd_paged: head_dim %d not built (128 only)", kv->head_dim);
   IFX_REQUIRE(heads > 0 && kv->kv_heads == heads, "ifx_attn_fwd_paged: heads %d vs kv_heads %d", heads,
@@ -369,8 +370,14 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_paged: page_size must be > 0");
   if (q_rows == 0) return IFX_OK;
   const int variant = attn_variant();
+  if (splits > 1) {
+    IFX_REQUIRE(workspace && workspace_bytes >= (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits),
+                "ifx_attn_fwd_paged_split: workspace of %lld B too small for %d splits (need %lld B)",
+                (long long)workspace_bytes, splits, (long long)attn_pp_workspace_bytes(q_rows, heads, splits));
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, (hipStream_t)stream);
+  }
   if (variant == 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, (hipStream_t)stream);
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, (hipStream_t)stream);
   AttnArgs a;
   a.q = q;
   a.out = out;
@@ -398,6 +405,28 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
     else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
   }
   return check_launch("ifx_attn_fwd_paged");
+}
+
+extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
+                                  int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
+                                  void* stream) {
+  return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, 0, stream);
+}
+
+extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len,
+                                       int64_t* workspace_bytes) {
+  int splits = 1;
+  if (q_rows > 0 && heads > 0 && kv_len > kv_start) splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start);
+  if (workspace_bytes) *workspace_bytes = (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits);
+  return splits;
+}
+
+extern "C" int ifx_attn_fwd_paged_split(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv,
+                                        int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
+                                        int32_t num_splits, void* workspace, int64_t workspace_bytes, void* stream) {
+  IFX_REQUIRE(num_splits >= 1 && num_splits <= 64, "ifx_attn_fwd_paged_split: num_splits %d outside [1, 64]", num_splits);
+  return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, workspace_bytes,
+                       stream);
 }
 
 extern "C" int ifx_lse_merge(ifx_bf16* out_a, float* lse_a, const ifx_bf16* out_b, const float* lse_b,

@@ -61,6 +61,11 @@ struct AttnArgsPP {
   KvAddr ka;
   int q_rows, heads, kv_start, kv_len, num_slots, q_tiles, per_xcd, total;
   float scale, scale_log2;
+  // split-KV (SPLIT kernels only): `splits` key chunks of `chunk_tiles` 64-key tiles each; chunk sp of (head, q tile)
+  // writes a normalised fp32 partial O to part_o[sp][row][head][128] and its LSE to part_lse[sp][head][row]
+  int splits, chunk_tiles;
+  float* part_o;
+  float* part_lse;
 };
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
@@ -86,7 +91,7 @@ __device__ __forceinline__ void pp_wait_tiles(int tiles) {
   else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-template <bool PAGED>
+template <bool PAGED, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   using namespace pp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -98,7 +103,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
   const int wi = xcd * A.per_xcd + slot_i;
   if (slot_i >= A.per_xcd || wi >= A.total) return;
-  const int head = wi / A.q_tiles, qt = wi - head * A.q_tiles;
+  // work order (head, key chunk, q tile): the q tiles that stream the same K/V chunk sit on one XCD's L2
+  int head, qt, sp = 0;
+  if (SPLIT) {
+    const int per_head = A.splits * A.q_tiles;
+    head = wi / per_head;
+    const int rem = wi - head * per_head;
+    sp = rem / A.q_tiles;
+    qt = rem - sp * A.q_tiles;
+  } else {
+    head = wi / A.q_tiles;
+    qt = wi - head * A.q_tiles;
+  }
+  const int kv_s = SPLIT ? A.kv_start + sp * A.chunk_tiles * KT : A.kv_start;
+  const int kv_e = SPLIT ? min(A.kv_len, kv_s + A.chunk_tiles * KT) : A.kv_len;
   const int row_stride = A.heads * HD;
 
   const int qrow = qt * QT + wave * 32 + l31;
@@ -124,19 +142,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
     k_voff[r] = row * row_bytes + ((d_pc ^ (row & 15)) << 4);
     v_voff[r] = row * row_bytes + (((((d_pc >> 2) ^ (row & 3)) << 2) | (d_pc & 3)) << 4);
   }
-  const int nkeys = A.kv_len - A.kv_start;
+  const int nkeys = kv_e - kv_s;
   const int NT = (nkeys + KT - 1) / KT;
   // identity page map: descriptor covers logical tokens [0, kv_len); paged: whole cache, keys clamped by hand
-  const unsigned valid_rows = PAGED ? (unsigned)A.num_slots : (unsigned)A.kv_len;
+  const unsigned valid_rows = PAGED ? (unsigned)A.num_slots : (unsigned)kv_e;
   const unsigned nrec = (valid_rows - 1) * (unsigned)row_bytes + 256u;
   const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.k + head * HD), 0, nrec, 0x00020000);
   const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.v + head * HD), 0, nrec, 0x00020000);
-  const int last_key = A.kv_len - 1;
+  const int last_key = kv_e - 1;
   auto issue = [&](int t) {
     unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
     unsigned char* vb = smem + V_OFF + (t % RV) * 16384;
     if (!PAGED) {
-      const int soff = (A.kv_start + t * KT) * row_bytes;
+      const int soff = (kv_s + t * KT) * row_bytes;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (pp_lds_ptr_t)(kb + (r * 8 + wave) * 1024), 16, k_voff[r], soff, 0, 0);
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int key = min(A.kv_start + t * KT + d_rowi[r], last_key);
+        const int key = min(kv_s + t * KT + d_rowi[r], last_key);
         const int delta = (A.ka.slot(key) - d_rowi[r]) * row_bytes;      // physical row instead of tile row
         __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (pp_lds_ptr_t)(kb + (r * 8 + wave) * 1024), 16, k_voff[r] + delta, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (pp_lds_ptr_t)(vb + (r * 8 + wave) * 1024), 16, v_voff[r] + delta, 0, 0, 0);
@@ -259,7 +277,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
         for (int r = 0; r < 16; ++r)
           if (kidx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) s[b][r] = -INFINITY;
     }
-    float mx = pp_max3(s[0][0], s[1][0], m_run);
+    // first read of the S accumulators through a compiler-visible instruction (MFMA -> VALU wait states are not
+    // inserted for inline-asm operands; a wave that arrives last at the barrier starts this step at once)
+    float mx = pp_max3(__builtin_fmaxf(s[0][0], s[1][0]), m_run, m_run);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = pp_max3(mx, s[0][r], s[1][r]);
     const float m_new = pp_half_max(mx);
@@ -278,10 +298,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
     l_run = l_run * alpha + ps;
     asm volatile("" : "+v"(alpha));
     if (__any(alpha != 1.0f)) {
+      asm volatile("s_nop 7" ::: "memory");          // hazards around inline-asm operands are padded by hand (rare path)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[d][r]) : "v"(alpha));
+      asm volatile("s_nop 3" ::: "memory");
     }
   };
 
@@ -331,6 +353,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
+  if (SPLIT) {
+    if (qrow < A.q_rows) {
+      float* op = A.part_o + ((size_t)sp * A.q_rows + qrow) * row_stride + head * HD + 4 * hi;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e] * inv;
+          *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) = w;
+        }
+      if (hi == 0) A.part_lse[((size_t)sp * A.heads + head) * A.q_rows + qrow] = m_run * A.scale + __logf(l_tot);
+    }
+    return;
+  }
   if (qrow < A.q_rows) {
     unsigned short* op = A.out + (size_t)qrow * row_stride + head * HD + 4 * hi;
 #pragma unroll
@@ -346,8 +384,56 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   }
 }
 
+// out[row][head][:] = sum_s w_s * part_o[s][row][head][:],  w_s = exp(lse_s - LSE) ; LSE = log sum_s exp(lse_s)
+// (the same algebra as ifx_lse_merge, over `splits` fp32 partials, rounded to bf16 once)
+__global__ __launch_bounds__(256) void attn_split_merge_kernel(const float* __restrict__ part_o,
+                                                               const float* __restrict__ part_lse,
+                                                               unsigned short* __restrict__ out, float* __restrict__ lse,
+                                                               int q_rows, int heads, int splits) {
+  const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);      // (row, head) pair, 32 lanes x 4 channels
+  if (pair >= q_rows * heads) return;
+  const int row = pair / heads, head = pair - row * heads, c = (threadIdx.x & 31) * 4;
+  float mx = -INFINITY;
+  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, part_lse[((size_t)s * heads + head) * q_rows + row]);
+  float den = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float w = __expf(part_lse[((size_t)s * heads + head) * q_rows + row] - mx);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + (((size_t)s * q_rows + row) * heads + head) * 128 + c);
+    den += w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+  }
+  const float inv = 1.0f / den;
+  u16x4 w4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w4[e] = f2bf(acc[e] * inv);
+  *reinterpret_cast<u16x4*>(out + ((size_t)row * heads + head) * 128 + c) = w4;
+  if (lse != nullptr && c == 0) lse[(size_t)head * q_rows + row] = mx + __logf(den);
+}
+
+size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits) {
+  return splits <= 1 ? 0 : (size_t)splits * q_rows * heads * (128 + 1) * sizeof(float);
+}
+
+// number of key chunks that fills the chip: one 8-wave workgroup per CU, 256 CUs
+int attn_pp_split_heuristic(int q_rows, int heads, int nkeys) {
+  using namespace pp;
+  const int tiles = ((q_rows + QT - 1) / QT) * heads;
+  const int nt = (nkeys + KT - 1) / KT;
+  if (tiles >= 176 || nt < 16) return 1;               // >= ~70 % of the CUs already busy / nothing to split
+  int best = 1;
+  float best_eff = (float)tiles / 256.f;
+  for (int s = 2; s <= 32 && s * 8 <= nt; ++s) {        // chunks of >= 8 tiles (512 keys)
+    const int wg = tiles * s, rounds = (wg + 255) / 256;
+    const float eff = (float)wg / (256.f * rounds) * (1.f - 0.01f * s);   // small per-chunk prologue/merge penalty
+    if (eff > best_eff + 1e-3f) best_eff = eff, best = s;
+  }
+  return best;
+}
+
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
-                   int heads, int kv_start, int kv_len, float scale, hipStream_t stream) {
+                   int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, hipStream_t stream) {
   using namespace pp;
   AttnArgsPP a;
   a.q = q;
@@ -362,19 +448,40 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.kv_len = kv_len;
   a.num_slots = kv->num_slots;
   a.q_tiles = (q_rows + QT - 1) / QT;
-  a.total = a.q_tiles * heads;
+  const int nt = (kv_len - kv_start + KT - 1) / KT;
+  splits = max(1, min(splits, nt));
+  a.chunk_tiles = (nt + splits - 1) / splits;
+  a.splits = (nt + a.chunk_tiles - 1) / a.chunk_tiles;   // no empty chunk
+  a.part_o = (float*)workspace;
+  a.part_lse = a.part_o ? a.part_o + (size_t)a.splits * q_rows * heads * 128 : nullptr;
+  a.total = a.q_tiles * heads * a.splits;
   a.per_xcd = (a.total + 7) / 8;
   a.scale = scale > 0.f ? scale : 0.08838834764831845f;
   a.scale_log2 = a.scale * 1.4426950408889634f;
   const dim3 grid(a.per_xcd * 8), block(512);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  if (kv->page_table) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, block, LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid, block, LDS_BYTES, stream, a);
+  if (a.splits > 1) {
+    if (workspace == nullptr) {
+      set_error("ifx_attn_fwd_paged_split: splits > 1 needs a workspace");
+      return IFX_EINVAL;
+    }
+    if (kv->page_table) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), grid, block, LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true>), grid, block, LDS_BYTES, stream, a);
+    const int pairs = q_rows * heads;
+    hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, a.part_o, a.part_lse, out,
+                       lse, q_rows, heads, a.splits);
+  } else if (kv->page_table) {
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false>), grid, block, LDS_BYTES, stream, a);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false>), grid, block, LDS_BYTES, stream, a);
+  }
   return check_launch("ifx_attn_fwd_paged(pp)");
 }
 

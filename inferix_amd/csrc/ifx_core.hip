@@ -1,5 +1,6 @@
 // Library identity + error plumbing of libinferix_hip (C-ABI: include/inferix_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ifx_common.h"
@@ -14,6 +15,18 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// kernel-selection overrides (ifx_set_option); -1 = unset -> environment variable -> 0 (auto)
+static int g_gemm_variant = -1, g_attn_variant = -1;
+static int opt_or_env(int& slot, const char* env) {
+  if (slot < 0) {
+    const char* e = getenv(env);
+    slot = e ? atoi(e) : 0;
+  }
+  return slot;
+}
+int gemm_variant() { return opt_or_env(g_gemm_variant, "IFX_GEMM_VARIANT"); }
+int attn_variant() { return opt_or_env(g_attn_variant, "IFX_ATTN_VARIANT"); }
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -27,3 +40,9 @@ int check_launch(const char* what) {
 extern "C" int ifx_version(void) { return (0 << 16) | (1 << 8) | 0; }
 extern "C" const char* ifx_last_error(void) { return ifx::g_err; }
 extern "C" const char* ifx_arch(void) { return "gfx950"; }
+extern "C" int ifx_set_option(const char* key, int32_t value) {
+  if (key && !strcmp(key, "gemm_variant") && value >= 0 && value <= 4) { ifx::g_gemm_variant = value; return IFX_OK; }
+  if (key && !strcmp(key, "attn_variant") && value >= 0 && value <= 2) { ifx::g_attn_variant = value; return IFX_OK; }
+  ifx::set_error("ifx_set_option: unknown key or value out of range: %s = %d", key ? key : "(null)", (int)value);
+  return IFX_EINVAL;
+}

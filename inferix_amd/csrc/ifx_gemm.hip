@@ -175,16 +175,21 @@ int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, 
                      int N, int K, int mode, const unsigned short* bias, const unsigned short* residual, int ld_res,
                      const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group, hipStream_t s);
 
-// kernel selection: 0 = auto (LDS-DMA 256x128 kernel for M >= 1024, else the 128x128 kernel), 1 = force v1, 2 = force glds
-static int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("IFX_GEMM_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
+int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
+                        int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
+                        int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
+                        hipStream_t s);
+
+// LDS-DMA tile choice: the largest tile that still gives every CU a workgroup (256 CUs); tiny shapes take 64x64
+static int pick_tile(int M, int N) {
+  auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  if (wgs(256, 128) >= 224) return 0;
+  if (wgs(128, 128) >= 200) return 1;
+  return 2;
 }
 
+// kernel selection: 0 = auto (LDS-DMA kernels, tile by shape), 1 = force the register-staged 128x128 kernel,
+// 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64
 }  // namespace ifx
 
 using namespace ifx;
@@ -212,9 +217,11 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
   if (M == 0) return IFX_OK;
   const int variant = gemm_variant();
   const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0);
-  if (wide_ok && (variant == 2 || (variant == 0 && M >= 1024)))
-    return launch_gemm_glds(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots,
-                            ea.gate_slot, ea.rows_per_group, (hipStream_t)stream);
+  if (wide_ok && variant != 1) {
+    const int tile = variant >= 2 ? variant - 2 : pick_tile(M, N);
+    return launch_gemm_lds_dma(tile, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod,
+                               ea.mod_slots, ea.gate_slot, ea.rows_per_group, (hipStream_t)stream);
+  }
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const dim3 grid(((tiles_m * tiles_n + 7) / 8) * 8), block(256);
   const size_t lds = 65536;

@@ -258,6 +258,215 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small-M kernel family (sequence-parallel shards: M = 2340 / 1170 / 585 token rows per GPU).  With 256x128
+// tiles such launches leave most CUs idle (M=585, N=1536: 36 workgroups for 256 CUs) and the register-staged
+// 128^2 kernel is latency-bound at one workgroup per CU (28 us for 585x1536x1536).  Here: BM x BN in
+// {128x128, 64x64}, 4 waves (2x2), same LDS-DMA staging / swizzle / transposed MFMA tile / LDS-transposed
+// epilogue as above, a 4-stage ring with THREE K-tiles in flight and one barrier per K-tile; the 64x64 shape
+// uses 64 KiB of LDS so two workgroups share a CU and hide each other's waits.
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                         const unsigned short* __restrict__ w,
+                                                         unsigned short* __restrict__ y, int ldy, int M, int N, int K,
+                                                         int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
+  constexpr int BK = 64, NST = 4;
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int A_OFF = 0, B_OFF = BM * BK * 2;
+  constexpr int PA = BM / 32, PB = BN / 32, P = PA + PB;     // DMA instructions per wave per K-tile
+  constexpr int TJ = BM / 64, TI = BN / 64;                  // 32-blocks per wave: tokens, channels
+  constexpr int WM = BM / 2, WN = BN / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int t_id = xcd * per_xcd + slot_i;
+  if (slot_i >= per_xcd || t_id >= total) return;
+  constexpr int GM = 4;
+  const int tiles_n = total / tiles_m;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  const int r8 = lane >> 3, pc = lane & 7;
+  const unsigned short* src_a[PA];
+  const unsigned short* src_b[PB];
+#pragma unroll
+  for (int r = 0; r < PA; ++r) {
+    const int row = (r * 4 + wave) * 8 + r8;
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int r = 0; r < PB; ++r) {
+    const int row = (r * 4 + wave) * 8 + r8;
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 1) & 7)) * 8;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % NST) * STAGE;
+    const size_t ko = (size_t)kt * BK;
+#pragma unroll
+    for (int r = 0; r < PA; ++r)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < PB; ++r)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko), (lds_ptr_t)(st + B_OFF + (r * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = K / BK;
+  issue(0);
+  if (KT > 1) issue(1);
+  if (KT > 2) issue(2);
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  int a_row_off[TJ], b_row_off[TI], a_swz[TJ], b_swz[TI];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int row = wm * WM + j * 32 + l31;
+    a_row_off[j] = A_OFF + row * 128;
+    a_swz[j] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int row = wn * WN + i * 32 + l31;
+    b_row_off[i] = B_OFF + row * 128;
+    b_swz[i] = (row >> 1) & 7;
+  }
+
+  for (int kt = 0; kt < KT; ++kt) {
+    // own pieces of tile kt landed; up to two later tiles stay in flight
+    const int later = min(KT - 1 - kt, 2);
+    if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own fragment reads of tile kt-1 retired
+    __builtin_amdgcn_s_barrier();          // tile kt complete for everyone; slot (kt-1)%4 drained by everyone
+    if (kt + 3 < KT) issue(kt + 3);
+    const unsigned char* st = smem + (kt % NST) * STAGE;
+    bf16x8 fa[4][TJ], fb[4][TI];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + hi;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fb[ks][i] = *reinterpret_cast<const bf16x8*>(st + b_row_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fa[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_row_off[j] + ((c ^ a_swz[j]) << 4));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue: per-wave LDS transpose of v = bf16(acc + bias), then row-contiguous 16-byte accesses
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int RB = WN * 2, CR = RB / 16, RP = 64 / CR;     // row bytes, 16-B chunks per row, rows per instruction
+  unsigned char* tw = smem + wave * (WM * RB);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int mrow = j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = i * 32 + g * 8 + hi * 4;
+        const int n = n_base + wn * WN + nl;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (ea.bias && n < N) {
+          const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        const int chunk = (nl >> 3) ^ (mrow & (CR - 1));
+        *reinterpret_cast<u16x4*>(tw + mrow * RB + chunk * 16 + (nl & 4) * 2) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rr = lane / CR, cc = lane % CR;
+#pragma unroll
+    for (int p = 0; p < WM / RP; ++p) {
+      const int mrow = p * RP + rr;
+      const int m = m_base + wm * WM + mrow;
+      const int n = n_base + wn * WN + cc * 8;
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * RB + ((cc ^ (mrow & (CR - 1))) << 4));
+      if (m >= M || n >= N) continue;
+      u16x8 o;
+      if (EPI == IFX_EPI_BIAS) {
+        o = vv;
+      } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+      } else {
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
+        if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + bf2f(vv[e]));
+        } else {
+          const u16x8 gv = *reinterpret_cast<const u16x8*>(
+              ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+        }
+      }
+      *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+    }
+  }
+}
+
+template <int BM, int BN>
+static int launch_small(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
+                        int N, int K, int mode, const EpiArgs2& ea, hipStream_t s) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const dim3 grid(per_xcd * 8), block(256);
+  constexpr size_t lds = (size_t)4 * (BM + BN) * 128;
+#define IFX_LAUNCH_GS(E)                                                                                             \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_small_kernel<BM, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                           \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_small_kernel<BM, BN, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
+                       per_xcd, ea);                                                                                 \
+  } while (0)
+  switch (mode) {
+    case IFX_EPI_BIAS: IFX_LAUNCH_GS(IFX_EPI_BIAS); break;
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_GS(IFX_EPI_GELU_TANH); break;
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_GS(IFX_EPI_RESIDUAL); break;
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_GS(IFX_EPI_GATE_RES); break;
+    default: return IFX_EINVAL;
+  }
+#undef IFX_LAUNCH_GS
+  return check_launch("ifx_gemm_bf16(small)");
+}
+
+// tile: 0 = 256x128 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64
+int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
+                        int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
+                        int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
+                        hipStream_t s);
+
 // host launcher used by ifx_gemm_bf16 (ifx_gemm.hip) for large shapes
 int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                      int N, int K, int mode, const unsigned short* bias, const unsigned short* residual, int ld_res,
@@ -290,6 +499,18 @@ int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, 
   }
 #undef IFX_LAUNCH_G2
   return check_launch("ifx_gemm_bf16(glds)");
+}
+
+int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
+                        int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
+                        int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
+                        hipStream_t s) {
+  if (tile == 0)
+    return launch_gemm_glds(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot,
+                            rows_per_group, s);
+  EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
+  if (tile == 1) return launch_small<128, 128>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  return launch_small<64, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 
 }  // namespace ifx

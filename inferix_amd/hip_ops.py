@@ -180,9 +180,29 @@ def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[tor
     return q_out
 
 
+def set_option(key: str, value: int) -> None:
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..4, 'attn_variant' 0..2; 0 = choose by shape."""
+    _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
+
+
+_ATTN_WS: dict = {}      # (device index, stream) -> fp32 split-KV workspace, grown on demand
+_SPLIT_PLAN: dict = {}   # (rows, heads, nkeys) -> (splits, workspace bytes)
+
+
+def _attn_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    key = (dev.index, _stream())
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        _ATTN_WS[key] = ws
+    return ws
+
+
 def attention(q: torch.Tensor, kv: KvCacheView, kv_len: int, scale: float = 0.0,
-              out: Optional[torch.Tensor] = None, return_lse: bool = False, tag: str = "attn", kv_start: int = 0):
-    """softmax(q K^T * scale) V over logical cache tokens [kv_start, kv_len) read in place. q `[rows, heads, 128]`."""
+              out: Optional[torch.Tensor] = None, return_lse: bool = False, tag: str = "attn", kv_start: int = 0,
+              splits: Optional[int] = None):
+    """softmax(q K^T * scale) V over logical cache tokens [kv_start, kv_len) read in place. q `[rows, heads, 128]`.
+    `splits`: key chunks run as independent workgroups (None = ifx_attn_split_plan decides; 1 = never split)."""
     lib = _hip.load()
     assert q.dim() == 3 and q.is_contiguous()
     rows, heads, hd = q.shape
@@ -191,11 +211,27 @@ def attention(q: torch.Tensor, kv: KvCacheView, kv_len: int, scale: float = 0.0,
     ks = kv.struct()
     d = heads * hd
     nk = kv_len - kv_start
+    if splits is None:
+        plan = _SPLIT_PLAN.get((rows, heads, nk))
+        if plan is None:
+            need = C.c_int64(0)
+            plan = (int(lib.ifx_attn_split_plan(rows, heads, int(kv_start), int(kv_len), C.byref(need))), int(need.value))
+            _SPLIT_PLAN[(rows, heads, nk)] = plan
+        splits, ws_bytes = plan
+    else:
+        ws_bytes = splits * rows * heads * (hd + 1) * 4 if splits > 1 else 0
+    lse_p = _dev(lse, "lse", torch.float32) if lse is not None else None
     with _timed(tag, 4.0 * rows * nk * d, 2.0 * (2 * rows * d + 2 * nk * d)):
-        _hip.check(lib.ifx_attn_fwd_paged(_dev(q, "q"), _dev(out, "out"),
-                                          _dev(lse, "lse", torch.float32) if lse is not None else None,
-                                          C.byref(ks), rows, heads, int(kv_start), int(kv_len), float(scale), _stream()),
-                   "ifx_attn_fwd_paged")
+        if splits > 1:
+            ws = _attn_workspace(q.device, ws_bytes)
+            _hip.check(lib.ifx_attn_fwd_paged_split(_dev(q, "q"), _dev(out, "out"), lse_p, C.byref(ks), rows, heads,
+                                                    int(kv_start), int(kv_len), float(scale), int(splits),
+                                                    ws.data_ptr(), ws.numel() * 4, _stream()),
+                       "ifx_attn_fwd_paged_split")
+        else:
+            _hip.check(lib.ifx_attn_fwd_paged(_dev(q, "q"), _dev(out, "out"), lse_p, C.byref(ks), rows, heads,
+                                              int(kv_start), int(kv_len), float(scale), _stream()),
+                       "ifx_attn_fwd_paged")
     return (out, lse) if return_lse else out
 
 

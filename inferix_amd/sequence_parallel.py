@@ -93,11 +93,31 @@ class SequenceParallelExchange:
         return g.reshape(batch * frames * P * hw_local, c)
 
 
+class LoopbackExchange(SequenceParallelExchange):
+    """One rank of a `world`-way shard without a process group: the gather replicates the local rows `world`
+    times (a device copy instead of the collective).  Used by `bench.py --emulate-sp P` to time one rank's compute
+    on a single GPU; results are not a valid clip."""
+
+    def __init__(self, world: int, rank: int = 0):
+        self.group = None
+        self.world = world
+        self.rank = rank
+        self._slot_cache = {}
+        self._flat_ok = True
+
+    def all_gather_rows(self, local, out=None):
+        if out is None:
+            out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                              device=local.device)
+        out.view(self.world, *local.shape).copy_(local.unsqueeze(0).expand(self.world, *local.shape))
+        return out
+
+
 class HipSequenceParallel:
     """GPU side: what HipCausalWanModel calls per layer when world_size > 1."""
 
-    def __init__(self, group=None, overlap: bool = True):
-        self.ex = SequenceParallelExchange(group)
+    def __init__(self, group=None, overlap: bool = True, exchange: Optional[SequenceParallelExchange] = None):
+        self.ex = exchange if exchange is not None else SequenceParallelExchange(group)
         self.overlap = overlap
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._buf: Dict[Tuple, torch.Tensor] = {}
@@ -162,9 +182,10 @@ class HipSequenceParallel:
         return self.ex.gather_head(y_local, batch, frames)
 
 
-def attach_sequence_parallel(model, group=None, overlap: bool = True) -> HipSequenceParallel:
+def attach_sequence_parallel(model, group=None, overlap: bool = True,
+                             exchange: Optional[SequenceParallelExchange] = None) -> HipSequenceParallel:
     """Enable sequence parallelism on a HipCausalWanModel whose ParallelConfig has world_size > 1."""
-    sp = HipSequenceParallel(group, overlap)
+    sp = HipSequenceParallel(group, overlap, exchange)
     pc = model.parallel_config
     if pc.world_size != sp.ex.world or pc.rank != sp.ex.rank:
         raise ValueError(f"ParallelConfig (rank {pc.rank}/{pc.world_size}) does not match the process group "

@@ -122,7 +122,7 @@ def test_rope_golden(ops):
             assert_bf16_parity(qo.view(72, 2, 128), ref[0], floor=1.0, what="rope golden path")
 
 
-def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None):
+def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None, splits=None):
     g = torch.Generator().manual_seed(seed + rows + kv_len)
     hd = 128
     q = rnd(g, rows, heads, hd)
@@ -144,7 +144,7 @@ def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None):
         slot = perm[t // ps] * ps + t % ps
         kc[slot], vc[slot] = k, v
         view = ops.KvCacheView(gpu(kc), gpu(vc), gpu(perm.to(torch.int32)), ps)
-    out, lse = ops.attention(gpu(q), view, kv_len, return_lse=True)
+    out, lse = ops.attention(gpu(q), view, kv_len, return_lse=True, splits=splits)
     torch.cuda.synchronize()
     ref64, lse64 = O.attention_with_lse(q[None], k[None], v[None])
     ref_bf = O.attention(q[None], k[None], v[None])            # the reference's CPU path (SDPA bf16)
@@ -181,6 +181,36 @@ def test_attention_golden(ops):
 def test_attention_paged(ops):
     _attn_case(ops, 72, 2, 200, cap=240, page=24)
     _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
+
+
+@pytest.mark.parametrize("rows,heads,kv_len,splits,page", [
+    (72, 2, 1000, 2, None), (129, 2, 1025, 3, None), (300, 12, 2048, 7, None), (40, 2, 130, 5, None),
+    (130, 12, 1000, 4, 120), (72, 2, 200, 2, 24), (585, 12, 4680, None, None)])
+def test_attention_split_kv(ops, rows, heads, kv_len, splits, page):
+    """Split-KV launch (sequence-parallel shard shapes): chunks run as independent workgroups, fp32 partials are
+    merged before the single bf16 rounding -> same bound vs exact attention as the unsplit kernel."""
+    _attn_case(ops, rows, heads, kv_len, cap=(kv_len + 119) // 120 * 120 if page else kv_len + 5, page=page, splits=splits)
+
+
+def test_attention_split_plan_and_workspace_errors(ops):
+    import ctypes as C
+    from inferix_amd import _hip
+    lib = _hip.load()
+    need = C.c_int64(-1)
+    assert lib.ifx_attn_split_plan(4680, 12, 0, 32760, C.byref(need)) == 1 and need.value == 0
+    s = lib.ifx_attn_split_plan(585, 12, 0, 32760, C.byref(need))
+    assert 2 <= s <= 32 and need.value == s * 585 * 12 * 129 * 4
+    assert lib.ifx_attn_split_plan(585, 12, 0, 512, C.byref(need)) == 1          # too few keys to split
+    g = torch.Generator().manual_seed(0)
+    q, k = gpu(rnd(g, 64, 2, 128)), gpu(rnd(g, 256, 2, 128))
+    ws = torch.empty(16, dtype=torch.float32, device="cuda")
+    ks = ops.KvCacheView(k, k).struct()
+    rc = lib.ifx_attn_fwd_paged_split(q.data_ptr(), torch.empty_like(q).data_ptr(), None, C.byref(ks), 64, 2, 0, 256, 0.0,
+                                      2, ws.data_ptr(), 64, None)
+    assert rc != 0 and b"workspace" in lib.ifx_last_error()
+    rc = lib.ifx_attn_fwd_paged_split(q.data_ptr(), torch.empty_like(q).data_ptr(), None, C.byref(ks), 64, 2, 0, 256, 0.0,
+                                      0, None, 0, None)
+    assert rc != 0
 
 
 def test_attention_480p_block_shapes(ops):
@@ -271,6 +301,76 @@ def test_gemm_ffn_real_shapes(ops):
     assert_bf16_parity(u, u_ref, max_ulp=2, floor=1.0, what="ffn.0+gelu 1536->8960")
     y = ops.linear(gpu(u_ref), gpu(w2), gpu(b2))
     assert_bf16_parity(y, torch.nn.functional.linear(u_ref, w2, b2), what="ffn.2 8960->1536")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(585, 1536, 1536), (300, 640, 256), (77, 64, 64), (1170, 4608, 1536)])
+def test_gemm_every_tile_variant(ops, variant, M, N, K):
+    """Each GEMM kernel (register-staged 128x128, LDS-DMA 256x128 / 128x128 / 64x64) on shard shapes with ragged
+    M and N edges, all four epilogues; the auto choice is covered by the other tests."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(M + N + variant)
+    fs = (M + 2) // 3
+    x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+    res, mod = rnd(g, M, N), rnd(g, 3, 6, N, scale=0.5)
+    y = torch.nn.functional.linear(x, w, b)
+    ops.set_option("gemm_variant", variant)
+    try:
+        assert_bf16_parity(ops.linear(gpu(x), gpu(w), gpu(b)), y, what=f"variant {variant} bias")
+        got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_GELU_TANH)
+        assert_bf16_parity(got, torch.nn.functional.gelu(y, approximate="tanh"), max_ulp=2, floor=1.0,
+                           what=f"variant {variant} gelu")   # bf16(gelu(bf16(y))): two chained roundings
+        got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_RESIDUAL, residual=gpu(res))
+        assert_bf16_parity(got, res + y, max_ulp=2, floor=1.0, what=f"variant {variant} residual")
+        gate = torch.repeat_interleave(mod[:, 2], fs, dim=0)[:M]
+        got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_GATE_RES, residual=gpu(res), mod=gpu(mod),
+                         gate_slot=2, rows_per_group=fs)
+        assert_bf16_parity(got, res + (y * gate).to(BF), max_ulp=2, floor=1.0, what=f"variant {variant} gate+residual")
+    finally:
+        ops.set_option("gemm_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_both_kernels(ops, variant):
+    ops.set_option("attn_variant", variant)
+    try:
+        _attn_case(ops, 300, 12, 2048, cap=2100)
+        _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
+    finally:
+        ops.set_option("attn_variant", 0)
+
+
+def test_kernels_are_run_to_run_deterministic(ops):
+    """Same inputs -> same bits, launch after launch (a v_max3 inline-asm read scheduled right behind the last
+    S MFMA once read stale accumulators: still valid softmax, but timing-dependent roundings).  Shapes large enough
+    that waves of different workgroups share SIMDs."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(21)
+    rows, heads, L, dim, ffn = 585, 12, 4680, 1536, 8960
+    q, k, v = gpu(rnd(g, rows, heads, 128)), gpu(rnd(g, L, heads, 128)), gpu(rnd(g, L, heads, 128))
+    x, w, b = gpu(rnd(g, rows, dim)), gpu(rnd(g, ffn, dim, scale=dim ** -0.5)), gpu(rnd(g, ffn, scale=0.1))
+    junk = torch.zeros(2048, 2048, device="cuda")
+
+    def stable(fn, reps=40):
+        ref = fn().clone()
+        for i in range(reps):
+            if i % 3 == 0:
+                junk.add_(1.0)
+            if not torch.equal(fn(), ref):
+                return False
+        return True
+    try:
+        for av in (1, 2):
+            ops.set_option("attn_variant", av)
+            assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
+        ops.set_option("attn_variant", 0)
+        assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=4)), "split-KV attention"
+        for gv in (1, 2, 3, 4):
+            ops.set_option("gemm_variant", gv)
+            assert stable(lambda: ops.linear(x, w, b, epilogue=_hip.IFX_EPI_GELU_TANH), reps=15), f"gemm variant {gv}"
+    finally:
+        ops.set_option("attn_variant", 0)
+        ops.set_option("gemm_variant", 0)
 
 
 def test_kv_roll(ops):

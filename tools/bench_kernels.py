@@ -17,17 +17,19 @@ g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=10, warm=3, inner=10):
+    """median / min over `iters` samples of the mean of `inner` back-to-back launches (hides launch gaps)"""
     for _ in range(warm):
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(iters):
         s.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e.record()
         e.synchronize()
-        ts.append(s.elapsed_time(e))
+        ts.append(s.elapsed_time(e) / inner)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 
@@ -41,14 +43,17 @@ if what in ("gemm", "all"):
               ("o     N=1536 K=1536 gate", x, rnd(d, d) * 0.03, rnd(d), dict(epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=2, rows_per_group=(M + 2) // 3)),
               ("ffn0  N=8960 K=1536 gelu", x, rnd(f, d) * 0.03, rnd(f), dict(epilogue=_hip.IFX_EPI_GELU_TANH)),
               ("ffn2  N=1536 K=8960 gate", u, rnd(d, f) * 0.01, rnd(d), dict(epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=5, rows_per_group=(M + 2) // 3))]
-    tot = 0.0
-    for name, a, w, b, kw in shapes:
-        out = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=dev)
-        med, mn = timeit(lambda: ops.linear(a, w, b, out=out, **kw))
-        fl = 2.0 * M * w.shape[0] * w.shape[1]
-        tot += med
-        print(f"gemm {name}: {med*1e3:8.1f} us (min {mn*1e3:7.1f})  {fl/med/1e9:7.1f} TFLOP/s")
-    print(f"gemm sum of 4 = {tot*1e3:.1f} us  (variant env IFX_GEMM_VARIANT={os.environ.get('IFX_GEMM_VARIANT', '0')})")
+    for variant in ([0] if M >= 4000 else [0, 1, 2, 3, 4]):
+        ops.set_option("gemm_variant", variant)
+        tot = 0.0
+        for name, a, w, b, kw in shapes:
+            out = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=dev)
+            med, mn = timeit(lambda: ops.linear(a, w, b, out=out, **kw))
+            fl = 2.0 * M * w.shape[0] * w.shape[1]
+            tot += med
+            print(f"gemm v{variant} {name}: {med*1e3:8.1f} us (min {mn*1e3:7.1f})  {fl/med/1e9:7.1f} TFLOP/s")
+        print(f"gemm v{variant} sum of 4 = {tot*1e3:.1f} us")
+    ops.set_option("gemm_variant", 0)
 if what in ("attn", "all"):
     q = rnd(M, H, D)
     for blk in (1, 4, 7):
@@ -74,3 +79,15 @@ if what in ("norm", "all"):
     w1 = rnd(d)
     med, _ = timeit(lambda: ops.rmsnorm_rope_kv_append(qkv, w1, w1, 1e-6, rope, ops.KvCacheView(kc, vc), 0, d))
     print(f"rmsnorm+rope+append: {med*1e3:7.1f} us  {12.0*M*d/med/1e6:7.1f} GB/s")
+if what == "split":
+    q = rnd(M, H, D)
+    for blk in (1, 4, 7):
+        L = blk * 4680
+        k, v = rnd(L, H, D), rnd(L, H, D)
+        out = torch.empty_like(q)
+        fl = 4.0 * M * L * H * D
+        res = []
+        for sp in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, None):
+            med, mn = timeit(lambda: ops.attention(q, ops.KvCacheView(k, v), L, out=out, splits=sp), iters=10)
+            res.append(f"{'auto' if sp is None else sp}:{med*1e3:.0f}")
+        print(f"attn M={M} L={L:6d} us by splits  " + "  ".join(res) + f"   ideal@972TF {fl/972e6:.0f}")
