@@ -219,6 +219,15 @@ int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* w
 int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t evicted, int32_t rolled,
                 ifx_bf16* scratch, void* stream);
 
+/* Sequence-parallel cache write (the "cache write post-a2a" of CoreAttention.forward,
+ * inferix/models/attention/distributed.py:183-208, for the replicated-cache design of DESIGN.md §6): the
+ * all-gathered K/V rows of the new block, rank-major
+ *   gathered [world][2 (K,V)][frames*hw_local][kv_heads*128] bf16,
+ * go to the cache slots of logical tokens local_start + f*frame_tokens + r*hw_local + i, i.e. the single-GPU
+ * (frame, hw) order of causal_model.py:939-942 / 1008-1022, through the page table when there is one. */
+int ifx_kv_scatter_shards(const ifx_bf16* gathered, int32_t world, int32_t frames, int32_t hw_local,
+                          int32_t frame_tokens, int32_t local_start, const ifx_kv_view* kv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

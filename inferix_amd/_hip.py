@@ -61,6 +61,7 @@ SIGNATURES = {
     "ifx_attn_split_plan": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int64)]),
     "ifx_attn_fwd_paged_split": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
                                            C.c_int64, _vp]),
+    "ifx_kv_scatter_shards": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(KvView), _vp]),
     "ifx_lse_merge": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ifx_rmsnorm_rope_kv_append": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.POINTER(RopeGrid), C.POINTER(KvView),
                                              _i32, _i32, _i32, _f32, _vp]),

@@ -254,6 +254,29 @@ __global__ __launch_bounds__(256) void kv_copy_rows_kernel(const unsigned short*
   }
 }
 
+// Sequence-parallel cache write: rank-major all-gathered K/V rows -> cache slots in the single-GPU (frame, hw) order.
+//   gathered [world][2][frames*hw_local][row_elems]   (per rank: K rows then V rows of its shard)
+//   row (r, f, i) -> logical token local_start + f*frame_tokens + r*hw_local + i
+__global__ __launch_bounds__(256) void kv_scatter_shards_kernel(const unsigned short* __restrict__ gathered,
+                                                                unsigned short* __restrict__ kc,
+                                                                unsigned short* __restrict__ vc, KvAddr ka, int world,
+                                                                int frames, int hw_local, int frame_tokens,
+                                                                int local_start, int row_elems) {
+  const int n_local = frames * hw_local;
+  const int chunks = row_elems / 8;
+  const size_t total = (size_t)world * n_local * chunks;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / chunks), c = (int)(i - (size_t)row * chunks);
+    const int r = row / n_local, j = row - r * n_local;
+    const int f = j / hw_local, w = j - f * hw_local;
+    const int tok = local_start + f * frame_tokens + r * hw_local + w;
+    const size_t d = (size_t)ka.slot(tok) * row_elems + c * 8;
+    const unsigned short* ks = gathered + ((size_t)(2 * r) * n_local + j) * row_elems + c * 8;
+    *reinterpret_cast<u16x8*>(kc + d) = *reinterpret_cast<const u16x8*>(ks);
+    *reinterpret_cast<u16x8*>(vc + d) = *reinterpret_cast<const u16x8*>(ks + (size_t)n_local * row_elems);
+  }
+}
+
 template <typename F>
 static int dispatch_nch(int dim, F&& f) {
   const int nch = (dim + 511) / 512;
@@ -365,4 +388,23 @@ extern "C" int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t e
                        sink_tokens, rolled, row_elems, 0, 1);
   }
   return check_launch("ifx_kv_roll");
+}
+
+extern "C" int ifx_kv_scatter_shards(const ifx_bf16* gathered, int32_t world, int32_t frames, int32_t hw_local,
+                                     int32_t frame_tokens, int32_t local_start, const ifx_kv_view* kv, void* stream) {
+  IFX_REQUIRE(gathered && kv && kv->k && kv->v, "ifx_kv_scatter_shards: null argument");
+  IFX_REQUIRE(world > 0 && frames > 0 && hw_local > 0 && world * hw_local <= frame_tokens && local_start >= 0,
+              "ifx_kv_scatter_shards: bad shard geometry (world %d, frames %d, hw_local %d, frame_tokens %d)", world,
+              frames, hw_local, frame_tokens);
+  IFX_REQUIRE(local_start + (frames - 1) * frame_tokens + world * hw_local <= kv->num_slots,
+              "ifx_kv_scatter_shards: tokens [%d, %d) exceed the cache capacity %d", local_start,
+              local_start + (frames - 1) * frame_tokens + world * hw_local, kv->num_slots);
+  if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_kv_scatter_shards: page_size must be > 0");
+  const int row_elems = kv->kv_heads * kv->head_dim;
+  IFX_REQUIRE(row_elems % 8 == 0, "ifx_kv_scatter_shards: row of %d elements is not 16-byte granular", row_elems);
+  const size_t total = (size_t)world * frames * hw_local * (row_elems / 8);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(kv_scatter_shards_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gathered, kv->k, kv->v,
+                     KvAddr{kv->page_table, kv->page_size}, world, frames, hw_local, frame_tokens, local_start, row_elems);
+  return check_launch("ifx_kv_scatter_shards");
 }

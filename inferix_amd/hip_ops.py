@@ -235,6 +235,16 @@ def attention(q: torch.Tensor, kv: KvCacheView, kv_len: int, scale: float = 0.0,
     return (out, lse) if return_lse else out
 
 
+def kv_scatter_shards(gathered: torch.Tensor, world: int, frames: int, hw_local: int, frame_tokens: int,
+                      local_start: int, kv: KvCacheView) -> None:
+    """All-gathered `[world, 2, frames*hw_local, heads, 128]` K/V rows -> cache slots in the (frame, hw) token order."""
+    assert gathered.is_contiguous() and gathered.numel() == world * 2 * frames * hw_local * kv.k.shape[-2] * kv.k.shape[-1]
+    ks = kv.struct()
+    with _timed("kv_scatter", 0.0, 2.0 * gathered.numel() * 2):
+        _hip.check(_hip.load().ifx_kv_scatter_shards(_dev(gathered, "gathered"), world, frames, hw_local, frame_tokens,
+                                                     int(local_start), C.byref(ks), _stream()), "ifx_kv_scatter_shards")
+
+
 def lse_merge(out_a: torch.Tensor, lse_a: torch.Tensor, out_b: torch.Tensor, lse_b: torch.Tensor) -> None:
     lib = _hip.load()
     rows, heads, _ = out_a.shape

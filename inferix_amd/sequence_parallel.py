@@ -149,22 +149,24 @@ class HipSequenceParallel:
         stage = self._scratch("kv_stage", (2, n_local, H, hd), torch.bfloat16, dev)
         ops.rmsnorm_rope_kv_append(qkv_b, w["nq"], w["nk"], model.eps, rope, ops.KvCacheView(stage[0], stage[1]), 0,
                                    d, q_out=q_out)
-        kv_local = stage.permute(1, 0, 2, 3)                              # [n_local, 2, H, D] view
-        gathered = self._scratch("kv_gather", (N, 2, H, hd), torch.bfloat16, dev)
-        kv_local_c = self._scratch("kv_local", (n_local, 2, H, hd), torch.bfloat16, dev)
-        kv_local_c.copy_(kv_local)
+        gathered = self._scratch("kv_gather", (P, 2, n_local, H, hd), torch.bfloat16, dev)
         qv = q_out.view(n_local, H, hd)
         av = a_out.view(n_local, H, hd)
-        pt = view.page_table
         have_prefix = step.local_start > 0
+
+        def exchange():
+            # one collective: [2, n_local, H, D] per rank -> [P, 2, n_local, H, D]; one kernel scatters K and V rows
+            # to their cache slots (through the page table when there is one)
+            self.ex.all_gather_rows(stage.view(2 * n_local, H * hd), gathered.view(P * 2 * n_local, H * hd))
+            ops.kv_scatter_shards(gathered, P, frames, rope.hw_local, fs, step.local_start, view)
+
         if self.overlap and have_prefix and dev.type == "cuda":
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=dev)
             main = torch.cuda.current_stream(dev)
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
-                self.ex.exchange_new_block(kv_local_c, view.k, view.v, step.local_start, frames, fs, pt,
-                                           view.page_size, gathered)
+                exchange()
             # main stream: attend to the old prefix while the collective is in flight
             o1, l1 = ops.attention(qv, view, step.local_start, out=av, return_lse=True, tag="attn_self")
             main.wait_stream(self.comm_stream)
@@ -173,8 +175,7 @@ class HipSequenceParallel:
                                   kv_start=step.local_start)
             ops.lse_merge(av, l1, o2, l2)
         else:
-            self.ex.exchange_new_block(kv_local_c, view.k, view.v, step.local_start, frames, fs, pt, view.page_size,
-                                       gathered)
+            exchange()
             ops.attention(qv, view, step.local_end, out=av, tag="attn_self")
         return step
 

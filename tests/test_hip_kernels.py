@@ -373,6 +373,35 @@ def test_kernels_are_run_to_run_deterministic(ops):
         ops.set_option("gemm_variant", 0)
 
 
+@pytest.mark.parametrize("paged", [False, True])
+def test_kv_scatter_shards(ops, paged):
+    """Rank-major gathered K/V rows land in the (frame, rank, hw) token order, bit-exact (integer permutation)."""
+    g = torch.Generator().manual_seed(31)
+    P, frames, hw_local, heads, hd = 4, 3, 6, 2, 128
+    fs, local_start, cap = P * hw_local, 48, 168
+    n_local = frames * hw_local
+    gathered = rnd(g, P, 2, n_local, heads, hd)
+    k0, v0 = rnd(g, cap, heads, hd), rnd(g, cap, heads, hd)
+    pt, ps = None, 1
+    if paged:
+        ps = fs
+        pt = torch.randperm(cap // ps, generator=g).to(torch.int32)
+    kr, vr = k0.clone(), v0.clone()
+    for r in range(P):
+        for f in range(frames):
+            for i in range(hw_local):
+                tok = local_start + f * fs + r * hw_local + i
+                slot = int(pt[tok // ps]) * ps + tok % ps if paged else tok
+                kr[slot], vr[slot] = gathered[r, 0, f * hw_local + i], gathered[r, 1, f * hw_local + i]
+    kg, vg = gpu(k0), gpu(v0)
+    ops.kv_scatter_shards(gpu(gathered), P, frames, hw_local, fs, local_start,
+                          ops.KvCacheView(kg, vg, gpu(pt) if paged else None, ps))
+    assert torch.equal(kg.cpu(), kr) and torch.equal(vg.cpu(), vr)
+    from inferix_amd import _hip
+    with pytest.raises(_hip.HipKernelError):
+        ops.kv_scatter_shards(gpu(gathered), P, frames, hw_local, fs, cap - 10, ops.KvCacheView(kg, vg))
+
+
 def test_kv_roll(ops):
     g = torch.Generator().manual_seed(12)
     cap, heads, hd = 144, 2, 128
