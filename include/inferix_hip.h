@@ -79,7 +79,9 @@ typedef struct {
  * (causal_model.py:307-315).  Replaces `attention()` / `flash_attention()`
  * (inferix/models/attention/flash_attention.py:42-200) and the registry backends'
  * (out, lse) contract (inferix/models/attention/backends.py:36-76).
- *   q, out : [q_rows, heads, 128] bf16 (row stride = heads*128)
+ *   q, out : [q_rows, heads, 128] bf16 (row stride = heads*128); heads may be a multiple of kv->kv_heads
+ *            (grouped-query attention, MAGI: query head h reads kv head h / (heads/kv_heads),
+ *            inferix/models/magi/dit/dit_module.py:975-1018)
  *   lse    : optional [heads, q_rows] fp32 (natural log), NULL to skip
  *   scale  : softmax scale (1/sqrt(128) when <= 0)
  * bf16 in, fp32 softmax/accumulate, P rounded to bf16 for the PV product, bf16 out.

@@ -46,6 +46,7 @@ struct AttnArgs {
   const unsigned short* v;
   KvAddr ka;
   int q_rows, heads, kv_start, kv_len, q_tiles, per_xcd, total;   // keys [kv_start, kv_len)
+  int kv_heads, q_per_kv;   // grouped-query attention: query head h reads kv head h / q_per_kv
   float scale, scale_log2;
 };
 
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const int wi = xcd * A.per_xcd + slot_i;
   if (slot_i >= A.per_xcd || wi >= A.total) return;
   const int head = wi / A.q_tiles, qt = wi - head * A.q_tiles;
-  const int row_stride = A.heads * HD;   // elements between consecutive tokens
+  const int row_stride = A.heads * HD;   // elements between consecutive tokens (q, out)
+  const int kv_stride = A.kv_heads * HD;  // ... of the cache rows
+  const int kvh = head / A.q_per_kv;
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[q = l31][16*ks + 8*hi + 0..7]
   const int qrow = qt * QT + wave * 32 + l31;
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
     k_src_c[r] = (d_pc ^ (row & 15)) * 8;                  // element offset inside the 128-element head row
     v_src_c[r] = ((((d_pc >> 2) ^ (row & 3)) << 2) | (d_pc & 3)) * 8;
   }
-  const unsigned short* kbase = A.k + head * HD;
-  const unsigned short* vbase = A.v + head * HD;
+  const unsigned short* kbase = A.k + kvh * HD;
+  const unsigned short* vbase = A.v + kvh * HD;
   const int last_key = A.kv_len - 1;
   // issue<CLAMP=false>: steady-state tiles (all 64 keys valid) use one 64-bit add per piece
   auto issue = [&](int t, int buf, auto clamp_tag) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
     for (int r = 0; r < 4; ++r) {
       int key = A.kv_start + t * KT + d_rowi[r];
       if (CLAMP) key = min(key, last_key);                                 // ragged tail: re-read a valid row
-      const size_t off = (size_t)(PAGED ? A.ka.slot(key) : key) * row_stride;
+      const size_t off = (size_t)(PAGED ? A.ka.slot(key) : key) * kv_stride;
       __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)(kbase + off + k_src_c[r]),
                                        (attn_lds_ptr_t)(kb + (r * 4 + wave) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)(vbase + off + v_src_c[r]),
@@ -363,8 +366,8 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
                          int64_t workspace_bytes, void* stream) {
   IFX_REQUIRE(q && out && kv && kv->k && kv->v, "ifx_attn_fwd_paged: null argument");
   IFX_REQUIRE(kv->head_dim == HD, "ifx_attn_fwd_paged: head_dim %d not built (128 only)", kv->head_dim);
-  IFX_REQUIRE(heads > 0 && kv->kv_heads == heads, "ifx_attn_fwd_paged: heads %d vs kv_heads %d", heads,
-              kv->kv_heads);
+  IFX_REQUIRE(heads > 0 && kv->kv_heads > 0 && heads % kv->kv_heads == 0,
+              "ifx_attn_fwd_paged: heads %d is not a multiple of kv_heads %d", heads, kv->kv_heads);
   IFX_REQUIRE(q_rows >= 0 && kv_start >= 0 && kv_len > kv_start && kv_len <= kv->num_slots,
               "ifx_attn_fwd_paged: key range [%d, %d) out of range (capacity %d)", kv_start, kv_len, kv->num_slots);
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_paged: page_size must be > 0");
@@ -389,6 +392,8 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
   a.heads = heads;
   a.kv_start = kv_start;
   a.kv_len = kv_len;
+  a.kv_heads = kv->kv_heads;
+  a.q_per_kv = heads / kv->kv_heads;
   a.q_tiles = (q_rows + QT - 1) / QT;
   a.total = a.q_tiles * heads;
   a.per_xcd = (a.total + 7) / 8;

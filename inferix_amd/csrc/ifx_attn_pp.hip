@@ -64,6 +64,7 @@ struct AttnArgsPP {
   // split-KV (SPLIT kernels only): `splits` key chunks of `chunk_tiles` 64-key tiles each; chunk sp of (head, q tile)
   // writes a normalised fp32 partial O to part_o[sp][row][head][128] and its LSE to part_lse[sp][head][row]
   int splits, chunk_tiles;
+  int kv_heads, q_per_kv;   // grouped-query attention: query head h reads kv head h / q_per_kv
   float* part_o;
   float* part_lse;
 };
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   //      live (row * row_bytes + swizzled source chunk); the tile offset is a scalar soffset.  Rows beyond the
   //      descriptor's range (keys >= kv_len in the ragged last tile) read as ZERO by the hardware bounds check.
   const int d_row = lane >> 4, d_pc = lane & 15;
-  const int row_bytes = row_stride * 2;
+  const int row_bytes = A.kv_heads * HD * 2;     // cache row pitch
+  const int kvh = head / A.q_per_kv;
   int k_voff[2], v_voff[2], d_rowi[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   // identity page map: descriptor covers logical tokens [0, kv_len); paged: whole cache, keys clamped by hand
   const unsigned valid_rows = PAGED ? (unsigned)A.num_slots : (unsigned)kv_e;
   const unsigned nrec = (valid_rows - 1) * (unsigned)row_bytes + 256u;
-  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.k + head * HD), 0, nrec, 0x00020000);
-  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.v + head * HD), 0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.k + kvh * HD), 0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.v + kvh * HD), 0, nrec, 0x00020000);
   const int last_key = kv_e - 1;
   auto issue = [&](int t) {
     unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
@@ -447,6 +449,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.kv_start = kv_start;
   a.kv_len = kv_len;
   a.num_slots = kv->num_slots;
+  a.kv_heads = kv->kv_heads;
+  a.q_per_kv = heads / kv->kv_heads;
   a.q_tiles = (q_rows + QT - 1) / QT;
   const int nt = (kv_len - kv_start + KT - 1) / KT;
   splits = max(1, min(splits, nt));

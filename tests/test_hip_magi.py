@@ -1,0 +1,181 @@
+"""GPU: MAGI attention path (row a17) on the HIP kernels — grouped-query range attention read in place from the cache,
+the cache adapter against the reference's golden, and the Ulysses scheduler end to end with 2 ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import magi_cp_oracle as M  # noqa: E402
+from fixture_io import golden  # noqa: E402
+from util import rel_l2  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def _meta(q_range, k_range, **kw):
+    from inferix_amd.magi.types import ModelMetaArgs, PackedCoreAttnParams
+    qr, kr = np.asarray(q_range, dtype=np.int64), np.asarray(k_range, dtype=np.int64)
+    core = PackedCoreAttnParams(q_range=torch.tensor(qr), k_range=torch.tensor(kr), np_q_range=qr, np_k_range=kr,
+                                max_seqlen_q=int((qr[:, 1] - qr[:, 0]).max()), max_seqlen_k=int((kr[:, 1] - kr[:, 0]).max()))
+    base = dict(H=1, W=1, cp_pad_size=0, cp_split_sizes=None, slice_point=0, denoising_range_num=len(qr), range_num=len(qr),
+                extract_prefix_video_feature=False, fwd_extra_1st_chunk=False, distill_nearly_clean_chunk=False,
+                clip_token_nums=1, enable_cuda_graph=False, core_attn_params=core, cross_attn_params=None)
+    base.update(kw)
+    return ModelMetaArgs(**base)
+
+
+@pytest.mark.parametrize("hq,hk,sq,sk", [(3, 1, 300, 700), (12, 4, 130, 1100), (24, 8, 64, 64), (3, 1, 1200, 2500)])
+def test_gqa_range_attention_vs_oracle(hq, hk, sq, sk):
+    """Two denoising ranges with different key windows; query head h reads kv head h // (hq/hk).  Bound: as close to
+    exact attention as bf16-P flash attention is (tests/test_hip_kernels.py states the same tolerance)."""
+    from inferix_amd.magi.attention import core_attention
+    g = torch.Generator().manual_seed(hq * 1000 + sq)
+    q = torch.randn(sq, hq, 128, generator=g).to(BF)
+    k = torch.randn(sk, hk, 128, generator=g).to(BF)
+    v = torch.randn(sk, hk, 128, generator=g).to(BF)
+    h = sq // 2
+    q_range, k_range = [[0, h], [h, sq]], [[0, sk - 37], [5, sk]]
+    out = core_attention(q.cuda(), k.cuda(), v.cuda(), 1, _meta(q_range, k_range))
+    torch.cuda.synchronize()
+    ref = M.core_attention(q, k, v, q_range, k_range, out_dtype=torch.float64)
+    assert (out.cpu().double() - ref).abs().max().item() < 1.5e-2
+    assert rel_l2(out.cpu(), ref) < 3e-3
+
+
+def test_kv_cache_adapter_matches_reference_golden():
+    """Same call sequence as the reference's MagiKVCacheManager fixture: returned keys/values and the stored cache
+    are bit-identical, although nothing is concatenated here (in-place slots + scratch tail + token map)."""
+    from inferix_amd.magi.attention import MagiKVCacheManager
+    from inferix_amd.magi.types import InferenceParams
+    fx = golden("magi_cp.npz")
+    hn, hd, clip, cap = int(fx["kvm_hn"]), int(fx["kvm_hd"]), int(fx["kvm_clip"]), int(fx["kvm_max_tokens"])
+    mgr = MagiKVCacheManager(0, hn, hd, None)
+    ip = InferenceParams(1, cap, device="cuda")
+    for i in range(int(fx["kvm_kv_calls"])):
+        n, sp, upd, fe, di = fx[f"kvm_kv{i}_args"].tolist()
+        ip.update_kv_cache = bool(upd)
+        meta = _meta([[0, 1]], [[0, 1]], slice_point=sp, fwd_extra_1st_chunk=bool(fe), distill_nearly_clean_chunk=bool(di),
+                     clip_token_nums=clip)
+        handle = mgr.adjust_key_and_value_for_inference(fx[f"kvm_kv{i}_in"].cuda(), ip, meta)
+        k, v = handle.materialize()
+        assert handle.kv_len == fx[f"kvm_kv{i}_k"].shape[0] and handle.kv_heads == hn
+        assert torch.equal(k.cpu(), fx[f"kvm_kv{i}_k"]) and torch.equal(v.cpu(), fx[f"kvm_kv{i}_v"]), i
+    raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0")
+    stored = 18      # rows the rule stored: call 0 -> [0, 12), call 1 (nearly-clean: all but the last chunk) -> [12, 18)
+    assert torch.equal(raw[:, :stored].cpu(), fx["kvm_kv_cache_final"][:, :stored])
+    assert mgr.is_cached(ip) and mgr.get_cache_size(ip) == raw.numel()
+    mgr.clear_cache(ip)
+    assert not mgr.is_cached(ip)
+
+
+def test_attention_over_cache_with_unstored_tail():
+    """Prefix from the cache + new rows of which the last chunk is NOT stored (nearly-clean rule): attention through
+    the token map equals attention over the concatenation the reference would have built."""
+    from inferix_amd.magi.attention import MagiKVCacheManager, core_attention
+    from inferix_amd.magi.types import InferenceParams
+    g = torch.Generator().manual_seed(5)
+    hq, hk, hd, clip = 3, 1, 128, 200
+    mgr = MagiKVCacheManager(3, hk, hd, None)
+    ip = InferenceParams(1, 4 * clip, device="cuda")
+    oracle = M.MagiCacheOracle(4 * clip, hk, hd)
+    kv0 = torch.randn(2 * clip, hk, 2 * hd, generator=g).to(BF)
+    ip.update_kv_cache = True
+    m0 = _meta([[0, 2 * clip]], [[0, 2 * clip]], fwd_extra_1st_chunk=True, clip_token_nums=clip)
+    mgr.adjust_key_and_value_for_inference(kv0.cuda(), ip, m0)
+    oracle.adjust(kv0, slice_point=0, clip_token_nums=clip, update_kv_cache=True, fwd_extra_1st_chunk=True)
+    kv1 = torch.randn(2 * clip, hk, 2 * hd, generator=g).to(BF)
+    q = torch.randn(2 * clip, hq, hd, generator=g).to(BF)
+    q_range, k_range = [[0, clip], [clip, 2 * clip]], [[0, 3 * clip], [clip, 4 * clip]]
+    m1 = _meta(q_range, k_range, slice_point=2, distill_nearly_clean_chunk=True, clip_token_nums=clip)
+    handle = mgr.adjust_key_and_value_for_inference(kv1.cuda(), ip, m1)
+    assert handle.view.page_table is not None and handle.kv_len == 4 * clip
+    out = core_attention(q.cuda(), handle, None, 1, m1)
+    kr, vr = oracle.adjust(kv1, slice_point=2, clip_token_nums=clip, update_kv_cache=True, distill_nearly_clean_chunk=True)
+    ref = M.core_attention(q, kr, vr, q_range, k_range, out_dtype=torch.float64)
+    assert rel_l2(out.cpu(), ref) < 3e-3
+    raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_3")
+    assert torch.equal(raw[:, :3 * clip].cpu(), oracle.mem[:, :3 * clip])      # stored rows: [0, 2 clip) + [2 clip, 3 clip)
+    with pytest.raises(ValueError):
+        core_attention(q.cuda(), handle, None, 1, _meta([[0, clip]], [[0, 5 * clip]]))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CP2 = dict(S=301, HQ=6, HK=2, HD=128, PREFIX=256)
+
+
+def _sched_inputs():
+    g = torch.Generator().manual_seed(99)
+    c = CP2
+    q = torch.randn(c["S"], c["HQ"], c["HD"], generator=g).to(BF)
+    kv = torch.randn(c["S"], c["HK"], 2 * c["HD"], generator=g).to(BF)
+    prefix = torch.randn(c["PREFIX"], c["HK"], 2 * c["HD"], generator=g).to(BF)
+    return q, kv, prefix
+
+
+def _sched_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from inferix_amd.magi import context_parallel as cp
+        from inferix_amd.magi.attention import MagiKVCacheManager, core_attention
+        from inferix_amd.magi.types import InferenceParams
+        cp.set_cp_group(dist.group.WORLD)
+        c = CP2
+        q, kv, prefix = _sched_inputs()
+        sizes = [c["S"] // world + (1 if r < c["S"] % world else 0) for r in range(world)]
+        off = sum(sizes[:rank])
+        q_loc, kv_loc = q[off:off + sizes[rank]].contiguous(), kv[off:off + sizes[rank]].contiguous()
+        hk_loc = c["HK"] // world
+        # this rank's kv-head slice of the clean prefix is already in its cache (clip = PREFIX tokens, slice_point 1)
+        mgr = MagiKVCacheManager(0, hk_loc, c["HD"], None)
+        ip = InferenceParams(1, c["PREFIX"] + c["S"], device="cuda")
+        ip.update_kv_cache = True
+        pm = _meta([[0, 1]], [[0, 1]], fwd_extra_1st_chunk=True, clip_token_nums=c["PREFIX"])
+        mgr.adjust_key_and_value_for_inference(prefix[:, rank * hk_loc:(rank + 1) * hk_loc].contiguous().cuda(), ip, pm)
+        ip.update_kv_cache = False
+        total = c["PREFIX"] + c["S"]
+        meta = _meta([[0, c["S"]]], [[0, total]], slice_point=1, clip_token_nums=c["PREFIX"])
+        # the exchange runs on host tensors over gloo (any backend); cache and attention are the HIP product path
+        core, _ = cp.UlyssesScheduler.get_attn_and_xattn_with_fused_kv_comm(
+            lambda: q_loc, lambda: kv_loc,
+            lambda t: (mgr.adjust_key_and_value_for_inference(t.cuda(), ip, meta), None),
+            lambda qq, k, v: core_attention(qq.cuda(), k, None, 1, meta).cpu(), lambda: None, -1, 1, world, sizes)
+        torch.cuda.synchronize()
+        ret[rank] = core
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ulysses_scheduler_two_ranks_hip_attention_and_cache():
+    """2 ranks (both on cuda:0; host-side gloo exchange): sharded sequence, one kv head per rank, 3 query heads each,
+    cached prefix + new keys.  The gathered result equals plain grouped-query attention over prefix + sequence."""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sched_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        outs = [ret[r] for r in range(world)]
+    c = CP2
+    q, kv, prefix = _sched_inputs()
+    full_kv = torch.cat([prefix, kv], dim=0)
+    ref = M.exact_attention(q, full_kv[..., :c["HD"]], full_kv[..., c["HD"]:]).reshape(c["S"], 1, c["HQ"] * c["HD"])
+    got = torch.cat(outs, dim=0)
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < 3e-3 and (got.double() - ref).abs().max().item() < 1.5e-2
