@@ -30,6 +30,11 @@
 #ifndef PP_ABLATE
 #define PP_ABLATE 0
 #endif
+// PP_TRACE=1 (tools/trace_attn.sh): workgroup 0 stamps the cycle counter at the step boundaries of its first 64 tiles
+// into the LSE buffer (as int64 [tile][wave][4]: M start, M end, V start, V end).  0 in the shipped library.
+#ifndef PP_TRACE
+#define PP_TRACE 0
+#endif
 #ifndef PP_PRIO
 #define PP_PRIO 1      // 1: s_setprio(1) around the MFMA step (+4 % measured), 2: around the softmax step (+1 %)
 #endif
@@ -50,6 +55,7 @@ constexpr int PD = PP_PD;
 constexpr int RK = PD + 1, RV = PD + 2;
 constexpr int K_OFF = 0, V_OFF = RK * 16384;
 constexpr int LDS_BYTES = (RK + RV) * 16384;   // 114688
+constexpr int LDS_ALLOC = LDS_BYTES + (PP_TRACE ? 32768 : 0);
 }  // namespace pp
 
 struct AttnArgsPP {
@@ -70,6 +76,28 @@ struct AttnArgsPP {
 };
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
+typedef int pp_v4i __attribute__((ext_vector_type(4)));
+typedef float pp_f32x2 __attribute__((ext_vector_type(2)));
+
+// One LDS-DMA instruction (64 lanes x 16 B, lane-linear at LDS byte address `lds`), issued from inline asm ON PURPOSE:
+// hipcc tracks the LDS-DMA builtins as LDS stores and puts `s_waitcnt vmcnt(0)` in front of the next ds_read that
+// might alias them — here every fragment read of the MFMA step — which drains the whole prefetch queue once per tile.
+// The ring discipline below (counted vmcnt + workgroup barrier before a slot is read) is what orders DMA and reads.
+__device__ __forceinline__ void pp_dma16(pp_v4i rsrc, unsigned lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");      // m0 is a reserved register: hipcc sets it itself right before each of its own uses
+}
+__device__ __forceinline__ pp_v4i pp_make_rsrc(const void* base, unsigned num_bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  pp_v4i r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xffffu);      // stride 0
+  r[2] = (int)num_bytes;
+  r[3] = 0x00020000;
+  return r;
+}
 typedef const __attribute__((address_space(1))) void* pp_gbl_ptr_t;
 
 __device__ __forceinline__ float pp_max3(float a, float b, float c) {
@@ -128,6 +156,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
+  // Retire the Q loads HERE with a wait the compiler can see (vmcnt(0), expcnt/lgkmcnt untouched).  Otherwise it
+  // carries them as "maybe pending" around the loop back-edge and protects every first use of qf in the loop with
+  // vmcnt(7..0) — which, since the asm-issued DMA below shares the counter, drains the K/V prefetch queue every tile.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   // ---- LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): a tile is 16 K pieces + 16 V pieces of
   //      1 KiB (4 key rows x 256 B); wave w moves pieces w and w+8.  Per lane only a 32-bit voffset per piece is
@@ -149,26 +181,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   // identity page map: descriptor covers logical tokens [0, kv_len); paged: whole cache, keys clamped by hand
   const unsigned valid_rows = PAGED ? (unsigned)A.num_slots : (unsigned)kv_e;
   const unsigned nrec = (valid_rows - 1) * (unsigned)row_bytes + 256u;
-  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.k + kvh * HD), 0, nrec, 0x00020000);
-  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A.v + kvh * HD), 0, nrec, 0x00020000);
+  const pp_v4i krs = pp_make_rsrc(A.k + kvh * HD, nrec);
+  const pp_v4i vrs = pp_make_rsrc(A.v + kvh * HD, nrec);
+  const unsigned lds0 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem + wave * 1024;
   const int last_key = kv_e - 1;
   auto issue = [&](int t) {
-    unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
-    unsigned char* vb = smem + V_OFF + (t % RV) * 16384;
+    const unsigned kb = lds0 + K_OFF + (t % RK) * 16384;
+    const unsigned vb = lds0 + V_OFF + (t % RV) * 16384;
     if (!PAGED) {
       const int soff = (kv_s + t * KT) * row_bytes;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (pp_lds_ptr_t)(kb + (r * 8 + wave) * 1024), 16, k_voff[r], soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (pp_lds_ptr_t)(vb + (r * 8 + wave) * 1024), 16, v_voff[r], soff, 0, 0);
+        pp_dma16(krs, kb + r * 8192, k_voff[r], soff);
+        pp_dma16(vrs, vb + r * 8192, v_voff[r], soff);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int key = min(kv_s + t * KT + d_rowi[r], last_key);
         const int delta = (A.ka.slot(key) - d_rowi[r]) * row_bytes;      // physical row instead of tile row
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (pp_lds_ptr_t)(kb + (r * 8 + wave) * 1024), 16, k_voff[r] + delta, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (pp_lds_ptr_t)(vb + (r * 8 + wave) * 1024), 16, v_voff[r] + delta, 0, 0, 0);
+        pp_dma16(krs, kb + r * 8192, k_voff[r] + delta, 0);
+        pp_dma16(vrs, vb + r * 8192, v_voff[r] + delta, 0);
       }
     }
   };
@@ -188,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   f32x16 s[2];
   bf16x8 pb[2][2];
   bf16x8 fA[4], fB[4];
+  pb[0][0] = pb[0][1] = pb[1][0] = pb[1][1] = bf16x8{};      // P(-1) = 0 for the unconditional PV of tile 0
   if (PP_ABLATE) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) fA[i] = fB[i] = bf16x8{};
@@ -229,8 +263,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   // ---- step M(t): PV(t-1) then QK(t); fragment batches double buffered through fA / fB
   auto stepM = [&](int t) {
     const unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
-    if (t > 0) {
-      const unsigned char* vb = smem + V_OFF + ((t - 1) % RV) * 16384;
+    {
+      // PV(t-1).  At t == 0 there is no previous tile: P is all zero (initialised below) and the V fragments are
+      // read from tile 0, whose DMA has landed — O += V^T * 0.  Unconditional on purpose: a branch here made the
+      // O accumulators a phi and cost 32 v_mov_b64 per tile.
+      const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
       ldV(fA, vb, 0, 0);
       ldV(fB, vb, 0, 1);
       PP_SB();
@@ -244,10 +281,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
       ldK(fA, kb, 0, 0);
       PP_SB();
       mmaV(fB, pb[1][1]);
-      ldK(fB, kb, 0, 1);
-      PP_SB();
-    } else {
-      ldK(fA, kb, 0, 0);
       ldK(fB, kb, 0, 1);
       PP_SB();
     }
@@ -288,16 +321,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
     float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
     m_run = m_new;
     const float mc = m_new * c2;
-    float ps = 0.f;
+    // Packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction).  While its partner wave owns the
+    // matrix pipe this wave is the ONLY one issuing VALU work on the SIMD, and a single wave issues a VALU
+    // instruction only every ~10 cycles (tools/probe_overlap.hip) — the step is bound by instruction COUNT.
+    const pp_f32x2 c2v = {c2, c2}, mcv = {mc, mc};
+    pp_f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[b][r] * c2 - mc);
-        ps += p;
-        pb[b][r >> 3][r & 7] = static_cast<__bf16>(p);
+      for (int i = 0; i < 8; ++i) {
+        const pp_f32x2 sv = {s[b][2 * i], s[b][2 * i + 1]};
+        const pp_f32x2 e = sv * c2v - mcv;
+        const pp_f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        if (i & 1) acc1 += p;
+        else acc0 += p;
+        pb[b][i >> 2][(2 * i) & 7] = static_cast<__bf16>(p[0]);
+        pb[b][i >> 2][(2 * i + 1) & 7] = static_cast<__bf16>(p[1]);
       }
-    l_run = l_run * alpha + ps;
+    acc0 += acc1;
+    l_run = l_run * alpha + (acc0[0] + acc0[1]);
     asm volatile("" : "+v"(alpha));
     if (__any(alpha != 1.0f)) {
       asm volatile("s_nop 7" ::: "memory");          // hazards around inline-asm operands are padded by hand (rare path)
@@ -318,24 +360,42 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
     __builtin_amdgcn_s_barrier();
   }
   for (int t = 0; t < NT; ++t) {
+    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
     if (grp == 0) {                                  // own pieces of tile t landed (tile t+1 may stay in flight)
       pp_wait_tiles(min(NT - 1 - t, PD - 1));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
     stepM(t);
+    if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
     if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (grp == 1 && t + 1 < NT) {                    // own pieces of tile t+1 landed before G0 starts M(t+1)
       pp_wait_tiles(max(min(NT - 2 - t, PD - 2), 0));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (PP_TRACE) tr[4] = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);   // VALU step wins issue arbitration; MFMAs fill the gaps
+    if (PP_TRACE) tr[5] = __builtin_readcyclecounter();
     if (!(PP_ABLATE & 2)) stepV(t);
+    if (PP_TRACE && t < 64 && lane == 0) {           // stamps go to LDS (no VMEM traffic inside the loop)
+      long long* tp = reinterpret_cast<long long*>(smem + LDS_BYTES) + (t * 8 + wave) * 8;
+      tr[6] = __builtin_readcyclecounter();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) tp[i] = tr[i];
+    }
     if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the phase shift
+  if (PP_TRACE && wi == 0 && A.lse != nullptr) {
+    __syncthreads();
+    const long long* tp = reinterpret_cast<const long long*>(smem + LDS_BYTES);
+    for (int i = tid; i < 64 * 8 * 8; i += 512) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
+  }
   // ---- drain: PV of the last tile
   {
     const unsigned char* vb = smem + V_OFF + ((NT - 1) % RV) * 16384;
@@ -382,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
         for (int e = 0; e < 4; ++e) w[e] = f2bf(o[d][4 * g + e] * inv);
         *reinterpret_cast<u16x4*>(op + 32 * d + 8 * g) = w;
       }
-    if (A.lse != nullptr && hi == 0) A.lse[(size_t)head * A.q_rows + qrow] = m_run * A.scale + __logf(l_tot);
+    if (A.lse != nullptr && hi == 0 && !PP_TRACE) A.lse[(size_t)head * A.q_rows + qrow] = m_run * A.scale + __logf(l_tot);
   }
 }
 
@@ -465,10 +525,10 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   const dim3 grid(a.per_xcd * 8), block(512);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
     attr_set = true;
   }
   if (a.splits > 1) {
@@ -476,15 +536,15 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
       set_error("ifx_attn_fwd_paged_split: splits > 1 needs a workspace");
       return IFX_EINVAL;
     }
-    if (kv->page_table) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), grid, block, LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true>), grid, block, LDS_BYTES, stream, a);
+    if (kv->page_table) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true>), grid, block, LDS_ALLOC, stream, a);
     const int pairs = q_rows * heads;
     hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, a.part_o, a.part_lse, out,
                        lse, q_rows, heads, a.splits);
   } else if (kv->page_table) {
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false>), grid, block, LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false>), grid, block, LDS_ALLOC, stream, a);
   } else {
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false>), grid, block, LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false>), grid, block, LDS_ALLOC, stream, a);
   }
   return check_launch("ifx_attn_fwd_paged(pp)");
 }

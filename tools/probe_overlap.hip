@@ -1,0 +1,130 @@
+// Does a SIMD co-issue MFMA from one wave with VALU / transcendental ops from another?  (gfx950)
+// 8-wave workgroups (waves w and w+4 share a SIMD); waves 0-3 run role A, waves 4-7 role B.
+// roles: 0 idle, 1 MFMA 32x32x16 bf16 (4 independent accumulators), 2 v_fma_f32 (16 independent chains),
+//        3 v_exp_f32 (16 independent chains), 4 v_pk_fma_f32 (8 independent chains of 2), 5 MFMA with ONE accumulator
+// build: hipcc --offload-arch=gfx950 -O3 tools/probe_overlap.hip -o tools/bin/probe_overlap
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+template <int ROLE>
+__device__ __forceinline__ float run_role(int iters, float seed) {
+  if (ROLE == 1 || ROLE == 5) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {
+      if (ROLE == 1) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+      } else {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+      }
+    }
+    return c0[0] + c1[1] + c2[2] + c3[3];
+  } else if (ROLE == 2) {
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = seed + i;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(seed));
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += x[i];
+    return s;
+  } else if (ROLE == 3) {
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = seed * 0.001f + i * 0.01f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += x[i];
+    return s;
+  } else if (ROLE == 4) {
+    f32x2 x[8], k = {seed, seed};
+    for (int i = 0; i < 8; ++i) x[i] = f32x2{seed + i, seed - i};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(k));
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += x[i][0] + x[i][1];
+    return s;
+  }
+  return 0.f;
+}
+
+template <int RA, int RB>
+__global__ __launch_bounds__(512) void probe(float* out, int iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  const long long t0 = __builtin_readcyclecounter();
+  float r = wave < 4 ? run_role<RA>(iters, seed) : run_role<RB>(iters, seed);
+  const long long t1 = __builtin_readcyclecounter();
+  if (r == 12345.678f) out[threadIdx.x] = r;
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[1024 + wave] = (float)(t1 - t0);   // s_memtime ticks (100 MHz)
+}
+
+static float g_ta, g_tb;
+// three waves per SIMD: waves 0-3 role RA, 4-7 role RB, 8-11 role RC
+template <int RA, int RB, int RC>
+__global__ __launch_bounds__(768) void probe3(float* out, int iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  const long long t0 = __builtin_readcyclecounter();
+  float r = wave < 4 ? run_role<RA>(iters, seed) : (wave < 8 ? run_role<RB>(iters, seed) : run_role<RC>(iters, seed));
+  const long long t1 = __builtin_readcyclecounter();
+  if (r == 12345.678f) out[threadIdx.x] = r;
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[1024 + wave] = (float)(t1 - t0);
+}
+template <int RA, int RB, int RC>
+static void time3(float* d, int iters, const char** names) {
+  probe3<RA, RB, RC><<<256, 768>>>(d, iters, 1.0f);
+  hipDeviceSynchronize();
+  probe3<RA, RB, RC><<<256, 768>>>(d, iters, 1.0f);
+  hipDeviceSynchronize();
+  float h[12];
+  hipMemcpy(h, d + 1024, sizeof(h), hipMemcpyDeviceToHost);
+  printf("A=%-12s B=%-12s C=%-12s : cycles/iter A %6.1f  B %6.1f  C %6.1f\n", names[RA], names[RB], names[RC],
+         h[0] / iters, h[4] / iters, h[8] / iters);
+}
+
+template <int RA, int RB>
+static float time_it(float* d, int iters) {
+  hipEvent_t s, e;
+  hipEventCreate(&s); hipEventCreate(&e);
+  probe<RA, RB><<<256, 512>>>(d, iters, 1.0f);
+  hipDeviceSynchronize();
+  hipEventRecord(s);
+  probe<RA, RB><<<256, 512>>>(d, iters, 1.0f);
+  hipEventRecord(e);
+  hipEventSynchronize(e);
+  float ms; hipEventElapsedTime(&ms, s, e);
+  float h[8];
+  hipMemcpy(h, d + 1024, sizeof(h), hipMemcpyDeviceToHost);
+  g_ta = h[0]; g_tb = h[4];
+  return ms * 1e3f;
+}
+
+int main() {
+  float* d; hipMalloc(&d, 8192);
+  const int it = 20000;
+  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)"};
+#define T(A, B) { float us = time_it<A, B>(d, it); printf("A=%-12s B=%-12s : %8.1f us   role A %8.1f us  role B %8.1f us\n", names[A], names[B], us, g_ta * 0.01f, g_tb * 0.01f); }
+  T(1, 0) T(5, 0) T(0, 2) T(0, 3) T(0, 4) T(1, 1) T(2, 2) T(3, 3) T(1, 2) T(1, 3) T(1, 4) T(5, 2) T(5, 3) T(2, 3)
+  time3<1, 2, 0>(d, it, names);
+  time3<1, 2, 2>(d, it, names);
+  time3<1, 3, 3>(d, it, names);
+  time3<1, 2, 3>(d, it, names);
+  time3<1, 4, 4>(d, it, names);
+  time3<1, 1, 2>(d, it, names);
+  time3<0, 2, 2>(d, it, names);
+  time3<2, 2, 2>(d, it, names);
+  // per iteration: mfma role = 4 MFMA (4*32 = 128 pipe cycles); v_fma role = 16 VALU (64 issue cycles); v_exp = 16 trans
+  printf("iters %d; at 2.4 GHz 128 cycles * %d = %.1f us\n", it, it, 128.0 * it / 2400.0);
+  return 0;
+}
