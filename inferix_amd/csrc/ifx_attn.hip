@@ -353,9 +353,12 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
 }
 
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
-                   int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, hipStream_t stream);
+                   int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
+                   hipStream_t stream);
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
-int attn_pp_split_heuristic(int q_rows, int heads, int nkeys);
+int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt);
+// wave groups of the multi-wave kernel for a launch: 3 (384-row tiles) when variant 3 is forced or chosen, else 2
+static int attn_groups(int variant) { return variant == 3 ? 3 : 2; }
 
 }  // namespace ifx
 
@@ -377,10 +380,12 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
     IFX_REQUIRE(workspace && workspace_bytes >= (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits),
                 "ifx_attn_fwd_paged_split: workspace of %lld B too small for %d splits (need %lld B)",
                 (long long)workspace_bytes, splits, (long long)attn_pp_workspace_bytes(q_rows, heads, splits));
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, (hipStream_t)stream);
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant),
+                          (hipStream_t)stream);
   }
-  if (variant == 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, (hipStream_t)stream);
+  if (variant >= 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant),
+                          (hipStream_t)stream);
   AttnArgs a;
   a.q = q;
   a.out = out;
@@ -421,7 +426,8 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
 extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len,
                                        int64_t* workspace_bytes) {
   int splits = 1;
-  if (q_rows > 0 && heads > 0 && kv_len > kv_start) splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start);
+  if (q_rows > 0 && heads > 0 && kv_len > kv_start)
+    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, 128 * attn_groups(attn_variant()));
   if (workspace_bytes) *workspace_bytes = (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits);
   return splits;
 }

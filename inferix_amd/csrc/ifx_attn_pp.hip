@@ -35,8 +35,11 @@
 #ifndef PP_TRACE
 #define PP_TRACE 0
 #endif
+#ifndef PP_PACKED
+#define PP_PACKED 1    // 1: v_pk_fma_f32 for the exponent arguments (measured +5 % over plain v_fma_f32), 0: plain
+#endif
 #ifndef PP_PRIO
-#define PP_PRIO 1      // 1: s_setprio(1) around the MFMA step (+4 % measured), 2: around the softmax step (+1 %)
+#define PP_PRIO 2      // 1: raised priority around the MFMA step, 2: around the softmax step (measured best)
 #endif
 #ifndef PP_GROUP
 #define PP_GROUP 0     // 0: groups = waves 0-3 / 4-7 (waves w, w+4 share a SIMD); 1: even / odd waves
@@ -45,7 +48,6 @@
 namespace ifx {
 
 namespace pp {
-constexpr int QT = 256;   // query rows per workgroup (8 waves x 32)
 constexpr int KT = 64;
 constexpr int HD = 128;
 #ifndef PP_PD
@@ -55,7 +57,7 @@ constexpr int PD = PP_PD;
 constexpr int RK = PD + 1, RV = PD + 2;
 constexpr int K_OFF = 0, V_OFF = RK * 16384;
 constexpr int LDS_BYTES = (RK + RV) * 16384;   // 114688
-constexpr int LDS_ALLOC = LDS_BYTES + (PP_TRACE ? 32768 : 0);
+constexpr int LDS_ALLOC = LDS_BYTES + (PP_TRACE ? 49152 : 0);
 }  // namespace pp
 
 struct AttnArgsPP {
@@ -120,13 +122,20 @@ __device__ __forceinline__ void pp_wait_tiles(int tiles) {
   else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-template <bool PAGED, bool SPLIT>
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
+// NG = number of wave groups (4 waves each, one per SIMD): 2 = ping-pong (M | V), 3 = three-phase (M | V1 | V2).
+// Why three: while one wave streams MFMAs, a SINGLE other wave on that SIMD gets a VALU instruction issued only every
+// ~15 cycles, TWO other waves get one every ~8 (tools/probe_overlap.hip).  The softmax of a tile is ~110 VALU
+// instructions against 32 MFMAs (1024 cycles): with one softmax wave per SIMD the step takes ~2000 cycles and the
+// matrix pipe idles half the time (step trace, tools/trace_attn.sh); with two it fits in two MFMA steps.
+template <bool PAGED, bool SPLIT, int NG>
+__global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   using namespace pp;
+  constexpr int QT = 128 * NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = PP_GROUP ? (wave & 1) : (wave >> 2);
+  const int grp = (NG == 2 && PP_GROUP) ? (wave & 1) : (wave >> 2);
+  const bool loader = wave < 8;          // 32 DMA pieces per tile = 8 waves x 4 (a third group only computes)
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
@@ -165,17 +174,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   //      1 KiB (4 key rows x 256 B); wave w moves pieces w and w+8.  Per lane only a 32-bit voffset per piece is
   //      live (row * row_bytes + swizzled source chunk); the tile offset is a scalar soffset.  Rows beyond the
   //      descriptor's range (keys >= kv_len in the ragged last tile) read as ZERO by the hardware bounds check.
-  const int d_row = lane >> 4, d_pc = lane & 15;
   const int row_bytes = A.kv_heads * HD * 2;     // cache row pitch
   const int kvh = head / A.q_per_kv;
-  int k_voff[2], v_voff[2], d_rowi[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = (r * 8 + wave) * 4 + d_row;
-    d_rowi[r] = row;
-    k_voff[r] = row * row_bytes + ((d_pc ^ (row & 15)) << 4);
-    v_voff[r] = row * row_bytes + (((((d_pc >> 2) ^ (row & 3)) << 2) | (d_pc & 3)) << 4);
-  }
+  // piece r = 1 is 32 key rows below piece 0 (same swizzle phase): one voffset per matrix, +32 rows on the scalar side
   const int nkeys = kv_e - kv_s;
   const int NT = (nkeys + KT - 1) / KT;
   // identity page map: descriptor covers logical tokens [0, kv_len); paged: whole cache, keys clamped by hand
@@ -186,22 +187,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   const unsigned lds0 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem + wave * 1024;
   const int last_key = kv_e - 1;
   auto issue = [&](int t) {
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));                    // recomputed, not kept live (see stepM)
+    const int d_pc = ln & 15, d_row0 = wave * 4 + (ln >> 4);
+    const int k_voff = d_row0 * row_bytes + ((d_pc ^ (d_row0 & 15)) << 4);
+    const int v_voff = d_row0 * row_bytes + (((((d_pc >> 2) ^ (d_row0 & 3)) << 2) | (d_pc & 3)) << 4);
     const unsigned kb = lds0 + K_OFF + (t % RK) * 16384;
     const unsigned vb = lds0 + V_OFF + (t % RV) * 16384;
     if (!PAGED) {
       const int soff = (kv_s + t * KT) * row_bytes;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        pp_dma16(krs, kb + r * 8192, k_voff[r], soff);
-        pp_dma16(vrs, vb + r * 8192, v_voff[r], soff);
+        pp_dma16(krs, kb + r * 8192, k_voff, soff + r * 32 * row_bytes);
+        pp_dma16(vrs, vb + r * 8192, v_voff, soff + r * 32 * row_bytes);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int key = min(kv_s + t * KT + d_rowi[r], last_key);
-        const int delta = (A.ka.slot(key) - d_rowi[r]) * row_bytes;      // physical row instead of tile row
-        pp_dma16(krs, kb + r * 8192, k_voff[r] + delta, 0);
-        pp_dma16(vrs, vb + r * 8192, v_voff[r] + delta, 0);
+        const int key = min(kv_s + t * KT + d_row0 + 32 * r, last_key);
+        const int delta = (A.ka.slot(key) - d_row0) * row_bytes;         // physical row instead of tile row
+        pp_dma16(krs, kb + r * 8192, k_voff + delta, 0);
+        pp_dma16(vrs, vb + r * 8192, v_voff + delta, 0);
       }
     }
   };
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
 
   f32x16 s[2];
   bf16x8 pb[2][2];
-  bf16x8 fA[4], fB[4];
+  bf16x8 fA[4], fB[4];     // drain only
+  bf16x8 fr[3][2];         // operand-fragment ring of step M
   pb[0][0] = pb[0][1] = pb[1][0] = pb[1][1] = bf16x8{};      // P(-1) = 0 for the unconditional PV of tile 0
   if (PP_ABLATE) {
 #pragma unroll
@@ -260,86 +267,115 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
   };
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 
-  // ---- step M(t): PV(t-1) then QK(t); fragment batches double buffered through fA / fB
+  // ---- step M(t): PV(t-1) then QK(t) = 16 batches of two MFMAs.  Operand fragments rotate through a three-slot
+  //      ring of two fragments (24 VGPRs): the LDS reads of batch j+2 are issued before the MFMAs of batch j, so a
+  //      read has two batches (~128 matrix-pipe cycles) to land.  (Four-fragment double buffering cost 8 VGPRs more,
+  //      which is what did not fit next to O (64) + Q (32) + S (32) at three waves per SIMD.)
+  //        PV batch j = (block b = j>>2, k-slot s2 = (j>>1)&1, d pair dh = j&1)     j = 0..7
+  //        QK batch j = (block b = j>>2, k-steps 2*(j&3), 2*(j&3)+1)                 j = 0..7
   auto stepM = [&](int t) {
     const unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
-    {
-      // PV(t-1).  At t == 0 there is no previous tile: P is all zero (initialised below) and the V fragments are
-      // read from tile 0, whose DMA has landed — O += V^T * 0.  Unconditional on purpose: a branch here made the
-      // O accumulators a phi and cost 32 v_mov_b64 per tile.
-      const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
-      ldV(fA, vb, 0, 0);
-      ldV(fB, vb, 0, 1);
-      PP_SB();
-      mmaV(fA, pb[0][0]);
-      ldV(fA, vb, 1, 0);
-      PP_SB();
-      mmaV(fB, pb[0][1]);
-      ldV(fB, vb, 1, 1);
-      PP_SB();
-      mmaV(fA, pb[1][0]);
-      ldK(fA, kb, 0, 0);
-      PP_SB();
-      mmaV(fB, pb[1][1]);
-      ldK(fB, kb, 0, 1);
-      PP_SB();
-    }
+    // PV(t-1).  At t == 0 there is no previous tile: P is all zero and the V fragments are read from tile 0, whose
+    // DMA has landed — O += V^T * 0.  Unconditional on purpose: a branch here made the O accumulators a phi and
+    // cost 32 v_mov_b64 per tile.
+    const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
+    // lane-derived address terms are RECOMPUTED here from an opaque lane id (a handful of VALU ops): kept live across
+    // the loop they were spilled at three waves per SIMD, and a scratch reload drains the DMA queue (shared vmcnt)
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
+    const int hi = ln >> 5, l31 = ln & 31, kswz = ln & 15, v_rowq = (ln >> 2) & 3;
+    const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
+    auto load = [&](int j) {
+      if (PP_ABLATE & 4) return;
+      bf16x8(&f)[2] = fr[j % 3];
+      if (j < 8) {
+        const int bb = j >> 2, s2 = (j >> 1) & 1, dh = j & 1;
+        const unsigned char* vr0 = vb + (32 * bb + 16 * s2 + 4 * hi + v_rowq) * 256 + v_in;
+        const unsigned char* vr1 = vr0 + 8 * 256;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[0][r] = 0.f;
-      s[1][r] = 0.f;
+        for (int e = 0; e < 2; ++e) {
+          const int ch = ((2 * dh + e) ^ v_rowq) << 6;
+          const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr0 + ch));
+          const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr1 + ch));
+          f[e] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      } else {
+        const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
+        const unsigned char* krow = kb + (32 * bb + l31) * 256;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          f[e] = *reinterpret_cast<const bf16x8*>(krow + (((2 * (ks0 + e) + hi) ^ kswz) << 4));
+      }
+    };
+    auto mma = [&](int j) {
+      if (PP_ABLATE & 8) return;
+      bf16x8(&f)[2] = fr[j % 3];
+      if (j < 8) {
+        const int bb = j >> 2, s2 = (j >> 1) & 1, dh = j & 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          o[2 * dh + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], pb[bb][s2], o[2 * dh + e], 0, 0, 0);
+      } else {
+        const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
+        if ((q & 3) == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[bb][r] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) s[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], s[bb], 0, 0, 0);
+      }
+    };
+    load(0);
+    load(1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      PP_SB();
+      if (j + 2 < 16) load(j + 2);
+      mma(j);
     }
-    mmaK(s[0], fA, 0);
-    ldK(fA, kb, 1, 0);
-    PP_SB();
-    mmaK(s[0], fB, 1);
-    ldK(fB, kb, 1, 1);
-    PP_SB();
-    mmaK(s[1], fA, 0);
-    mmaK(s[1], fB, 1);
   };
 
-  // ---- step V(t): online softmax of the 64-key tile; P -> pb (bf16), in-place rescale of O when a max grew
-  auto stepV = [&](int t) {
-    // DMA of tile t+PD is issued HERE: an LDS-DMA instruction costs its issuing wave ~100+ cycles, which the
-    // VALU step can afford (it is shorter than the partner's MFMA step) and the MFMA step cannot
-    if (t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
-    if (t == NT - 1 && (nkeys & (KT - 1))) {     // ragged last tile (wave-uniform, executed once)
-      const int kidx = t * KT + 4 * hi;
+  // ---- step V(t): online softmax of the 64-key tile; P -> pb (bf16), in-place rescale of O when a max grew.
+  //      Two halves (one per 32-key block of exponentials) so that the three-group schedule can put a phase
+  //      boundary between them; with two groups they run back to back.
+  pp_f32x2 v_mcv = {0.f, 0.f}, v_acc = {0.f, 0.f};
+  const pp_f32x2 c2v = {c2, c2};
+  auto exp_block = [&](int b) {
+    // exponent arguments two at a time (v_pk_fma_f32); row sums in two plain chains
+    float a0 = 0.f, a1 = 0.f;
+    const float mc = v_mcv[0];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kidx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) s[b][r] = -INFINITY;
+    for (int i = 0; i < 8; ++i) {
+#if PP_PACKED
+      const pp_f32x2 sv = {s[b][2 * i], s[b][2 * i + 1]};
+      const pp_f32x2 e = sv * c2v - v_mcv;
+      const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+#else
+      const float p0 = __builtin_amdgcn_exp2f(s[b][2 * i] * c2 - mc);
+      const float p1 = __builtin_amdgcn_exp2f(s[b][2 * i + 1] * c2 - mc);
+#endif
+      a0 += p0;
+      a1 += p1;
+      pb[b][i >> 2][(2 * i) & 7] = static_cast<__bf16>(p0);
+      pb[b][i >> 2][(2 * i + 1) & 7] = static_cast<__bf16>(p1);
     }
+    v_acc += pp_f32x2{a0, a1};
+  };
+  // Lazy reference maximum.  softmax is invariant to the exponent reference: p = exp2(c2*(s - M)) with ANY finite M
+  // gives the same O / l as long as nothing overflows.  The true row maximum is computed for the first tile only;
+  // later tiles reuse M (no 16-deep v_max3 chain, no cross-half exchange, no rescale factor — a third of the step's
+  // VALU time, tools/trace_attn.sh) and only check the tile's row sums: if some row would exceed 2^20 (or overflowed
+  // to inf), the tile is redone against its true maximum and O / l are rescaled.  m_run holds M; LSE = M*scale + ln l.
+  constexpr float kLazyLimit = 1048576.f;
+  auto tile_max = [&]() -> float {
     // first read of the S accumulators through a compiler-visible instruction (MFMA -> VALU wait states are not
     // inserted for inline-asm operands; a wave that arrives last at the barrier starts this step at once)
     float mx = pp_max3(__builtin_fmaxf(s[0][0], s[1][0]), m_run, m_run);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = pp_max3(mx, s[0][r], s[1][r]);
-    const float m_new = pp_half_max(mx);
-    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-    m_run = m_new;
-    const float mc = m_new * c2;
-    // Packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction).  While its partner wave owns the
-    // matrix pipe this wave is the ONLY one issuing VALU work on the SIMD, and a single wave issues a VALU
-    // instruction only every ~10 cycles (tools/probe_overlap.hip) — the step is bound by instruction COUNT.
-    const pp_f32x2 c2v = {c2, c2}, mcv = {mc, mc};
-    pp_f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const pp_f32x2 sv = {s[b][2 * i], s[b][2 * i + 1]};
-        const pp_f32x2 e = sv * c2v - mcv;
-        const pp_f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-        if (i & 1) acc1 += p;
-        else acc0 += p;
-        pb[b][i >> 2][(2 * i) & 7] = static_cast<__bf16>(p[0]);
-        pb[b][i >> 2][(2 * i + 1) & 7] = static_cast<__bf16>(p[1]);
-      }
-    acc0 += acc1;
-    l_run = l_run * alpha + (acc0[0] + acc0[1]);
+    return pp_half_max(mx);
+  };
+  auto rescale_o = [&](float alpha) {
     asm volatile("" : "+v"(alpha));
     if (__any(alpha != 1.0f)) {
       asm volatile("s_nop 7" ::: "memory");          // hazards around inline-asm operands are padded by hand (rare path)
@@ -350,51 +386,145 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgsPP A) {
       asm volatile("s_nop 3" ::: "memory");
     }
   };
+  auto stepV1 = [&](int t) {
+    // DMA of tile t+PD is issued HERE: an LDS-DMA instruction costs its issuing wave ~100+ cycles, which a
+    // VALU step can afford and the MFMA step cannot
+    if (loader && t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+    if (t == NT - 1 && (nkeys & (KT - 1))) {     // ragged last tile (wave-uniform, executed once)
+      const int kidx = t * KT + 4 * hi;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kidx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) s[b][r] = -INFINITY;
+    }
+    if (t == 0) m_run = tile_max();               // O and l are still zero: nothing to rescale
+    const float mc = m_run * c2;
+    v_mcv = pp_f32x2{mc, mc};
+    v_acc = pp_f32x2{0.f, 0.f};
+    exp_block(0);
+  };
+  auto stepV2 = [&](int t) {
+    exp_block(1);
+    float tile_sum = v_acc[0] + v_acc[1];
+    if (__any(!(tile_sum < kLazyLimit))) {         // rare: this tile outgrew the reference (inf / NaN land here too)
+      const float m_new = tile_max();              // >= m_run, identical in lane and lane^32
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      m_run = m_new;
+      const float mc = m_new * c2;
+      v_mcv = pp_f32x2{mc, mc};
+      v_acc = pp_f32x2{0.f, 0.f};
+      exp_block(0);
+      exp_block(1);
+      tile_sum = v_acc[0] + v_acc[1];
+      l_run *= alpha;
+      rescale_o(alpha);
+    }
+    l_run += tile_sum;
+  };
+  auto phase_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
 
-  // ---- prologue: tiles 0 and 1 in flight
+  // ---- prologue: tiles 0 .. PD-1 in flight
 #pragma unroll
   for (int i = 0; i < PD; ++i)
-    if (i < NT) issue(i);
-  if (grp == 1) {                                   // phase shift: G1 runs one barrier behind G0
-    pp_wait_tiles(min(NT, PD) - 1);
-    __builtin_amdgcn_s_barrier();
-  }
-  for (int t = 0; t < NT; ++t) {
-    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
-    if (grp == 0) {                                  // own pieces of tile t landed (tile t+1 may stay in flight)
-      pp_wait_tiles(min(NT - 1 - t, PD - 1));
+    if (loader && i < NT) issue(i);
+
+  if (NG == 2) {
+    // barrier index :   2t            2t+1          2t+2
+    // G0            :   M(t)          V(t)          M(t+1)
+    // G1            :   V(t-1)        M(t)          V(t)
+    if (grp == 1) {                                   // phase shift: G1 runs one barrier behind G0
+      pp_wait_tiles(min(NT, PD) - 1);
+      __builtin_amdgcn_s_barrier();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
-    __builtin_amdgcn_s_barrier();
-    if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-    if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
-    stepM(t);
-    if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
-    if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    if (grp == 1 && t + 1 < NT) {                    // own pieces of tile t+1 landed before G0 starts M(t+1)
-      pp_wait_tiles(max(min(NT - 2 - t, PD - 2), 0));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (PP_TRACE) tr[4] = __builtin_readcyclecounter();
-    __builtin_amdgcn_s_barrier();
-    if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);   // VALU step wins issue arbitration; MFMAs fill the gaps
-    if (PP_TRACE) tr[5] = __builtin_readcyclecounter();
-    if (!(PP_ABLATE & 2)) stepV(t);
-    if (PP_TRACE && t < 64 && lane == 0) {           // stamps go to LDS (no VMEM traffic inside the loop)
-      long long* tp = reinterpret_cast<long long*>(smem + LDS_BYTES) + (t * 8 + wave) * 8;
-      tr[6] = __builtin_readcyclecounter();
+    for (int t = 0; t < NT; ++t) {
+      long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
+      if (grp == 0) pp_wait_tiles(min(NT - 1 - t, PD - 1));   // own pieces of tile t landed (t+1 may stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_barrier();
+      if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+      if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
+      stepM(t);
+      if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
+      if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      if (grp == 1 && t + 1 < NT) pp_wait_tiles(max(min(NT - 2 - t, PD - 2), 0));   // tile t+1 before G0's M(t+1)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (PP_TRACE) tr[4] = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_barrier();
+      if (PP_TRACE) tr[5] = __builtin_readcyclecounter();
+      if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
+      if (!(PP_ABLATE & 2)) {
+        stepV1(t);
+        stepV2(t);
+      }
+      if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      if (PP_TRACE && t < 64 && lane == 0) {           // stamps go to LDS (no VMEM traffic inside the loop)
+        long long* tp = reinterpret_cast<long long*>(smem + LDS_BYTES) + (t * 8 + wave) * 8;
+        tr[6] = __builtin_readcyclecounter();
 #pragma unroll
-      for (int i = 0; i < 7; ++i) tp[i] = tr[i];
+        for (int i = 0; i < 7; ++i) tp[i] = tr[i];
+      }
     }
-    if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the phase shift
+  } else {
+    // Three groups, one phase apart; phase p is opened by barrier B_p, group g runs its local phase p - g:
+    //   B index :  3t       3t+1     3t+2     3t+3     3t+4
+    //   G0      :  M(t)     V1(t)    V2(t)    M(t+1)   V1(t+1)
+    //   G1      :  V2(t-1)  M(t)     V1(t)    V2(t)    M(t+1)
+    //   G2      :  V1(t-1)  V2(t-1)  M(t)     V1(t)    V2(t)
+    // -> every phase has exactly one group on the matrix pipe and two groups sharing the VALU.
+    // Tile t (K for QK(t), V for PV(t) one tile later) must be complete at B_3t, the barrier before G0's M(t): the
+    // loader waves of G0 retire their pieces just before it at the top of their iteration t, those of G1 before
+    // the same barrier between their V1(t-1) and V2(t-1).  Ring slot of K(t+PD) = slot of K(t-1), last read by G2's
+    // M(t-1) in phase 3t-1; it is refilled by G0 in phase 3t+1 and by G1 in phase 3t+2.  (V: slot of V(t-2), same.)
+    if (grp >= 1) {
+      if (loader) pp_wait_tiles(min(NT, PD) - 1);      // B_0 publishes tile 0
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 2) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < NT; ++t) {
+      long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
+      if (grp == 0) pp_wait_tiles(min(NT - 1 - t, PD - 1));
+      phase_barrier();
+      if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+      if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
+      stepM(t);
+      if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
+      if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      phase_barrier();
+      if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
+      if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
+      if (!(PP_ABLATE & 2)) stepV1(t);
+      if (grp == 1 && t + 1 < NT) pp_wait_tiles(min(NT - 2 - t, PD - 1));   // own pieces of tile t+1 (B_3(t+1) is next)
+      if (PP_TRACE) {
+        asm volatile("" ::"v"(v_acc));
+        tr[4] = __builtin_readcyclecounter();
+      }
+      phase_barrier();
+      if (PP_TRACE) tr[5] = __builtin_readcyclecounter();
+      if (!(PP_ABLATE & 2)) stepV2(t);
+      if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      if (PP_TRACE && t < 64 && lane == 0) {
+        asm volatile("" ::"v"(l_run), "v"(pb[1][1]));
+        long long* tp = reinterpret_cast<long long*>(smem + LDS_BYTES) + (t * 12 + wave) * 8;
+        tr[6] = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tp[i] = tr[i];
+      }
+    }
+    if (grp <= 1) __builtin_amdgcn_s_barrier();        // balance the phase shifts
+    if (grp == 0) __builtin_amdgcn_s_barrier();
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();        // balance the phase shift
   if (PP_TRACE && wi == 0 && A.lse != nullptr) {
     __syncthreads();
     const long long* tp = reinterpret_cast<const long long*>(smem + LDS_BYTES);
-    for (int i = tid; i < 64 * 8 * 8; i += 512) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
+    for (int i = tid; i < 64 * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
   }
   // ---- drain: PV of the last tile
   {
@@ -478,14 +608,14 @@ size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits) {
   return splits <= 1 ? 0 : (size_t)splits * q_rows * heads * (128 + 1) * sizeof(float);
 }
 
-// number of key chunks that fills the chip: one 8-wave workgroup per CU, 256 CUs
-int attn_pp_split_heuristic(int q_rows, int heads, int nkeys) {
+// number of key chunks that fills the chip (one workgroup per CU, 256 CUs) for a query tile of `qt` rows
+int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt) {
   using namespace pp;
-  const int tiles = ((q_rows + QT - 1) / QT) * heads;
+  const int tiles = ((q_rows + qt - 1) / qt) * heads;
   const int nt = (nkeys + KT - 1) / KT;
-  if (tiles >= 176 || nt < 16) return 1;               // >= ~70 % of the CUs already busy / nothing to split
+  if (tiles >= 208 || nt < 16) return 1;               // >= ~80 % of the CUs already busy / nothing to split
   int best = 1;
-  float best_eff = (float)tiles / 256.f;
+  float best_eff = (float)tiles / (256.f * ((tiles + 255) / 256));
   for (int s = 2; s <= 32 && s * 8 <= nt; ++s) {        // chunks of >= 8 tiles (512 keys)
     const int wg = tiles * s, rounds = (wg + 255) / 256;
     const float eff = (float)wg / (256.f * rounds) * (1.f - 0.01f * s);   // small per-chunk prologue/merge penalty
@@ -494,9 +624,33 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys) {
   return best;
 }
 
-int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
-                   int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, hipStream_t stream) {
+template <int NG>
+static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   using namespace pp;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    attr_set = true;
+  }
+  const dim3 block(NG * 256);
+  if (split) {
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, NG>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, NG>), grid, block, LDS_ALLOC, stream, a);
+  } else {
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, NG>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, NG>), grid, block, LDS_ALLOC, stream, a);
+  }
+}
+
+// groups: 2 = ping-pong (256 query rows per workgroup), 3 = three-phase (384 rows)
+int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
+                   int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
+                   hipStream_t stream) {
+  using namespace pp;
+  const int QT = 128 * groups;
   AttnArgsPP a;
   a.q = q;
   a.out = out;
@@ -522,29 +676,17 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.per_xcd = (a.total + 7) / 8;
   a.scale = scale > 0.f ? scale : 0.08838834764831845f;
   a.scale_log2 = a.scale * 1.4426950408889634f;
-  const dim3 grid(a.per_xcd * 8), block(512);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    attr_set = true;
+  const dim3 grid(a.per_xcd * 8);
+  if (a.splits > 1 && workspace == nullptr) {
+    set_error("ifx_attn_fwd_paged_split: splits > 1 needs a workspace");
+    return IFX_EINVAL;
   }
+  if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, a.splits > 1, grid, stream);
+  else launch_pp_ng<2>(a, kv->page_table != nullptr, a.splits > 1, grid, stream);
   if (a.splits > 1) {
-    if (workspace == nullptr) {
-      set_error("ifx_attn_fwd_paged_split: splits > 1 needs a workspace");
-      return IFX_EINVAL;
-    }
-    if (kv->page_table) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true>), grid, block, LDS_ALLOC, stream, a);
     const int pairs = q_rows * heads;
     hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, a.part_o, a.part_lse, out,
                        lse, q_rows, heads, a.splits);
-  } else if (kv->page_table) {
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false>), grid, block, LDS_ALLOC, stream, a);
-  } else {
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false>), grid, block, LDS_ALLOC, stream, a);
   }
   return check_launch("ifx_attn_fwd_paged(pp)");
 }

@@ -330,12 +330,15 @@ def test_gemm_every_tile_variant(ops, variant, M, N, K):
         ops.set_option("gemm_variant", 0)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_attention_both_kernels(ops, variant):
     ops.set_option("attn_variant", variant)
     try:
         _attn_case(ops, 300, 12, 2048, cap=2100)
         _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
+        _attn_case(ops, 1000, 2, 700, cap=777)                 # several query tiles, ragged last key tile
+        _attn_case(ops, 390, 3, 64, cap=64)                    # a single key tile
+        _attn_case(ops, 500, 2, 1111, cap=1200, splits=3)
     finally:
         ops.set_option("attn_variant", 0)
 
@@ -360,7 +363,7 @@ def test_kernels_are_run_to_run_deterministic(ops):
                 return False
         return True
     try:
-        for av in (1, 2):
+        for av in (1, 2, 3):
             ops.set_option("attn_variant", av)
             assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
         ops.set_option("attn_variant", 0)

@@ -55,6 +55,8 @@ if what in ("gemm", "all"):
         print(f"gemm v{variant} sum of 4 = {tot*1e3:.1f} us")
     ops.set_option("gemm_variant", 0)
 if what in ("attn", "all"):
+    av = int(os.environ.get("ATTN_VARIANT", "0"))
+    ops.set_option("attn_variant", av)
     q = rnd(M, H, D)
     for blk in (1, 4, 7):
         L = blk * 4680
@@ -80,6 +82,7 @@ if what in ("norm", "all"):
     med, _ = timeit(lambda: ops.rmsnorm_rope_kv_append(qkv, w1, w1, 1e-6, rope, ops.KvCacheView(kc, vc), 0, d))
     print(f"rmsnorm+rope+append: {med*1e3:7.1f} us  {12.0*M*d/med/1e6:7.1f} GB/s")
 if what == "split":
+    ops.set_option("attn_variant", int(os.environ.get("ATTN_VARIANT", "0")))
     q = rnd(M, H, D)
     for blk in (1, 4, 7):
         L = blk * 4680

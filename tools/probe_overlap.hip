@@ -29,6 +29,33 @@ __device__ __forceinline__ float run_role(int iters, float seed) {
       }
     }
     return c0[0] + c1[1] + c2[2] + c3[3];
+  } else if (ROLE == 6) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
+    for (int it = 0; it < iters; ++it) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c4, 0, 0, 0);
+      c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c5, 0, 0, 0);
+      c6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c6, 0, 0, 0);
+      c7 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c7, 0, 0, 0);
+    }
+    return c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
+  } else if (ROLE == 7) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    s16x4 a = {1, 2, 3, 4}, b = {4, 3, 2, 1};
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c3, 0, 0, 0);
+    }
+    return c0[0] + c1[1] + c2[2] + c3[3];
   } else if (ROLE == 2) {
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = seed + i;
@@ -93,6 +120,29 @@ static void time3(float* d, int iters, const char** names) {
          h[0] / iters, h[4] / iters, h[8] / iters);
 }
 
+// as probe, but role B raises its wave priority (s_setprio 3) and role A lowers it (0)
+template <int RA, int RB>
+__global__ __launch_bounds__(512) void probe_prio(float* out, int iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  if (wave >= 4) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(0);
+  const long long t0 = __builtin_readcyclecounter();
+  float r = wave < 4 ? run_role<RA>(iters, seed) : run_role<RB>(iters, seed);
+  const long long t1 = __builtin_readcyclecounter();
+  if (r == 12345.678f) out[threadIdx.x] = r;
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[1024 + wave] = (float)(t1 - t0);
+}
+template <int RA, int RB>
+static void time_prio(float* d, int iters, const char** names) {
+  probe_prio<RA, RB><<<256, 512>>>(d, iters, 1.0f);
+  hipDeviceSynchronize();
+  probe_prio<RA, RB><<<256, 512>>>(d, iters, 1.0f);
+  hipDeviceSynchronize();
+  float h[8];
+  hipMemcpy(h, d + 1024, sizeof(h), hipMemcpyDeviceToHost);
+  printf("PRIO(B=3,A=0) A=%-12s B=%-12s : cycles/iter A %6.1f  B %6.1f\n", names[RA], names[RB], h[0] / iters, h[4] / iters);
+}
+
 template <int RA, int RB>
 static float time_it(float* d, int iters) {
   hipEvent_t s, e;
@@ -113,9 +163,15 @@ static float time_it(float* d, int iters) {
 int main() {
   float* d; hipMalloc(&d, 8192);
   const int it = 20000;
-  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)"};
+  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4"};
 #define T(A, B) { float us = time_it<A, B>(d, it); printf("A=%-12s B=%-12s : %8.1f us   role A %8.1f us  role B %8.1f us\n", names[A], names[B], us, g_ta * 0.01f, g_tb * 0.01f); }
   T(1, 0) T(5, 0) T(0, 2) T(0, 3) T(0, 4) T(1, 1) T(2, 2) T(3, 3) T(1, 2) T(1, 3) T(1, 4) T(5, 2) T(5, 3) T(2, 3)
+  T(2, 1) T(6, 0) T(6, 2) T(7, 0) T(7, 2) T(2, 7)
+  T(3, 1) T(4, 1) T(3, 7) T(2, 6)
+  time_prio<1, 2>(d, it, names);
+  time_prio<1, 3>(d, it, names);
+  time_prio<1, 4>(d, it, names);
+  time_prio<2, 1>(d, it, names);
   time3<1, 2, 0>(d, it, names);
   time3<1, 2, 2>(d, it, names);
   time3<1, 3, 3>(d, it, names);

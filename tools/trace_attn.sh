@@ -8,24 +8,31 @@ mkdir -p $R/tools/bin/abl
 if [ "$1" = "build" ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DPP_TRACE=1 ${TRACE_FLAGS:-} $R/inferix_amd/csrc/ifx_*.hip -o $R/tools/bin/abl/libtrace.so
 else
-  IFX_HIP_LIB=$R/tools/bin/abl/libtrace.so python - "$2" <<'PY'
+  IFX_HIP_LIB=${TRACE_LIB:-$R/tools/bin/abl/libtrace.so} python - "$2" <<'PY'
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(os.environ["IFX_HIP_LIB"]))) + "/../..")
 sys.path.insert(0, "/root/repo")
 import torch
 from inferix_amd import hip_ops as ops
 L = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] else 18720
+NG = int(os.environ.get("ATTN_VARIANT", "2"))
+ops.set_option("attn_variant", NG)
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g, device="cuda").to(torch.bfloat16)
 q, k, v = rnd(4680, 12, 128), rnd(L, 12, 128), rnd(L, 12, 128)
 for _ in range(2):
     out, lse = ops.attention(q, ops.KvCacheView(k, v), L, return_lse=True, splits=1)
 torch.cuda.synchronize()
-tr = lse.reshape(-1).view(torch.int64)[:64 * 8 * 8].view(64, 8, 8).cpu()
+W = 4 * NG
+tr = lse.reshape(-1).view(torch.int64)[:64 * W * 8].view(64, W, 8).cpu()
 import numpy as np
+np.set_printoptions(linewidth=200)
 t = tr.numpy().astype(np.int64)
-names = ["wait DMA (G0) ", "barrier A     ", "M step        ", "wait DMA (G1) ", "barrier B     ", "V step        "]
-print("mean cycles over tiles 8..56, per wave 0..7 (waves w and w+4 share a SIMD)")
+if NG == 2:
+    names = ["wait DMA (G0) ", "barrier A     ", "M step        ", "wait DMA (G1) ", "barrier B     ", "V step        "]
+else:
+    names = ["wait+barrier M", "M step        ", "barrier V1    ", "V1 (+DMA wait)", "barrier V2    ", "V2 step       "]
+print(f"mean cycles over tiles 8..56, per wave 0..{W-1} (waves w, w+4, w+8 share a SIMD)")
 for i, n in enumerate(names):
     print(n, (t[8:56, :, i + 1] - t[8:56, :, i]).mean(0).round(0))
 print("tile period   ", (t[9:57, :, 0] - t[8:56, :, 0]).mean(0).round(0))
