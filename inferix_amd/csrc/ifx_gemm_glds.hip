@@ -432,6 +432,202 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256(tokens) x 256(channels) x 32(K) tiles, 8 waves (2 x 4, 128 x 64 outputs each), 4-stage LDS-DMA ring.
+// Why: the 256x128x64 kernel is bound by operand DELIVERY, not by the matrix pipe — with MFMAs and fragment reads
+// ablated it still takes 127 of 209 us on the 4680x8960x1536 GEMM (profiles/r1d_gemm_ablation.md): the ring keeps
+// two 48 KiB tiles (96 KiB) in flight per CU against ~2 us of L2 latency = ~20 B/clk/CU.  A 256x256 tile needs a
+// third fewer operand bytes per FLOP (64 KiB per 8.4 MFLOP against 48 KiB per 4.2), and K-steps of 32 in four
+// 32 KiB stages keep 96 KiB in flight in a 128 KiB ring.  Used when the tile count still fills the chip
+// (pick_tile in ifx_gemm.hip); same operand roles, swizzled DMA and LDS-transposed epilogue as above.
+//   LDS rows are 64 B (32 bf16): physical 16-byte chunk = logical chunk XOR ((row >> 2) & 3).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                       const unsigned short* __restrict__ w,
+                                                       unsigned short* __restrict__ y, int ldy, int M, int N, int K,
+                                                       int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
+  constexpr int BM = 256, BN = 256, BK = 32, NST = 4;
+  constexpr int STAGE = (BM + BN) * BK * 2;              // 32768 B
+  constexpr int A_OFF = 0, B_OFF = BM * BK * 2;          // x tile [256][64 B], W tile [256][64 B]
+  constexpr int WM = 128, WN = 64, TJ = 4, TI = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int t_id = xcd * per_xcd + slot_i;
+  if (slot_i >= per_xcd || t_id >= total) return;
+  constexpr int GM = 4;
+  const int tiles_n = total / tiles_m;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // LDS-DMA: one wave-instruction = 16 rows x 64 B; lane -> row (lane >> 2), physical chunk (lane & 3)
+  const int r16 = lane >> 2, pc = lane & 3;
+  const unsigned short* src_a[2];
+  const unsigned short* src_b[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = (r * 8 + wave) * 16 + r16;            // 0..255
+    const int lc = pc ^ ((row >> 2) & 3);
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + lc * 8;
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + lc * 8;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % NST) * STAGE;
+    const size_t ko = (size_t)kt * BK;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko), (lds_ptr_t)(st + B_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = K / BK;
+  issue(0);
+  if (KT > 1) issue(1);
+  if (KT > 2) issue(2);
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  int a_off[TJ], b_off[TI], a_swz[TJ], b_swz[TI];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int row = wm * WM + j * 32 + l31;
+    a_off[j] = A_OFF + row * 64;
+    a_swz[j] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int row = wn * WN + i * 32 + l31;
+    b_off[i] = B_OFF + row * 64;
+    b_swz[i] = (row >> 2) & 3;
+  }
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int later = min(KT - 1 - kt, 2);                 // own pieces of tile kt landed; later tiles stay in flight
+    if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 3 < KT) issue(kt + 3);
+    const unsigned char* st = smem + (kt % NST) * STAGE;
+    bf16x8 fa[2][TJ], fb[2][TI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + hi;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fb[ks][i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fa[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_off[j] + ((c ^ a_swz[j]) << 4));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue: per-wave LDS transpose of v = bf16(acc + bias) (128 tokens x 128 B, 16 KiB per wave = the whole
+  //      ring), then row-contiguous 16-byte accesses for residual / gate / store
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  unsigned char* tw = smem + wave * (WM * WN * 2);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int mrow = j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = i * 32 + g * 8 + hi * 4;
+        const int n = n_base + wn * WN + nl;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (ea.bias && n < N) {
+          const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        const int chunk = (nl >> 3) ^ (mrow & 7);
+        *reinterpret_cast<u16x4*>(tw + mrow * 128 + chunk * 16 + (nl & 4) * 2) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int p = 0; p < WM / 8; ++p) {
+      const int mrow = p * 8 + rr;
+      const int m = m_base + wm * WM + mrow;
+      const int n = n_base + wn * WN + cc * 8;
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * 128 + ((cc ^ (mrow & 7)) << 4));
+      if (m >= M || n >= N) continue;
+      u16x8 o;
+      if (EPI == IFX_EPI_BIAS) {
+        o = vv;
+      } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+      } else {
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
+        if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + bf2f(vv[e]));
+        } else {
+          const u16x8 gv = *reinterpret_cast<const u16x8*>(
+              ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+        }
+      }
+      *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+    }
+  }
+}
+
+static int launch_big(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N,
+                      int K, int mode, const EpiArgs2& ea, hipStream_t s) {
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const dim3 grid(per_xcd * 8), block(512);
+  constexpr size_t lds = 4 * 32768;
+#define IFX_LAUNCH_GB(E)                                                                                             \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_big_kernel<E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd, ea); \
+  } while (0)
+  switch (mode) {
+    case IFX_EPI_BIAS: IFX_LAUNCH_GB(IFX_EPI_BIAS); break;
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_GB(IFX_EPI_GELU_TANH); break;
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_GB(IFX_EPI_RESIDUAL); break;
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_GB(IFX_EPI_GATE_RES); break;
+    default: return IFX_EINVAL;
+  }
+#undef IFX_LAUNCH_GB
+  return check_launch("ifx_gemm_bf16(256x256)");
+}
+
 template <int BM, int BN>
 static int launch_small(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                         int N, int K, int mode, const EpiArgs2& ea, hipStream_t s) {
@@ -461,7 +657,7 @@ static int launch_small(const unsigned short* x, int ldx, const unsigned short* 
   return check_launch("ifx_gemm_bf16(small)");
 }
 
-// tile: 0 = 256x128 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64
+// tile: 0 = 256x128 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64, 3 = 256x256x32
 int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
                         int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
                         int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
@@ -510,6 +706,7 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
                             rows_per_group, s);
   EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
   if (tile == 1) return launch_small<128, 128>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 3) return launch_big(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   return launch_small<64, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 
