@@ -56,6 +56,53 @@ __device__ __forceinline__ float run_role(int iters, float seed) {
       c3 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c3, 0, 0, 0);
     }
     return c0[0] + c1[1] + c2[2] + c3[3];
+  } else if (ROLE == 8) {
+    float x[8];
+    f32x2 y[4], k = {seed, seed};
+    for (int i = 0; i < 8; ++i) x[i] = seed * 0.001f + i * 0.01f;
+    for (int i = 0; i < 4; ++i) y[i] = f32x2{seed + i, seed - i};
+    unsigned pk[4] = {0, 0, 0, 0};
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(y[i]) : "v"(k));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[i]) : "v"(k));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[i]) : "v"(x[2 * i]), "v"(x[2 * i + 1]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x[i]));
+    }
+    float s = acc + (float)(pk[0] + pk[1] + pk[2] + pk[3]);
+    for (int i = 0; i < 4; ++i) s += y[i][0] + y[i][1];
+    return s;
+  } else if (ROLE == 9 || ROLE == 10) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    const unsigned char* base = lds + (threadIdx.x & 63) * 16;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 c[8] = {};
+    f32x16 d0 = {}, d1 = {}, d2 = {}, d3 = {};
+    for (int it = 0; it < iters; ++it) {
+      bf16x8 f0 = *reinterpret_cast<const bf16x8*>(base + ((it & 3) << 10));
+      bf16x8 f1 = *reinterpret_cast<const bf16x8*>(base + 4096 + ((it & 3) << 10));
+      asm volatile("" : "+v"(f0), "+v"(f1));
+      if (ROLE == 9) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i & 1 ? f1 : f0, b, c[i], 0, 0, 0);
+      } else {
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, b, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, b, d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, b, d2, 0, 0, 0);
+        d3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, b, d3, 0, 0, 0);
+      }
+    }
+    float s = d0[0] + d1[1] + d2[2] + d3[3];
+    for (int i = 0; i < 8; ++i) s += c[i][0];
+    return s;
   } else if (ROLE == 2) {
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = seed + i;
@@ -163,11 +210,12 @@ static float time_it(float* d, int iters) {
 int main() {
   float* d; hipMalloc(&d, 8192);
   const int it = 20000;
-  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4"};
+  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4", "softmax mix 24", "M16+lds", "M32+lds"};
 #define T(A, B) { float us = time_it<A, B>(d, it); printf("A=%-12s B=%-12s : %8.1f us   role A %8.1f us  role B %8.1f us\n", names[A], names[B], us, g_ta * 0.01f, g_tb * 0.01f); }
   T(1, 0) T(5, 0) T(0, 2) T(0, 3) T(0, 4) T(1, 1) T(2, 2) T(3, 3) T(1, 2) T(1, 3) T(1, 4) T(5, 2) T(5, 3) T(2, 3)
   T(2, 1) T(6, 0) T(6, 2) T(7, 0) T(7, 2) T(2, 7)
   T(3, 1) T(4, 1) T(3, 7) T(2, 6)
+  T(8, 0) T(9, 0) T(10, 0) T(8, 10) T(10, 8) T(8, 9) T(9, 8) T(8, 8)
   time_prio<1, 2>(d, it, names);
   time_prio<1, 3>(d, it, names);
   time_prio<1, 4>(d, it, names);
