@@ -258,7 +258,7 @@ def main():
             "ms_per_denoise_step": round(sum(denoise_ms) / len(denoise_ms), 3),
             "ms_per_forward_by_block": per_block_ms,
             "generator_forwards_timed": forwards,
-            "roofline": {"kernel": "ifx::attn_fwd_kernel (block-causal paged flash attention)", "bound": "mfma",
+            "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (block-causal paged flash attention, self-attention launches)", "bound": "mfma",
                          "achieved": round(attn_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(attn_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / max(ks["launches"], 1), 4),
