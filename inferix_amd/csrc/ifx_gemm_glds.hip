@@ -441,15 +441,17 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
 // 32 KiB stages keep 96 KiB in flight in a 128 KiB ring.  Used when the tile count still fills the chip
 // (pick_tile in ifx_gemm.hip); same operand roles, swizzled DMA and LDS-transposed epilogue as above.
 //   LDS rows are 64 B (32 bf16): physical 16-byte chunk = logical chunk XOR ((row >> 2) & 3).
-template <int EPI>
+template <int BM, int BN, int WAVES_M, int NST, int EPI>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
                                                        const unsigned short* __restrict__ w,
                                                        unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                        int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
-  constexpr int BM = 256, BN = 256, BK = 32, NST = 4;
-  constexpr int STAGE = (BM + BN) * BK * 2;              // 32768 B
-  constexpr int A_OFF = 0, B_OFF = BM * BK * 2;          // x tile [256][64 B], W tile [256][64 B]
-  constexpr int WM = 128, WN = 64, TJ = 4, TI = 2;
+  constexpr int BK = 32;
+  constexpr int STAGE = (BM + BN) * BK * 2;              // 32 KiB (256x256) / 24 KiB (256x128)
+  constexpr int A_OFF = 0, B_OFF = BM * BK * 2;          // x tile [BM][64 B], W tile [BN][64 B]
+  constexpr int WAVES_N = 8 / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TJ = WM / 32, TI = WN / 32;
+  constexpr int PA = BM / 128, PB = BN / 128, P = PA + PB;   // DMA instructions per wave per K-tile (16 rows each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -464,27 +466,31 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   const int rem = t_id % grp_sz;
   const int tile_m = first_m + rem % gm, tile_n = rem / gm;
   const int m_base = tile_m * BM, n_base = tile_n * BN;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
   // LDS-DMA: one wave-instruction = 16 rows x 64 B; lane -> row (lane >> 2), physical chunk (lane & 3)
   const int r16 = lane >> 2, pc = lane & 3;
-  const unsigned short* src_a[2];
-  const unsigned short* src_b[2];
+  const unsigned short* src_a[PA];
+  const unsigned short* src_b[PB];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = (r * 8 + wave) * 16 + r16;            // 0..255
-    const int lc = pc ^ ((row >> 2) & 3);
-    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + lc * 8;
-    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + lc * 8;
+  for (int r = 0; r < PA; ++r) {
+    const int row = (r * 8 + wave) * 16 + r16;
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 2) & 3)) * 8;
+  }
+#pragma unroll
+  for (int r = 0; r < PB; ++r) {
+    const int row = (r * 8 + wave) * 16 + r16;
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 2) & 3)) * 8;
   }
   auto issue = [&](int kt) {
     unsigned char* st = smem + (kt % NST) * STAGE;
     const size_t ko = (size_t)kt * BK;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < PA; ++r)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < PB; ++r)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko), (lds_ptr_t)(st + B_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
-    }
   };
 
   f32x16 acc[TI][TJ];
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int KT = K / BK;
-  issue(0);
-  if (KT > 1) issue(1);
-  if (KT > 2) issue(2);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < KT) issue(i);
 
   const int l31 = lane & 31, hi = lane >> 5;
   int a_off[TJ], b_off[TI], a_swz[TJ], b_swz[TI];
@@ -516,13 +522,15 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   }
 
   for (int kt = 0; kt < KT; ++kt) {
-    const int later = min(KT - 1 - kt, 2);                 // own pieces of tile kt landed; later tiles stay in flight
-    if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int later = min(KT - 1 - kt, NST - 2);           // own pieces of tile kt landed; later tiles stay in flight
+    if (later >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * P) : "memory");
+    else if (later == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * P) : "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 3 < KT) issue(kt + 3);
+    if (kt + NST - 1 < KT) issue(kt + NST - 1);
     const unsigned char* st = smem + (kt % NST) * STAGE;
     bf16x8 fa[2][TJ], fb[2][TI];
 #pragma unroll
@@ -546,7 +554,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   //      ring), then row-contiguous 16-byte accesses for residual / gate / store
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  unsigned char* tw = smem + wave * (WM * WN * 2);
+  constexpr int RB = WN * 2, CR = RB / 16, RP = 64 / CR;   // row bytes, 16-B chunks per row, rows per instruction
+  unsigned char* tw = smem + wave * (WM * RB);
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int mrow = j * 32 + l31;
@@ -565,19 +574,19 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
         u16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        const int chunk = (nl >> 3) ^ (mrow & 7);
-        *reinterpret_cast<u16x4*>(tw + mrow * 128 + chunk * 16 + (nl & 4) * 2) = o;
+        const int chunk = (nl >> 3) ^ (mrow & (CR - 1));
+        *reinterpret_cast<u16x4*>(tw + mrow * RB + chunk * 16 + (nl & 4) * 2) = o;
       }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   {
-    const int rr = lane >> 3, cc = lane & 7;
+    const int rr = lane / CR, cc = lane % CR;
 #pragma unroll
-    for (int p = 0; p < WM / 8; ++p) {
-      const int mrow = p * 8 + rr;
+    for (int p = 0; p < WM / RP; ++p) {
+      const int mrow = p * RP + rr;
       const int m = m_base + wm * WM + mrow;
       const int n = n_base + wn * WN + cc * 8;
-      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * 128 + ((cc ^ (mrow & 7)) << 4));
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * RB + ((cc ^ (mrow & (CR - 1))) << 4));
       if (m >= M || n >= N) continue;
       u16x8 o;
       if (EPI == IFX_EPI_BIAS) {
@@ -602,20 +611,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   }
 }
 
+template <int BM, int BN, int WAVES_M, int NST>
 static int launch_big(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N,
                       int K, int mode, const EpiArgs2& ea, hipStream_t s) {
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(512);
-  constexpr size_t lds = 4 * 32768;
+  constexpr size_t lds = (size_t)NST * (BM + BN) * 64;
 #define IFX_LAUNCH_GB(E)                                                                                             \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WAVES_M, NST, E>,                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_big_kernel<E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd, ea); \
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WAVES_M, NST, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K,  \
+                       tiles_m, total, per_xcd, ea);                                                                 \
   } while (0)
   switch (mode) {
     case IFX_EPI_BIAS: IFX_LAUNCH_GB(IFX_EPI_BIAS); break;
@@ -625,7 +637,7 @@ static int launch_big(const unsigned short* x, int ldx, const unsigned short* w,
     default: return IFX_EINVAL;
   }
 #undef IFX_LAUNCH_GB
-  return check_launch("ifx_gemm_bf16(256x256)");
+  return check_launch("ifx_gemm_bf16(k32)");
 }
 
 template <int BM, int BN>
@@ -657,7 +669,8 @@ static int launch_small(const unsigned short* x, int ldx, const unsigned short* 
   return check_launch("ifx_gemm_bf16(small)");
 }
 
-// tile: 0 = 256x128 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64, 3 = 256x256x32
+// tile: 0 = 256x128x64 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64, 3 = 256x256x32 (4 stages).  (A 256x128x32 six-stage instantiation of the same template, 120 KiB in flight,
+// measured equal to tile 0 — 90.7 / 36.1 / 201 / 150 us on the four block GEMMs — and is not built.)
 int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
                         int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
                         int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
@@ -706,7 +719,7 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
                             rows_per_group, s);
   EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
   if (tile == 1) return launch_small<128, 128>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
-  if (tile == 3) return launch_big(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 3) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   return launch_small<64, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 
