@@ -214,3 +214,21 @@ def test_components_match_oracle():
     assert torch.equal(C.patchify(lat, cfg.patch_size), O.patchify(lat, cfg).flatten(0, 1))
     y = torch.randn(2 * 72, 64, generator=g)
     assert torch.equal(C.unpatchify(y, 2, (3, 4, 6), cfg.patch_size, 16), O.unpatchify(y.view(2, 72, 64), (3, 4, 6), cfg))
+
+
+def test_outer_plugin_refuses_to_run_without_a_gpu(tmp_path):
+    """`SelfForcingPipeline` (the reference's plugin class name) exists, parses its yaml, and fails loudly on a host
+    without an MI355X instead of falling back to anything."""
+    import yaml
+    from inferix_amd.pipeline import SelfForcingPipeline
+    import torch
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text(yaml.safe_dump({"denoising_step_list": [1000, 750, 500, 250], "model_kwargs": {}}))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_hip_plugin_api.py")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SelfForcingPipeline(str(cfg))
+    bidir = tmp_path / "b.yaml"
+    bidir.write_text(yaml.safe_dump({"model_kwargs": {}}))
+    with pytest.raises(NotImplementedError):
+        SelfForcingPipeline(str(bidir))
