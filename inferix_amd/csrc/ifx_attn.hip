@@ -53,6 +53,14 @@ struct AttnArgs {
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* attn_gbl_ptr_t;
 
+// One LDS-DMA instruction issued from inline asm (64 lanes x 16 B, lane-linear at LDS byte address `lds`).  hipcc tracks
+// the LDS-DMA builtin as an LDS store and drains vmcnt in front of the next LDS read that may alias it — here the
+// V^T fragment reads of the CURRENT tile — which made every tile wait for the prefetch of the NEXT one
+// (profiles/r1d_attention_step_trace.md).  Ordering is by the explicit vmcnt(0) + barrier at the end of each tile.
+__device__ __forceinline__ void attn_dma16(const unsigned short* src, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(src) : "memory");
+}
+
 // single-instruction 3-input max (plain fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max per input)
 __device__ __forceinline__ float max3f(float a, float b, float c) {
   float r;
@@ -106,6 +114,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
+  // retire the Q loads with a wait the compiler can see, or it guards every use of qf in the loop with vmcnt waits
+  // that (sharing the counter with the asm-issued DMA) drain the prefetch
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   // ---- LDS-DMA map: one wave instruction = 1 KiB = 4 key rows x 256 B; lane -> row (lane >> 4) of the
   //      group, PHYSICAL 16-byte chunk pc = lane & 15.  K: physical chunk pc holds logical chunk
@@ -122,19 +133,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const unsigned short* kbase = A.k + kvh * HD;
   const unsigned short* vbase = A.v + kvh * HD;
   const int last_key = A.kv_len - 1;
+  const unsigned lds0 = (unsigned)(unsigned long long)(attn_lds_ptr_t)smem + wave * 1024;
   // issue<CLAMP=false>: steady-state tiles (all 64 keys valid) use one 64-bit add per piece
   auto issue = [&](int t, int buf, auto clamp_tag) {
     constexpr bool CLAMP = decltype(clamp_tag)::value;
-    unsigned char* kb = smem + buf * 32768;
+    const unsigned kb = lds0 + buf * 32768;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int key = A.kv_start + t * KT + d_rowi[r];
       if (CLAMP) key = min(key, last_key);                                 // ragged tail: re-read a valid row
       const size_t off = (size_t)(PAGED ? A.ka.slot(key) : key) * kv_stride;
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)(kbase + off + k_src_c[r]),
-                                       (attn_lds_ptr_t)(kb + (r * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)(vbase + off + v_src_c[r]),
-                                       (attn_lds_ptr_t)(kb + 16384 + (r * 4 + wave) * 1024), 16, 0, 0);
+      attn_dma16(kbase + off + k_src_c[r], kb + r * 4096);
+      attn_dma16(vbase + off + v_src_c[r], kb + 16384 + r * 4096);
     }
   };
 
@@ -194,7 +204,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[d], p, o[d], 0, 0, 0);
     };
-    // softmax of one 32-key block: returns alpha (1 when the running max did not move)
+    // softmax of one 32-key block against the LAZY reference maximum m_run (see ifx_attn_pp.hip): the true row
+    // maximum is taken for the very first block only; afterwards p = exp2(c2*(s - m_run)) is formed directly and only
+    // the block's row sums are checked — a row that outgrew the reference by 2^20 (or overflowed) makes the wave redo
+    // the block against its true maximum.  Returns the factor O and l must be rescaled by (1 in the common case).
+    auto block_max = [&](f32x16& sb) -> float {
+      // the FIRST read of the S accumulators is a compiler-visible instruction: hipcc inserts the MFMA -> VALU wait
+      // states for it, which it does not do for operands of inline asm
+      float mx = __builtin_fmaxf(sb[0], sb[1]);
+      mx = max3f(mx, sb[2], m_run);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = max3f(mx, sb[r], sb[r + 1]);
+      mx = max3f(mx, sb[15], mx);
+      return half_swap_max(mx);                        // >= m_run, identical in lane and lane^32
+    };
+    auto exp_block = [&](f32x16& sb, bf16x8(&pb)[2]) -> float {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float mc = m_run * c2;
+      const f32x2 c2v = {c2, c2}, mcv = {mc, mc};
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 sv = {sb[2 * i], sb[2 * i + 1]};
+        const f32x2 e = sv * c2v - mcv;
+        const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+        a0 += p0;
+        a1 += p1;
+        pb[i >> 2][(2 * i) & 7] = static_cast<__bf16>(p0);
+        pb[i >> 2][(2 * i + 1) & 7] = static_cast<__bf16>(p1);
+      }
+      return a0 + a1;
+    };
     auto softmax_block = [&](f32x16& sb, int b, bf16x8(&pb)[2]) -> float {
       if (RAGGED) {
         const int kidx = t * KT + 32 * b + 4 * hi;
@@ -202,27 +242,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
         for (int r = 0; r < 16; ++r)
           if (kidx + (r & 3) + 8 * (r >> 2) >= nkeys) sb[r] = -INFINITY;
       }
-      // The FIRST read of the S accumulators is a compiler-visible instruction: hipcc inserts the MFMA -> VALU
-      // wait states (or useful work) for it, which it does not do for operands of inline asm.  (A v_max3 asm as
-      // first reader was scheduled right behind the last S MFMA and read the accumulators one k-step stale —
-      // still a valid softmax stabiliser, but timing dependent: run-to-run different roundings.)
-      float mx = __builtin_fmaxf(sb[0], sb[1]);
-      mx = max3f(mx, sb[2], m_run);
-#pragma unroll
-      for (int r = 3; r < 15; r += 2) mx = max3f(mx, sb[r], sb[r + 1]);
-      mx = max3f(mx, sb[15], mx);                       // m_new candidate for this half-wave
-      const float m_new = half_swap_max(mx);             // >= m_run, identical in lane and lane^32
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);   // exp2(-inf)=0 on the first block
-      m_run = m_new;
-      const float mc = m_new * c2;
-      float ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sb[r] * c2 - mc);
-        ps += p;
-        pb[r >> 3][r & 7] = static_cast<__bf16>(p);
+      if (t == 0 && b == 0) m_run = block_max(sb);       // O and l are still zero: nothing to rescale
+      float ps = exp_block(sb, pb);
+      float alpha = 1.0f;
+      if (__any(!(ps < 1048576.f))) {                    // rare: redo against the true maximum (inf / NaN land here)
+        const float m_new = block_max(sb);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+        m_run = m_new;
+        ps = exp_block(sb, pb);
+        l_run *= alpha;
       }
-      l_run = l_run * alpha + ps;
+      l_run += ps;
       return alpha;
     };
     auto rescale_o = [&](float alpha) {
