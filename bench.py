@@ -63,10 +63,11 @@ def build_pipeline(device, parallel_config=None, num_layers=None):
     return model, gen, pipe
 
 
-def cpu_baseline(budget_layers: int = 2):
-    """The CPU oracle (port of the reference's CPU/PyTorch path, parity-pinned to it) on this box's host
-    cores: `budget_layers` real-size layers of one block-0 forward (N = L_kv = 4680), extrapolated linearly to
-    30 layers x 35 forwards.  Attention cost growth with the prefix is ignored, which FAVOURS the CPU."""
+def cpu_baseline(budget_layers: int = 4):
+    """The CPU oracle (port of the reference's CPU/PyTorch path, parity-pinned to it) on this box's host cores:
+    `budget_layers` real-size layers of one denoise forward at the prefix of block 0, 3 and 6 (L_kv = 4680, 18720,
+    32760; about 10-20 s of CPU work).  The clip = 7 blocks x 5 forwards x 30 layers is then priced with the
+    per-layer time interpolated linearly in the block index between the measured prefixes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wan_oracle as O
     cfg = O.WanConfig(num_layers=budget_layers)
@@ -74,24 +75,42 @@ def cpu_baseline(budget_layers: int = 2):
     g = torch.Generator().manual_seed(0)
     fs = cfg.frame_seqlen
     n = BLOCK * fs
-    x = torch.randn(1, n, cfg.dim, generator=g).to(torch.bfloat16)
+    nblk = FRAMES // BLOCK
+    x0 = torch.randn(1, n, cfg.dim, generator=g).to(torch.bfloat16)
     e0 = (torch.randn(1, BLOCK, 6, cfg.dim, generator=g) * 0.5).to(torch.bfloat16)
     ctx = torch.randn(1, cfg.text_len, cfg.dim, generator=g).to(torch.bfloat16)
-    state = O.CacheState.allocate(cfg, 1, torch.bfloat16, cache_tokens=n)
     freqs = O.rope_freqs(cfg.head_dim)
-    grid = (BLOCK, 30, 52)
-    t0 = time.perf_counter()
+    state = O.CacheState.allocate(cfg, 1, torch.bfloat16, cache_tokens=nblk * n)
+    for l in state.layers:                      # a filled prefix (values are irrelevant for the timing)
+        l.k.normal_(generator=g)
+        l.v.normal_(generator=g)
+    per_layer = {}
+    total = 0.0
     with torch.no_grad():
-        for i in range(budget_layers):
-            x = O.block_forward(x, e0, ctx, W, i, cfg, grid, freqs, state, 0)
-    dt = time.perf_counter() - t0
-    per_layer = dt / budget_layers
-    clip_s = per_layer * 30 * 35
+        for b in (0, nblk // 2, nblk - 1):
+            for l in state.layers:
+                l.global_end = l.local_end = b * n
+            x = x0
+            t0 = time.perf_counter()
+            for i in range(budget_layers):
+                x = O.block_forward(x, e0, ctx, W, i, cfg, (BLOCK, 30, 52), freqs, state, b * n)
+            dt = time.perf_counter() - t0
+            total += dt
+            per_layer[b] = dt / budget_layers
+    bs = sorted(per_layer)
+
+    def interp(b):
+        lo = max(v for v in bs if v <= b)
+        hi = min(v for v in bs if v >= b)
+        return per_layer[lo] if lo == hi else per_layer[lo] + (per_layer[hi] - per_layer[lo]) * (b - lo) / (hi - lo)
+    clip_s = sum(interp(b) for b in range(nblk)) * (len(STEPS_LIST) + 1) * 30
     return {"value": FRAMES / clip_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{budget_layers} of 30 layers of one block-0 denoise forward (N=L_kv=4680, real Wan-1.3B dims, "
-                      f"bf16 CPU oracle), {dt:.1f} s measured, x(30/{budget_layers}) layers x35 forwards; "
-                      "prefix growth ignored (favours CPU)",
-            "ms_per_layer_forward": per_layer * 1e3, "host_cpus": os.cpu_count()}
+            "sample": f"{budget_layers} of 30 layers of one generator forward at block 0 / {nblk // 2} / {nblk - 1} "
+                      f"(N = 4680 queries, L_kv = 4680 / {(nblk // 2 + 1) * n} / {nblk * n}; real Wan-1.3B dims, bf16 CPU "
+                      f"oracle), {total:.1f} s measured; clip = 7 blocks x 5 forwards x 30 layers, per-layer time "
+                      "interpolated linearly in the block index",
+            "ms_per_layer_forward_by_block": {str(k): round(v * 1e3, 1) for k, v in per_layer.items()},
+            "host_cpus": os.cpu_count()}
 
 
 def pmc_traffic(shards):
