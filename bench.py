@@ -28,6 +28,7 @@ from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver stack
 import torch  # noqa: E402
 
 # gfx950 peaks (MI355X_MICROARCH.md): dense bf16 MFMA ~2.5 PFLOP/s, HBM3E 8 TB/s

@@ -236,13 +236,6 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     s[0] = s[1] = f32x16{};
   }
 
-  auto ldK = [&](bf16x8(&f)[4], const unsigned char* kb, int b, int kh) {
-    if (PP_ABLATE & 4) return;
-    const unsigned char* krow = kb + (32 * b + l31) * 256;
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4)
-      f[k4] = *reinterpret_cast<const bf16x8*>(krow + (((2 * (4 * kh + k4) + hi) ^ kswz) << 4));
-  };
   auto ldV = [&](bf16x8(&f)[4], const unsigned char* vb, int b, int s2) {
     if (PP_ABLATE & 4) return;
     const unsigned char* vr0 = vb + (32 * b + 16 * s2 + 4 * hi + v_rowq) * 256 + v_in;
@@ -254,11 +247,6 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr1 + ch));
       f[d] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
-  };
-  auto mmaK = [&](f32x16& acc, bf16x8(&f)[4], int kh) {
-    if (PP_ABLATE & 8) return;
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[k4], qf[4 * kh + k4], acc, 0, 0, 0);
   };
   auto mmaV = [&](bf16x8(&f)[4], const bf16x8& p) {
     if (PP_ABLATE & 8) return;

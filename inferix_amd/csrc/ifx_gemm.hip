@@ -180,19 +180,27 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
                         int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
                         hipStream_t s);
 
-// LDS-DMA tile choice: the largest tile that still gives every CU a workgroup (256 CUs); tiny shapes take 64x64.
-// 256x256 (a third fewer operand bytes per FLOP) when there are at least two full rounds of tiles — measured on
-// 4680 x 8960 x 1536: 167 us against 198 us with 256x128; with fewer tiles the coarser quantisation loses.
+// LDS-DMA tile choice: score = (measured relative throughput of the tile at full occupancy) x (how well the launch's
+// workgroups fill whole rounds of the chip).  256 CUs; the 64-wide tiles run two workgroups per CU.
+//   tile 3 = 256x256x32, 0 = 256x128x64, 1 = 128x128, 4 = 128x64, 2 = 64x64   (bench: tools/bench_kernels.py gemm M)
 static int pick_tile(int M, int N) {
-  auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-  if (wgs(256, 256) >= 512) return 3;
-  if (wgs(256, 128) >= 224) return 0;
-  if (wgs(128, 128) >= 200) return 1;
-  return 2;
+  struct Cand { int tile, bm, bn, slots; float base; };
+  static const Cand cands[] = {{3, 256, 256, 256, 1.00f}, {0, 256, 128, 256, 0.85f}, {1, 128, 128, 256, 0.75f},
+                               {4, 128, 64, 512, 0.78f},  {2, 64, 64, 512, 0.50f}};
+  int best = 2;
+  float best_score = -1.f;
+  for (const Cand& c : cands) {
+    const int tm = (M + c.bm - 1) / c.bm, tn = (N + c.bn - 1) / c.bn, wgs = tm * tn;
+    const int rounds = (wgs + c.slots - 1) / c.slots;
+    const float edge = ((float)M * (float)N) / ((float)(tm * c.bm) * (float)(tn * c.bn));   // work in ragged edge tiles
+    const float score = c.base * edge * (float)wgs / (float)(c.slots * rounds);
+    if (score > best_score) best_score = score, best = c.tile;
+  }
+  return best;
 }
 
 // kernel selection: 0 = auto (LDS-DMA kernels, tile by shape), 1 = force the register-staged 128x128 kernel,
-// 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32
+// 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32, 6 = force LDS-DMA 128x64
 }  // namespace ifx
 
 using namespace ifx;

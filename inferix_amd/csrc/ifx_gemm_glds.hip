@@ -265,12 +265,12 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short*
 // {128x128, 64x64}, 4 waves (2x2), same LDS-DMA staging / swizzle / transposed MFMA tile / LDS-transposed
 // epilogue as above, a 4-stage ring with THREE K-tiles in flight and one barrier per K-tile; the 64x64 shape
 // uses 64 KiB of LDS so two workgroups share a CU and hide each other's waits.
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int NST, int EPI>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* __restrict__ x, int ldx,
                                                          const unsigned short* __restrict__ w,
                                                          unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                          int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
-  constexpr int BK = 64, NST = 4;
+  constexpr int BK = 64;
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int A_OFF = 0, B_OFF = BM * BK * 2;
   constexpr int PA = BM / 32, PB = BN / 32, P = PA + PB;     // DMA instructions per wave per K-tile
@@ -325,9 +325,9 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int KT = K / BK;
-  issue(0);
-  if (KT > 1) issue(1);
-  if (KT > 2) issue(2);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < KT) issue(i);
 
   const int l31 = lane & 31, hi = lane >> 5;
   int a_row_off[TJ], b_row_off[TI], a_swz[TJ], b_swz[TI];
@@ -346,13 +346,13 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
 
   for (int kt = 0; kt < KT; ++kt) {
     // own pieces of tile kt landed; up to two later tiles stay in flight
-    const int later = min(KT - 1 - kt, 2);
+    const int later = min(KT - 1 - kt, NST - 2);
     if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own fragment reads of tile kt-1 retired
-    __builtin_amdgcn_s_barrier();          // tile kt complete for everyone; slot (kt-1)%4 drained by everyone
-    if (kt + 3 < KT) issue(kt + 3);
+    __builtin_amdgcn_s_barrier();          // tile kt complete for everyone; the slot of tile kt-1 drained by everyone
+    if (kt + NST - 1 < KT) issue(kt + NST - 1);
     const unsigned char* st = smem + (kt % NST) * STAGE;
     bf16x8 fa[4][TJ], fb[4][TI];
 #pragma unroll
@@ -640,22 +640,22 @@ static int launch_big(const unsigned short* x, int ldx, const unsigned short* w,
   return check_launch("ifx_gemm_bf16(k32)");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 static int launch_small(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                         int N, int K, int mode, const EpiArgs2& ea, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
-  constexpr size_t lds = (size_t)4 * (BM + BN) * 128;
+  constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
 #define IFX_LAUNCH_GS(E)                                                                                             \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_small_kernel<BM, BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)gemm_small_kernel<BM, BN, NST, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                           \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_small_kernel<BM, BN, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
+    hipLaunchKernelGGL((gemm_small_kernel<BM, BN, NST, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
                        per_xcd, ea);                                                                                 \
   } while (0)
   switch (mode) {
@@ -669,7 +669,7 @@ static int launch_small(const unsigned short* x, int ldx, const unsigned short* 
   return check_launch("ifx_gemm_bf16(small)");
 }
 
-// tile: 0 = 256x128x64 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64, 3 = 256x256x32 (4 stages).  (A 256x128x32 six-stage instantiation of the same template, 120 KiB in flight,
+// tile: 0 = 256x128x64 (8 waves, ping-pong), 1 = 128x128, 2 = 64x64, 3 = 256x256x32 (4 stages), 4 = 128x64 (3 stages).  (A 256x128x32 six-stage instantiation of the same template, 120 KiB in flight,
 // measured equal to tile 0 — 90.7 / 36.1 / 201 / 150 us on the four block GEMMs — and is not built.)
 int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
                         int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
@@ -718,9 +718,10 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
     return launch_gemm_glds(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot,
                             rows_per_group, s);
   EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
-  if (tile == 1) return launch_small<128, 128>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 1) return launch_small<128, 128, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 4) return launch_small<128, 64, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 3) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
-  return launch_small<64, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 
 }  // namespace ifx

@@ -303,7 +303,7 @@ def test_gemm_ffn_real_shapes(ops):
     assert_bf16_parity(y, torch.nn.functional.linear(u_ref, w2, b2), what="ffn.2 8960->1536")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(585, 1536, 1536), (300, 640, 256), (77, 64, 64), (1170, 4608, 1536)])
 def test_gemm_every_tile_variant(ops, variant, M, N, K):
     """Each GEMM kernel (register-staged 128x128, LDS-DMA 256x128 / 128x128 / 64x64) on shard shapes with ragged
@@ -368,7 +368,7 @@ def test_kernels_are_run_to_run_deterministic(ops):
             assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
         ops.set_option("attn_variant", 0)
         assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=4)), "split-KV attention"
-        for gv in (1, 2, 3, 4, 5):
+        for gv in (1, 2, 3, 4, 5, 6):
             ops.set_option("gemm_variant", gv)
             assert stable(lambda: ops.linear(x, w, b, epilogue=_hip.IFX_EPI_GELU_TANH), reps=15), f"gemm variant {gv}"
     finally:
