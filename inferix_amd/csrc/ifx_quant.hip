@@ -240,6 +240,248 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_kernel(const unsigned char* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the large shapes: BM x BN tiles, K-steps of 64 one-byte elements, 8 waves, 4-stage ring of
+// 64-byte rows — byte for byte the geometry of the bf16 K=32 kernel (ifx_gemm_glds.hip: gemm_big_kernel), so the DMA
+// map, the chunk swizzle ((row >> 2) & 3), the fragment reads and the LDS-transposed epilogue are the same; per FLOP it
+// moves half the operand bytes, which is what bounds the bf16 GEMMs (profiles/r1d_gemm_ablation.md).
+//   FP8 : PP_F8F6F4 = 1 -> one v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales) per 32-byte fragment pair: the 5 PFLOP/s
+//         instruction; 0 -> four v_mfma_f32_32x32x16_fp8_fp8.     INT8: two v_mfma_i32_32x32x32_i8.
+// The K order inside a fragment is whatever the hardware uses — both operands are read with the same lane -> byte map,
+// and a dot product does not care about a common permutation of k.
+#ifndef IFX_Q8_F8F6F4
+#define IFX_Q8_F8F6F4 1
+#endif
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((address_space(3))) void* q8_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* q8_gbl_ptr_t;
+
+template <bool FP8, int BM, int BN, int WAVES_M, int EPI>
+__global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* __restrict__ x, int ldx,
+                                                          const unsigned char* __restrict__ w,
+                                                          unsigned short* __restrict__ y, int ldy, int M, int N, int K,
+                                                          int tiles_m, int total, int per_xcd, EpiArgsQ ea) {
+  constexpr int BKB = 64, NST = 4;
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int A_OFF = 0, B_OFF = BM * BKB;
+  constexpr int WAVES_N = 8 / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TJ = WM / 32, TI = WN / 32;
+  constexpr int PA = BM / 128, PB = BN / 128, P = PA + PB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int t_id = xcd * per_xcd + slot_i;
+  if (slot_i >= per_xcd || t_id >= total) return;
+  constexpr int GM = 4;
+  const int tiles_n = total / tiles_m;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+  const int r16 = lane >> 2, pc = lane & 3;
+  const unsigned char* src_a[PA];
+  const unsigned char* src_b[PB];
+#pragma unroll
+  for (int r = 0; r < PA; ++r) {
+    const int row = (r * 8 + wave) * 16 + r16;
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 2) & 3)) * 16;
+  }
+#pragma unroll
+  for (int r = 0; r < PB; ++r) {
+    const int row = (r * 8 + wave) * 16 + r16;
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 2) & 3)) * 16;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % NST) * STAGE;
+    const size_t ko = (size_t)kt * BKB;
+#pragma unroll
+    for (int r = 0; r < PA; ++r)
+      __builtin_amdgcn_global_load_lds((q8_gbl_ptr_t)(src_a[r] + ko), (q8_lds_ptr_t)(st + A_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < PB; ++r)
+      __builtin_amdgcn_global_load_lds((q8_gbl_ptr_t)(src_b[r] + ko), (q8_lds_ptr_t)(st + B_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 facc[TI][TJ];
+  i32x16 iacc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        facc[i][j][r] = 0.f;
+        iacc[i][j][r] = 0;
+      }
+
+  const int KT = K / BKB;
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < KT) issue(i);
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  int a_off[TJ], b_off[TI], a_swz[TJ], b_swz[TI];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int row = wm * WM + j * 32 + l31;
+    a_off[j] = A_OFF + row * 64;
+    a_swz[j] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int row = wn * WN + i * 32 + l31;
+    b_off[i] = B_OFF + row * 64;
+    b_swz[i] = (row >> 2) & 3;
+  }
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int later = min(KT - 1 - kt, NST - 2);
+    if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < KT) issue(kt + NST - 1);
+    const unsigned char* st = smem + (kt % NST) * STAGE;
+    i32x4 fa[2][TJ], fb[2][TI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + hi;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fb[ks][i] = *reinterpret_cast<const i32x4*>(st + b_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fa[ks][j] = *reinterpret_cast<const i32x4*>(st + a_off[j] + ((c ^ a_swz[j]) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        if (FP8) {
+#if IFX_Q8_F8F6F4
+          const i32x8 av = __builtin_shufflevector(fb[0][i], fb[1][i], 0, 1, 2, 3, 4, 5, 6, 7);
+          const i32x8 bv = __builtin_shufflevector(fa[0][j], fa[1][j], 0, 1, 2, 3, 4, 5, 6, 7);
+          facc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, facc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#else
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const i64x2 al = __builtin_bit_cast(i64x2, fb[ks][i]), bl = __builtin_bit_cast(i64x2, fa[ks][j]);
+            facc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[0], bl[0], facc[i][j], 0, 0, 0);
+            facc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[1], bl[1], facc[i][j], 0, 0, 0);
+          }
+#endif
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            iacc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][i], fa[ks][j], iacc[i][j], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- epilogue: v = bf16(acc * sa[m] * sw[n] + bias[n]) transposed through LDS per wave, then 16-byte row accesses
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int RB = WN * 2, CR = RB / 16, RP = 64 / CR;
+  unsigned char* tw = smem + wave * (WM * RB);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int mrow = j * 32 + l31;
+    const int m = m_base + wm * WM + mrow;
+    const float sa = ea.sa[min(m, M - 1)];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = i * 32 + g * 8 + hi * 4;
+        const int n = n_base + wn * WN + nl;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) {
+          const f32x4 swv = *reinterpret_cast<const f32x4*>(ea.sw + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float acc = FP8 ? facc[i][j][4 * g + e] : (float)iacc[i][j][4 * g + e];
+            v[e] = acc * (sa * swv[e]);
+          }
+          if (ea.bias) {
+            const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+          }
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        const int chunk = (nl >> 3) ^ (mrow & (CR - 1));
+        *reinterpret_cast<u16x4*>(tw + mrow * RB + chunk * 16 + (nl & 4) * 2) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rr = lane / CR, cc = lane % CR;
+#pragma unroll
+    for (int p = 0; p < WM / RP; ++p) {
+      const int mrow = p * RP + rr;
+      const int m = m_base + wm * WM + mrow;
+      const int n = n_base + wn * WN + cc * 8;
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * RB + ((cc ^ (mrow & (CR - 1))) << 4));
+      if (m >= M || n >= N) continue;
+      u16x8 o;
+      if (EPI == IFX_EPI_BIAS) {
+        o = vv;
+      } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_q(bf2f(vv[e])));
+      } else {
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
+        if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + bf2f(vv[e]));
+        } else {
+          const u16x8 gv = *reinterpret_cast<const u16x8*>(
+              ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+        }
+      }
+      *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+    }
+  }
+}
+
+template <bool FP8, int BM, int BN, int WAVES_M>
+static int launch_q8_dma(const unsigned char* x, int ldx, const unsigned char* w, unsigned short* y, int ldy, int M, int N,
+                         int K, int mode, const EpiArgsQ& ea, hipStream_t s) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const dim3 grid(per_xcd * 8), block(512);
+  constexpr size_t ring = (size_t)4 * (BM + BN) * 64, epi = (size_t)BM * BN * 2;
+  constexpr size_t lds = ring > epi ? ring : epi;
+#define IFX_LAUNCH_Q8D(E)                                                                                            \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_q8_dma_kernel<FP8, BM, BN, WAVES_M, E>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_q8_dma_kernel<FP8, BM, BN, WAVES_M, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, \
+                       tiles_m, total, per_xcd, ea);                                                                 \
+  } while (0)
+  switch (mode) {
+    case IFX_EPI_BIAS: IFX_LAUNCH_Q8D(IFX_EPI_BIAS); break;
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_Q8D(IFX_EPI_GELU_TANH); break;
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_Q8D(IFX_EPI_RESIDUAL); break;
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_Q8D(IFX_EPI_GATE_RES); break;
+    default: return IFX_EINVAL;
+  }
+#undef IFX_LAUNCH_Q8D
+  return check_launch("ifx_gemm_q8(dma)");
+}
+
 }  // namespace ifx
 
 using namespace ifx;
@@ -283,12 +525,25 @@ extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, co
     ea.rows_per_group = epi->rows_per_group;
   }
   if (M == 0) return IFX_OK;
-  const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
-  const dim3 grid(((tiles_m * tiles_n + 7) / 8) * 8), block(256);
-  const size_t lds = 65536;
   hipStream_t s = (hipStream_t)stream;
   const unsigned char* xp = (const unsigned char*)xq;
   const unsigned char* wp = (const unsigned char*)wq;
+  // large shapes: LDS-DMA tiles (256x256 with >= 2 rounds of tiles, else 256x128 when it fills the chip);
+  // variant override through ifx_set_option("gemm_variant"): 1 = always the register-staged 128x128 kernel
+  const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0) && K % 64 == 0;
+  if (wide_ok && gemm_variant() != 1) {
+    auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    const int t = wgs(256, 256) >= 512 ? 2 : (wgs(256, 128) >= 224 ? 1 : 0);
+    if (t == 2)
+      return format == IFX_Q_FP8_E4M3 ? launch_q8_dma<true, 256, 256, 2>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s)
+                                      : launch_q8_dma<false, 256, 256, 2>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s);
+    if (t == 1)
+      return format == IFX_Q_FP8_E4M3 ? launch_q8_dma<true, 256, 128, 4>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s)
+                                      : launch_q8_dma<false, 256, 128, 4>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s);
+  }
+  const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+  const dim3 grid(((tiles_m * tiles_n + 7) / 8) * 8), block(256);
+  const size_t lds = 65536;
 #define IFX_LAUNCH_Q8(F, E)                                                                                      \
   do {                                                                                                           \
     static bool attr_set = false;                                                                                \
