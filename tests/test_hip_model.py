@@ -272,3 +272,29 @@ def test_other_resolutions_vs_oracle(lat_h, lat_w, frames):
     ref, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=8.0, num_frame_per_block=3)
     r = rel_l2(out.cpu(), ref)
     assert torch.isfinite(out.float()).all() and r < 1e-2, f"{lat_h}x{lat_w}: rollout rel-L2 {r:.3e}"
+
+
+def test_wan_14b_channel_geometry_vs_oracle():
+    """The 14B variant's channel geometry (dim 5120 = 40 heads x 128, ffn 13824) through the same kernels: one layer, a
+    two-block rollout on a small latent grid against the CPU oracle."""
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausalInferencePipeline
+    cfg = O.tiny_config(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, freq_dim=256)
+    W = O.init_weights(cfg, seed=2)
+    m, gen, args = _pipeline(cfg, W, [1000, 500], 5.0)
+    args.kv_cache_tokens = 6 * cfg.frame_seqlen
+    g = torch.Generator().manual_seed(14)
+    noise = torch.randn(1, 6, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF)
+    pe = torch.zeros(1, cfg.text_len, cfg.text_dim)
+    pe[:, :9] = torch.randn(1, 9, cfg.text_dim, generator=g)
+    pe = pe.to(BF)
+    eps = [torch.randn(3, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF) for _ in range(2)]
+    pipe = CausalInferencePipeline(args, "cuda", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe.cuda()},
+                                   vae=None)
+    out = pipe.inference(noise=noise.cuda(), text_prompts=["x"], kv_cache_manager=KVCacheManager("cuda"),
+                         kv_cache_requests=[KVCacheRequest("r")], decode_mode=DecodeMode.NO_DECODE, renoise=list(eps))
+    torch.cuda.synchronize()
+    ref, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=5.0, num_frame_per_block=3)
+    r = rel_l2(out.cpu(), ref)
+    assert torch.isfinite(out.float()).all() and r < 1e-2, f"14B geometry: rollout rel-L2 {r:.3e}"
