@@ -30,7 +30,9 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(2))) long i64x2;
 
 // ---------------------------------------------------------------------------------------------------------
-template <bool FP8>
+// NCH = ceil(K / 512) chunks of 8 elements per lane: the whole row is loaded ONCE with all its 16-byte loads in flight
+// (NCH <= 18, K <= 9216 — the 8960-wide FFN activations); NCH == 0 is the generic two-pass loop for wider rows.
+template <bool FP8, int NCH>
 __global__ __launch_bounds__(256) void quant_rows_kernel(const unsigned short* __restrict__ x, int ldx,
                                                          unsigned char* __restrict__ q, int ldq,
                                                          float* __restrict__ scale, int rows, int K) {
@@ -38,6 +40,49 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const unsigned short* _
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const unsigned short* xr = x + (size_t)r * ldx;
+  constexpr float QMAX = FP8 ? 448.0f : 127.0f;
+  auto pack = [&](const float (&v)[8]) -> u32x2 {
+    if (FP8) {
+      unsigned w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+      return u32x2{w0, w1};
+    }
+    unsigned w[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i >> 2] |= ((unsigned)(int)rintf(v[i]) & 0xffu) << (8 * (i & 3));
+    return u32x2{w[0], w[1]};
+  };
+  unsigned char* qr = q + (size_t)r * ldq;
+  if constexpr (NCH > 0) {
+    u16x8 u[NCH > 0 ? NCH : 1];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < K) u[c] = *reinterpret_cast<const u16x8*>(xr + col);
+      else u[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(bf2f(u[c][i])));
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / QMAX : 1.0f;
+    if (lane == 0) scale[r] = s;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col >= K) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(bf2f(u[c][i]) / s, -QMAX), QMAX);
+      *reinterpret_cast<u32x2*>(qr + col) = pack(v);
+    }
+    return;
+  }
   float amax = 0.f;
   for (int col = lane * 8; col < K; col += 512) {
     const u16x8 u = *reinterpret_cast<const u16x8*>(xr + col);
@@ -45,30 +90,14 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const unsigned short* _
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(bf2f(u[i])));
   }
   amax = wave_max(amax);
-  constexpr float QMAX = FP8 ? 448.0f : 127.0f;
   const float s = amax > 0.f ? amax / QMAX : 1.0f;
   if (lane == 0) scale[r] = s;
-  unsigned char* qr = q + (size_t)r * ldq;
   for (int col = lane * 8; col < K; col += 512) {
     const u16x8 u = *reinterpret_cast<const u16x8*>(xr + col);
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(bf2f(u[i]) / s, -QMAX), QMAX);
-    u32x2 o;
-    if (FP8) {
-      unsigned w0 = 0, w1 = 0;
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
-      o = u32x2{w0, w1};
-    } else {
-      unsigned w[2] = {0, 0};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) w[i >> 2] |= ((unsigned)(int)rintf(v[i]) & 0xffu) << (8 * (i & 3));
-      o = u32x2{w[0], w[1]};
-    }
-    *reinterpret_cast<u32x2*>(qr + col) = o;
+    *reinterpret_cast<u32x2*>(qr + col) = pack(v);
   }
 }
 
@@ -493,12 +522,23 @@ extern "C" int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int3
   IFX_REQUIRE(format == IFX_Q_FP8_E4M3 || format == IFX_Q_INT8, "ifx_quant_per_token: unknown format %d", format);
   if (rows == 0) return IFX_OK;
   const dim3 grid((rows + 3) / 4), block(256);
-  if (format == IFX_Q_FP8_E4M3)
-    hipLaunchKernelGGL((quant_rows_kernel<true>), grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned char*)q, ldq,
-                       scale, rows, K);
-  else
-    hipLaunchKernelGGL((quant_rows_kernel<false>), grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned char*)q, ldq,
-                       scale, rows, K);
+  const int nch = (K + 511) / 512;
+#define IFX_LAUNCH_QR(NC)                                                                                          \
+  do {                                                                                                             \
+    if (format == IFX_Q_FP8_E4M3)                                                                                  \
+      hipLaunchKernelGGL((quant_rows_kernel<true, NC>), grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned char*)q, \
+                         ldq, scale, rows, K);                                                                     \
+    else                                                                                                           \
+      hipLaunchKernelGGL((quant_rows_kernel<false, NC>), grid, block, 0, (hipStream_t)stream, x, ldx, (unsigned char*)q, \
+                         ldq, scale, rows, K);                                                                     \
+  } while (0)
+  if (nch <= 1) IFX_LAUNCH_QR(1);
+  else if (nch <= 3) IFX_LAUNCH_QR(3);
+  else if (nch <= 6) IFX_LAUNCH_QR(6);
+  else if (nch <= 10) IFX_LAUNCH_QR(10);
+  else if (nch <= 18) IFX_LAUNCH_QR(18);
+  else IFX_LAUNCH_QR(0);
+#undef IFX_LAUNCH_QR
   return check_launch("ifx_quant_per_token");
 }
 
