@@ -102,6 +102,18 @@ int ifx_attn_fwd_paged_split(const ifx_bf16* q, ifx_bf16* out, float* lse, const
                              int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
                              int32_t num_splits, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same split-KV algebra in separate launches that share one workspace: under sequence parallelism the cached
+ * prefix is attended while the collective that delivers the new block's keys is still in flight, then the new keys,
+ * then ONE merge.  ifx_attn_fwd_partial writes the fp32 partials of up to `num_splits` key chunks of
+ * [kv_start, kv_len) into slots [slot_base, slot_base + *slots_used) of a workspace laid out for `slot_cap` slots
+ * (slot_cap * q_rows * heads * 129 floats); ifx_attn_merge_partials combines the first `slots_used` slots into
+ * out (bf16, one rounding) and the optional lse. */
+int ifx_attn_fwd_partial(const ifx_bf16* q, const ifx_kv_view* kv, int32_t q_rows, int32_t heads, int32_t kv_start,
+                         int32_t kv_len, float scale, int32_t num_splits, void* workspace, int64_t workspace_bytes,
+                         int32_t slot_base, int32_t slot_cap, int32_t* slots_used, void* stream);
+int ifx_attn_merge_partials(const void* workspace, int32_t slot_cap, int32_t slots_used, ifx_bf16* out, float* lse,
+                            int32_t q_rows, int32_t heads, void* stream);
+
 /* Merge two partial attention results over disjoint key sets (split-KV / context
  * parallel).  Replaces update_out_and_lse_pass_q
  * (inferix/models/attention/distributed.py:30-48).

@@ -62,6 +62,9 @@ SIGNATURES = {
     "ifx_attn_fwd_paged_split": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
                                            C.c_int64, _vp]),
     "ifx_kv_scatter_shards": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(KvView), _vp]),
+    "ifx_attn_fwd_partial": (C.c_int, [_vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp, C.c_int64, _i32,
+                                       _i32, C.POINTER(_i32), _vp]),
+    "ifx_attn_merge_partials": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "ifx_lse_merge": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ifx_rmsnorm_rope_kv_append": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.POINTER(RopeGrid), C.POINTER(KvView),
                                              _i32, _i32, _i32, _f32, _vp]),

@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
 
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
-                   hipStream_t stream);
+                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr);
+int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsigned short* out, float* lse, int q_rows,
+                      int heads, hipStream_t stream);
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
 int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt);
 // wave groups of the multi-wave kernel for a launch: 3 (384-row tiles) when variant 3 is forced or chosen, else 2
@@ -468,6 +470,32 @@ extern "C" int ifx_attn_fwd_paged_split(const ifx_bf16* q, ifx_bf16* out, float*
   IFX_REQUIRE(num_splits >= 1 && num_splits <= 64, "ifx_attn_fwd_paged_split: num_splits %d outside [1, 64]", num_splits);
   return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, workspace_bytes,
                        stream);
+}
+
+extern "C" int ifx_attn_fwd_partial(const ifx_bf16* q, const ifx_kv_view* kv, int32_t q_rows, int32_t heads,
+                                    int32_t kv_start, int32_t kv_len, float scale, int32_t num_splits, void* workspace,
+                                    int64_t workspace_bytes, int32_t slot_base, int32_t slot_cap, int32_t* slots_used,
+                                    void* stream) {
+  IFX_REQUIRE(q && kv && kv->k && kv->v && workspace, "ifx_attn_fwd_partial: null argument");
+  IFX_REQUIRE(kv->head_dim == HD, "ifx_attn_fwd_partial: head_dim %d not built (128 only)", kv->head_dim);
+  IFX_REQUIRE(heads > 0 && kv->kv_heads > 0 && heads % kv->kv_heads == 0,
+              "ifx_attn_fwd_partial: heads %d is not a multiple of kv_heads %d", heads, kv->kv_heads);
+  IFX_REQUIRE(q_rows > 0 && kv_start >= 0 && kv_len > kv_start && kv_len <= kv->num_slots,
+              "ifx_attn_fwd_partial: key range [%d, %d) out of range (capacity %d)", kv_start, kv_len, kv->num_slots);
+  IFX_REQUIRE(num_splits >= 1 && slot_base >= 0 && slot_cap >= 1 && slot_cap <= 128,
+              "ifx_attn_fwd_partial: bad split / slot arguments (%d splits, base %d, cap %d)", num_splits, slot_base, slot_cap);
+  IFX_REQUIRE(workspace_bytes >= (int64_t)slot_cap * q_rows * heads * 129 * (int64_t)sizeof(float),
+              "ifx_attn_fwd_partial: workspace of %lld B too small for %d slots", (long long)workspace_bytes, slot_cap);
+  if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_partial: page_size must be > 0");
+  return launch_attn_pp(q, nullptr, nullptr, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, 2,
+                        (hipStream_t)stream, slot_base, slot_cap, slots_used);
+}
+
+extern "C" int ifx_attn_merge_partials(const void* workspace, int32_t slot_cap, int32_t slots_used, ifx_bf16* out,
+                                       float* lse, int32_t q_rows, int32_t heads, void* stream) {
+  IFX_REQUIRE(workspace && out && q_rows > 0 && heads > 0 && slots_used >= 1 && slots_used <= slot_cap,
+              "ifx_attn_merge_partials: bad arguments (%d of %d slots)", slots_used, slot_cap);
+  return launch_attn_merge((const float*)workspace, slot_cap, slots_used, out, lse, q_rows, heads, (hipStream_t)stream);
 }
 
 extern "C" int ifx_lse_merge(ifx_bf16* out_a, float* lse_a, const ifx_bf16* out_b, const float* lse_b,

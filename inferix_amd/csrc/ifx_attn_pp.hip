@@ -633,10 +633,13 @@ static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid,
   }
 }
 
-// groups: 2 = ping-pong (256 query rows per workgroup), 3 = three-phase (384 rows)
+// groups: 2 = ping-pong (256 query rows per workgroup), 3 = three-phase (384 rows).
+// slot_cap == 0: self-contained launch (partials in slots [0, splits) of `workspace`, merged here when splits > 1).
+// slot_cap  > 0: PARTIAL launch for a workspace laid out for slot_cap slots: always writes fp32 partials, into slots
+//                [slot_base, slot_base + splits), no merge; *slots_used reports how many chunks were written.
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
-                   hipStream_t stream) {
+                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr) {
   using namespace pp;
   const int QT = 128 * groups;
   AttnArgsPP a;
@@ -658,25 +661,44 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   splits = max(1, min(splits, nt));
   a.chunk_tiles = (nt + splits - 1) / splits;
   a.splits = (nt + a.chunk_tiles - 1) / a.chunk_tiles;   // no empty chunk
-  a.part_o = (float*)workspace;
-  a.part_lse = a.part_o ? a.part_o + (size_t)a.splits * q_rows * heads * 128 : nullptr;
+  const bool partial = slot_cap > 0;
+  if (partial && slot_base + a.splits > slot_cap) {
+    set_error("ifx_attn_fwd_partial: slots [%d, %d) exceed the workspace's %d", slot_base, slot_base + a.splits, slot_cap);
+    return IFX_EINVAL;
+  }
+  const int cap = partial ? slot_cap : a.splits;
+  float* ws = (float*)workspace;
+  a.part_o = ws ? ws + (size_t)slot_base * q_rows * heads * 128 : nullptr;
+  a.part_lse = ws ? ws + (size_t)cap * q_rows * heads * 128 + (size_t)slot_base * heads * q_rows : nullptr;
   a.total = a.q_tiles * heads * a.splits;
   a.per_xcd = (a.total + 7) / 8;
   a.scale = scale > 0.f ? scale : 0.08838834764831845f;
   a.scale_log2 = a.scale * 1.4426950408889634f;
   const dim3 grid(a.per_xcd * 8);
-  if (a.splits > 1 && workspace == nullptr) {
-    set_error("ifx_attn_fwd_paged_split: splits > 1 needs a workspace");
+  const bool write_partials = partial || a.splits > 1;
+  if (write_partials && workspace == nullptr) {
+    set_error("ifx_attn_fwd_paged_split: split / partial launches need a workspace");
     return IFX_EINVAL;
   }
-  if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, a.splits > 1, grid, stream);
-  else launch_pp_ng<2>(a, kv->page_table != nullptr, a.splits > 1, grid, stream);
-  if (a.splits > 1) {
+  if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, write_partials, grid, stream);
+  else launch_pp_ng<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
+  if (slots_used) *slots_used = a.splits;
+  if (!partial && a.splits > 1) {
     const int pairs = q_rows * heads;
     hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, a.part_o, a.part_lse, out,
                        lse, q_rows, heads, a.splits);
   }
   return check_launch("ifx_attn_fwd_paged(pp)");
+}
+
+int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsigned short* out, float* lse, int q_rows,
+                      int heads, hipStream_t stream) {
+  const float* part_o = workspace;
+  const float* part_lse = workspace + (size_t)slot_cap * q_rows * heads * 128;
+  const int pairs = q_rows * heads;
+  hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, part_o, part_lse, out, lse,
+                     q_rows, heads, slots_used);
+  return check_launch("ifx_attn_merge_partials");
 }
 
 }  // namespace ifx

@@ -235,6 +235,45 @@ def attention(q: torch.Tensor, kv: KvCacheView, kv_len: int, scale: float = 0.0,
     return (out, lse) if return_lse else out
 
 
+def attention_split_plan(rows: int, heads: int, nkeys: int) -> int:
+    """Key-chunk count `ifx_attn_split_plan` recommends for this launch shape (1 = do not split)."""
+    plan = _SPLIT_PLAN.get((rows, heads, nkeys))
+    if plan is None:
+        need = C.c_int64(0)
+        plan = (int(_hip.load().ifx_attn_split_plan(rows, heads, 0, int(nkeys), C.byref(need))), int(need.value))
+        _SPLIT_PLAN[(rows, heads, nkeys)] = plan
+    return plan[0]
+
+
+def attention_partial(q: torch.Tensor, kv: KvCacheView, kv_len: int, kv_start: int, splits: int, workspace: torch.Tensor,
+                      slot_base: int, slot_cap: int, scale: float = 0.0, tag: str = "attn") -> int:
+    """fp32 partials of the key chunks of [kv_start, kv_len) into `workspace` slots from `slot_base`; returns the number
+    of slots written.  Finish with `attention_merge`."""
+    rows, heads, hd = q.shape
+    ks = kv.struct()
+    used = C.c_int32(0)
+    nk = kv_len - kv_start
+    with _timed(tag, 4.0 * rows * nk * heads * hd, 2.0 * (2 * rows * heads * hd + 2 * nk * heads * hd)):
+        _hip.check(_hip.load().ifx_attn_fwd_partial(_dev(q, "q"), C.byref(ks), rows, heads, int(kv_start), int(kv_len),
+                                                    float(scale), int(splits), workspace.data_ptr(), workspace.numel() * 4,
+                                                    int(slot_base), int(slot_cap), C.byref(used), _stream()),
+                   "ifx_attn_fwd_partial")
+    return int(used.value)
+
+
+def attention_merge(workspace: torch.Tensor, slot_cap: int, slots_used: int, out: torch.Tensor,
+                    lse: Optional[torch.Tensor] = None) -> None:
+    rows, heads, _ = out.shape
+    _hip.check(_hip.load().ifx_attn_merge_partials(workspace.data_ptr(), int(slot_cap), int(slots_used), _dev(out, "out"),
+                                                   _dev(lse, "lse", torch.float32) if lse is not None else None, rows, heads,
+                                                   _stream()), "ifx_attn_merge_partials")
+
+
+def attention_workspace(q: torch.Tensor, slot_cap: int) -> torch.Tensor:
+    rows, heads, hd = q.shape
+    return _attn_workspace(q.device, slot_cap * rows * heads * (hd + 1) * 4)
+
+
 def kv_scatter_shards(gathered: torch.Tensor, world: int, frames: int, hw_local: int, frame_tokens: int,
                       local_start: int, kv: KvCacheView) -> None:
     """All-gathered `[world, 2, frames*hw_local, heads, 128]` K/V rows -> cache slots in the (frame, hw) token order."""

@@ -167,13 +167,16 @@ class HipSequenceParallel:
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
                 exchange()
-            # main stream: attend to the old prefix while the collective is in flight
-            o1, l1 = ops.attention(qv, view, step.local_start, out=av, return_lse=True, tag="attn_self")
+            # main stream: attend to the old prefix while the collective is in flight; both launches write fp32 partials
+            # into one workspace and a single merge rounds to bf16 once
+            s1 = ops.attention_split_plan(n_local, H, step.local_start)
+            s2 = ops.attention_split_plan(n_local, H, step.local_end - step.local_start)
+            cap = s1 + s2
+            ws = ops.attention_workspace(qv, cap)
+            u1 = ops.attention_partial(qv, view, step.local_start, 0, s1, ws, 0, cap, tag="attn_self")
             main.wait_stream(self.comm_stream)
-            o2 = self._scratch("o2", (n_local, H, hd), torch.bfloat16, dev)
-            _, l2 = ops.attention(qv, view, step.local_end, out=o2, return_lse=True, tag="attn_self",
-                                  kv_start=step.local_start)
-            ops.lse_merge(av, l1, o2, l2)
+            u2 = ops.attention_partial(qv, view, step.local_end, step.local_start, s2, ws, u1, cap, tag="attn_self")
+            ops.attention_merge(ws, cap, u1 + u2, av)
         else:
             exchange()
             ops.attention(qv, view, step.local_end, out=av, tag="attn_self")

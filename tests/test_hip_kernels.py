@@ -213,6 +213,32 @@ def test_attention_split_plan_and_workspace_errors(ops):
     assert rc != 0
 
 
+def test_attention_partial_launches_share_one_merge(ops):
+    """Sequence-parallel form: prefix and new-block keys attended in separate launches that write fp32 partials into one
+    workspace, merged once — equals the single launch over all keys."""
+    g = torch.Generator().manual_seed(41)
+    rows, heads, L, cut = 585, 12, 4680 + 1560 * 3, 4680
+    q, k, v = rnd(g, rows, heads, 128), rnd(g, L, heads, 128), rnd(g, L, heads, 128)
+    qg, view = gpu(q), ops.KvCacheView(gpu(k), gpu(v))
+    full, lse = ops.attention(qg, view, L, return_lse=True, splits=1)
+    s1, s2 = ops.attention_split_plan(rows, heads, cut), ops.attention_split_plan(rows, heads, L - cut)
+    cap = s1 + s2
+    ws = ops.attention_workspace(qg, cap)
+    u1 = ops.attention_partial(qg, view, cut, 0, s1, ws, 0, cap)
+    u2 = ops.attention_partial(qg, view, L, cut, s2, ws, u1, cap)
+    assert 1 <= u1 <= s1 and 1 <= u2 <= s2
+    out = torch.empty_like(qg)
+    l2 = torch.empty(heads, rows, dtype=torch.float32, device="cuda")
+    ops.attention_merge(ws, cap, u1 + u2, out, l2)
+    # two groupings of the same keys differ by the bf16 rounding noise of P itself (diffuse softmax, |o| ~ 0.02)
+    assert rel_l2(out.cpu(), full.cpu()) < 5e-3 and (l2 - lse).abs().max().item() < 1e-3
+    ref64 = O.attention(q[:64][None], k[None], v[None], impl="math")[0]
+    assert (out[:64].cpu().double() - ref64).abs().max().item() < 1.5e-2
+    from inferix_amd import _hip
+    with pytest.raises(_hip.HipKernelError):
+        ops.attention_partial(qg, view, L, cut, s2, ws, cap, cap)            # slots beyond the workspace
+
+
 def test_attention_480p_block_shapes(ops):
     """Real tile geometry: 4680 queries x 12 heads over 1 and 2 cached blocks (CPU fp64 reference on a
     row subset keeps this in seconds)."""
