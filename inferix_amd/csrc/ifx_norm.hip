@@ -164,6 +164,20 @@ __device__ __forceinline__ void rope4(float (&t)[8], int jp0, const RopeArgs& ra
   }
 }
 
+// rotation with the four (cos, sin) pairs of this lane already in registers: a lane's 8 channels sit at the same
+// offset inside their head in every 512-channel chunk (512 % head_dim == 0), and q and k use the same positions, so
+// one set of table reads serves the whole token (was re-read per chunk and per q / k: 24 loads instead of 4)
+__device__ __forceinline__ void rope4_cs(float (&t)[8], const double2 (&cs)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const double a = (double)t[2 * p], b = (double)t[2 * p + 1];
+    const double re = __dmul_rn(a, cs[p].x) - __dmul_rn(b, cs[p].y);
+    const double im = __dmul_rn(a, cs[p].y) + __dmul_rn(b, cs[p].x);
+    t[2 * p] = (float)re;
+    t[2 * p + 1] = (float)im;
+  }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
     const unsigned short* __restrict__ qkv, int ld, unsigned short* __restrict__ q_out,
@@ -187,11 +201,35 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
   }
   size_t slot_off = 0;
   if (kc != nullptr) slot_off = (size_t)ka.slot(local_start + r) * dim;
+  const bool shared_cs = has_rope && (512 % head_dim) == 0;
+  double2 cs4[4];
+  if (shared_cs) {
+    const int jp0 = ((lane * 8) % head_dim) >> 1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int j = jp0 + p;
+      const int pos = (j < n_t) ? pos_t : ((j < n_t + n_h) ? pos_h : pos_w);
+      cs4[p] = *reinterpret_cast<const double2*>(ra.freqs + ((size_t)pos * half + j) * 2);
+    }
+  }
 
+  // all three rows of the token are requested up front (q, k and the raw v chunks): the kernel is a chain of
+  // load -> wave reduction -> dependent table / weight loads -> store per row, and one wave per token cannot hide
+  // three such chains back to back
+  Row<NCH> rowq, rowk;
+  u16x8 vraw[NCH];
+  rowq.load(base, dim, lane);
+  if (kc != nullptr) {
+    rowk.load(base + dim, dim, lane);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < dim) vraw[c] = *reinterpret_cast<const u16x8*>(base + 2 * dim + col);
+    }
+  }
   // ---- q ----
   {
-    Row<NCH> row;
-    row.load(base, dim, lane);
+    Row<NCH>& row = rowq;
     const float rs = 1.0f / sqrtf(wave_sum(row.sumsq()) / (float)dim + eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -201,7 +239,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
       float t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = rbf(rbf(row.v[c][i] * rs) * bf2f(wv[i]));
-      if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
+      if (shared_cs) rope4_cs(t, cs4);
+      else if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
       u16x8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i]);
@@ -211,8 +250,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
   if (kc == nullptr) return;
   // ---- k ----
   {
-    Row<NCH> row;
-    row.load(base + dim, dim, lane);
+    Row<NCH>& row = rowk;
     const float rs = 1.0f / sqrtf(wave_sum(row.sumsq()) / (float)dim + eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -222,7 +260,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
       float t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = rbf(rbf(row.v[c][i] * rs) * bf2f(wv[i]));
-      if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
+      if (shared_cs) rope4_cs(t, cs4);
+      else if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
       u16x8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i]);
@@ -234,7 +273,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
     if (col >= dim) continue;
-    *reinterpret_cast<u16x8*>(vc + slot_off + col) = *reinterpret_cast<const u16x8*>(base + 2 * dim + col);
+    *reinterpret_cast<u16x8*>(vc + slot_off + col) = vraw[c];
   }
 }
 
