@@ -64,6 +64,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   if (r >= rows) return;
   Row<NCH> row;
   row.load(x + (size_t)r * dim, dim, lane);
+  // the per-channel vectors of the epilogue are requested together with the row (they do not depend on the statistics):
+  // a wave is one chain load -> two wave reductions -> store, and these loads used to sit behind the reductions
+  u16x8 pa[NCH], pb[NCH];
+  {
+    const unsigned short* pa_p = nullptr;
+    const unsigned short* pb_p = nullptr;
+    if (mode == IFX_LN_MODULATE) {
+      const size_t g0 = (size_t)(r / rows_per_group) * mod_slots;
+      pa_p = mod + (g0 + scale_slot) * dim;
+      pb_p = mod + (g0 + shift_slot) * dim;
+    } else if (mode == IFX_LN_AFFINE) {
+      pa_p = gamma;
+      pb_p = beta;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (pa_p != nullptr && col < dim) {
+        pa[c] = *reinterpret_cast<const u16x8*>(pa_p + col);
+        pb[c] = *reinterpret_cast<const u16x8*>(pb_p + col);
+      } else {
+        pa[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        pb[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
   const float inv_n = 1.0f / (float)dim;
   const float mean = wave_sum(row.sum()) * inv_n;
   float ss = 0.f;
@@ -80,21 +106,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   const float var = wave_sum(ss) * inv_n;
   const float rstd = 1.0f / sqrtf(var + eps);
 
-  const unsigned short* shift_p = nullptr;
-  const unsigned short* scale_p = nullptr;
-  if (mode == IFX_LN_MODULATE) {
-    const size_t g = (size_t)(r / rows_per_group) * mod_slots;
-    shift_p = mod + (g + shift_slot) * dim;
-    scale_p = mod + (g + scale_slot) * dim;
-  }
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
     if (col >= dim) continue;
     u16x8 o;
     if (mode == IFX_LN_MODULATE) {
-      u16x8 sc = *reinterpret_cast<const u16x8*>(scale_p + col);
-      u16x8 sh = *reinterpret_cast<const u16x8*>(shift_p + col);
+      const u16x8 sc = pa[c], sh = pb[c];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float t = rbf((row.v[c][i] - mean) * rstd);   // norm output is a bf16 tensor
@@ -103,8 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
         o[i] = f2bf(t + bf2f(sh[i]));
       }
     } else if (mode == IFX_LN_AFFINE) {
-      u16x8 g = *reinterpret_cast<const u16x8*>(gamma + col);
-      u16x8 b = *reinterpret_cast<const u16x8*>(beta + col);
+      const u16x8 g = pa[c], b = pb[c];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         o[i] = f2bf((row.v[c][i] - mean) * rstd * bf2f(g[i]) + bf2f(b[i]));
