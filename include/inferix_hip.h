@@ -242,6 +242,51 @@ int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t evicted, int
 int ifx_kv_scatter_shards(const ifx_bf16* gathered, int32_t world, int32_t frames, int32_t hw_local,
                           int32_t frame_tokens, int32_t local_start, const ifx_kv_view* kv, void* stream);
 
+/* ----------------------------------------------------------------------
+ * VAE decoder: channels-last causal 3-D convolution.
+ * Replaces CausalConv3d.forward + the feature-cache concatenation around it
+ * (inferix/models/wan_base/vae.py:26-34, 207-216), the nearest-2x Upsample +
+ * Conv2d of Resample (vae.py:58-64, 83-90, 139-141) and the residual add of
+ * ResidualBlock.forward (vae.py:219).
+ *   x          frames [slot][hs][ws][cin] bf16; logical input frame f (0 .. t_out+kt-2: for kt = 3 the two
+ *              history frames, then the new ones) lives at x + in_slots[f] * in_frame_stride; in_slots[f] < 0
+ *              = an all-zero frame (the causal padding in front of the stream)
+ *   upsample   1: the 3x3 taps read the nearest-2x upsampled frame (output 2hs x 2ws), never materialised
+ *   w          [kt*ks*ks][cout][cin] bf16 (tap-major repack of the torch [cout][cin][kt][ks][ks] weight)
+ *   y          output frame t at y + out_slots[t] * out_frame_stride, [ho][wo][cout]
+ *   residual   NULL or contiguous [t_out][ho][wo][cout]: y = bf16(bf16(conv + bias) + residual)
+ *   zero_page  >= 64 bytes of zeros in device memory
+ * in_slots / out_slots are HOST arrays (copied into the launch).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const ifx_bf16* x;
+  int64_t in_frame_stride;      /* elements */
+  const int32_t* in_slots;
+  int32_t hs, ws, cin, upsample;
+  const ifx_bf16* w;
+  const ifx_bf16* bias;         /* [cout] or NULL */
+  int32_t kt, ks;               /* temporal 1|3, spatial 1|3 */
+  ifx_bf16* y;
+  int64_t out_frame_stride;     /* elements */
+  const int32_t* out_slots;
+  int32_t cout, t_out;
+  const ifx_bf16* residual;
+  const void* zero_page;
+} ifx_conv3d_desc;
+int ifx_conv3d_cl(const ifx_conv3d_desc* desc, void* stream);
+
+/* Per-pixel channel RMS norm (+ SiLU) of channels-last frames x [frames][frame_pixels][channels], with the bf16 op
+ * chain of RMS_norm.forward (vae.py:52-55) and nn.SiLU; frame f is written to y + out_slots[f] * out_frame_stride
+ * (the ring buffer that holds the next conv's input and its two-frame history).  out_slots is a HOST array. */
+int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16* y, int64_t out_frame_stride,
+                   const int32_t* out_slots, int32_t frames, int32_t frame_pixels, int32_t channels,
+                   int32_t silu, void* stream);
+
+/* probs = softmax(scores * scale) row-wise, bf16 [rows][ld] (single-head attention of the VAE middle block,
+ * vae.py:250-254, between the two ifx_gemm_bf16 launches that form QK^T and PV). */
+int ifx_softmax_rows(const ifx_bf16* scores, ifx_bf16* probs, int32_t rows, int32_t cols, int32_t ld, float scale,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,15 @@ class RopeGrid(C.Structure):
                 ("hw_local", C.c_int32)]
 
 
+class Conv3dDesc(C.Structure):
+    """ifx_conv3d_desc"""
+    _fields_ = [("x", C.c_void_p), ("in_frame_stride", C.c_int64), ("in_slots", C.POINTER(C.c_int32)),
+                ("hs", C.c_int32), ("ws", C.c_int32), ("cin", C.c_int32), ("upsample", C.c_int32),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("kt", C.c_int32), ("ks", C.c_int32),
+                ("y", C.c_void_p), ("out_frame_stride", C.c_int64), ("out_slots", C.POINTER(C.c_int32)),
+                ("cout", C.c_int32), ("t_out", C.c_int32), ("residual", C.c_void_p), ("zero_page", C.c_void_p)]
+
+
 class Epilogue(C.Structure):
     """ifx_epilogue"""
     _fields_ = [("epilogue", C.c_int32), ("residual", C.c_void_p), ("ld_res", C.c_int32),
@@ -61,6 +70,9 @@ SIGNATURES = {
     "ifx_attn_split_plan": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int64)]),
     "ifx_attn_fwd_paged_split": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
                                            C.c_int64, _vp]),
+    "ifx_conv3d_cl": (C.c_int, [C.POINTER(Conv3dDesc), _vp]),
+    "ifx_rmsnorm_cl": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),
+    "ifx_softmax_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ifx_kv_scatter_shards": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(KvView), _vp]),
     "ifx_attn_fwd_partial": (C.c_int, [_vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp, C.c_int64, _i32,
                                        _i32, C.POINTER(_i32), _vp]),

@@ -1,0 +1,456 @@
+// Channels-last causal 3-D convolution for the Wan VAE decoder, gfx950 only.
+//
+// Replaces `CausalConv3d.forward` (inferix/models/wan_base/vae.py:26-34) + the feature-cache concatenation around it
+// (vae.py:207-216), `Upsample` + `Conv2d` of `Resample` (vae.py:58-64, 83-90, 139-141) and the residual add of
+// `ResidualBlock.forward` (vae.py:219).
+//
+// Design (LDS-tiled direct convolution on the matrix cores, not an im2col GEMM):
+//   * activations are [frame][h][w][C] bf16; a workgroup (8 waves) owns an 8 x 64 pixel tile of ONE output frame and BN
+//     output channels; wave w computes image row w of the tile (two 32-pixel MFMA blocks) for all BN channels.
+//   * the K loop runs over stages (input frame dt, 32-channel chunk cc).  Per stage the (8+2) x (64+2) pixel halo patch of
+//     that frame / chunk is DMA'd into LDS once (`global_load_lds`, 64 B per pixel, zero page for padding pixels and for
+//     the all-zero frames in front of the stream) and ALL nine spatial taps read their A fragments from it at a per-tap
+//     offset — 3.9 patch loads per output pixel-chunk instead of the 27 an implicit GEMM gathers.  The nearest-2x
+//     upsample in front of the `Resample` conv2d is folded into the fragment address (source pixel = (o + d - 1) >> 1),
+//     so the 4x larger upsampled tensor never exists.
+//   * weights [tap][Cout][Cin] stream through a ring of 8 KiB slots (one tap x 32 channels x 128 rows), D steps ahead.
+//   * both DMA streams share the wave's vmcnt; the wait before step k allows exactly the instructions issued after
+//     weights(k): min(D-1, total-1-k) weight pieces + the patch pieces of the next stage issued in the last D-1 steps.
+//   * epilogue: bias, bf16 rounding, optional residual add (second rounding, as `x + h` in bf16 upstream), stores into
+//     caller-chosen frame slots (ring buffers of the next conv, or the even/odd frames of the temporal upsampler).
+#include "ifx_common.h"
+
+namespace ifx {
+namespace conv {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+constexpr int TH = 8, TW = 64;          // output tile (pixels)
+constexpr int MAXF = 16;                // frames per call (inputs incl. history / outputs)
+constexpr int W_SLOT = 128 * 64;        // weight ring slot: 128 rows x 32 channels
+
+struct ConvArgs {
+  const unsigned short* x;
+  const unsigned short* w;
+  const unsigned short* bias;
+  const unsigned short* res;
+  const unsigned short* zero;
+  unsigned short* y;
+  long long in_frame_stride, out_frame_stride;
+  int in_slot[MAXF], out_slot[MAXF];
+  int Hs, Ws, Cin, Ho, Wo, Cout, KT, t_out;
+  int tiles_w, tiles_h, tiles_n, per_xcd, total;
+};
+
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+template <int UPS, int KS>
+struct Geo {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int PH = UPS ? TH / 2 + 2 : TH + KS - 1;
+  static constexpr int PW = UPS ? TW / 2 + 2 : TW + KS - 1;
+  static constexpr int NP = PH * PW;                    // patch pixels
+  static constexpr int NPI = (NP + 15) / 16;            // 1 KiB DMA instructions per patch
+  static constexpr int PPW = (NPI + 7) / 8;             // per wave
+  static constexpr int P_SLOT = NPI * 1024;
+  static constexpr int WR = TAPS == 9 ? 6 : 2;          // weight ring depth
+  static constexpr int D = WR - 1;                      // steps of weight lookahead
+  static constexpr int NPT = TAPS == 9 ? (PPW + 1) / 2 : 1;   // steps of a stage that carry patch pieces of the next stage
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WR * W_SLOT, LDS = S_OFF + 8 * 1024;
+  static_assert(TAPS == 1 || D <= TAPS - NPT, "weight lookahead must not overtake the patch of its own stage");
+  // patch pieces issued at tap `t` of a stage (for the next stage)
+  static constexpr int cnt(int t) { return TAPS == 1 ? (t == 0 ? PPW : 0) : (t < 0 || t >= NPT ? 0 : (PPW - 2 * t >= 2 ? 2 : PPW - 2 * t)); }
+  // patch pieces issued in the D-1 steps before tap `t` of the same stage
+  static constexpr int psum(int t) {
+    int s = 0;
+    for (int d = 1; d <= D - 1; ++d) s += cnt(t - d);
+    return s;
+  }
+};
+
+template <int BN, int UPS, int KS>
+__global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
+  using G = Geo<UPS, KS>;
+  constexpr int TAPS = G::TAPS, PW = G::PW, PPW = G::PPW, D = G::D, WR = G::WR;
+  constexpr int TI = BN / 32, TJ = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int t_id = xcd * A.per_xcd + slot_i;
+  if (slot_i >= A.per_xcd || t_id >= A.total) return;
+  // work order: channel tile fastest (the workgroups that read the same halo patch sit on one XCD's L2)
+  int rem = t_id;
+  const int nt = rem % A.tiles_n;
+  rem /= A.tiles_n;
+  const int tw = rem % A.tiles_w;
+  rem /= A.tiles_w;
+  const int th = rem % A.tiles_h;
+  const int to = rem / A.tiles_h;
+  const int h0 = th * TH, w0 = tw * TW, n_base = nt * BN;
+
+  // ---- patch DMA sources: piece p = wave + 8 r covers patch pixels [16 p, 16 p + 16) x 4 chunks of 16 B
+  const int ph0 = UPS ? h0 / 2 - 1 : h0 - KS / 2, pw0 = UPS ? w0 / 2 - 1 : w0 - KS / 2;
+  int poff[PPW];
+#pragma unroll
+  for (int r = 0; r < PPW; ++r) {
+    const int p = wave + 8 * r;
+    const int px = p * 16 + (lane >> 2);
+    const int pr = px / PW, pc = px - pr * PW;
+    const int sh = ph0 + pr, sw = pw0 + pc;
+    const bool ok = p < G::NPI && px < G::NP && sh >= 0 && sh < A.Hs && sw >= 0 && sw < A.Ws;
+    poff[r] = ok ? (sh * A.Ws + sw) * A.Cin + (((lane & 3) ^ ((px >> 2) & 3)) << 3) : -1;
+  }
+  const int CC = A.Cin >> 5;
+  const int S = A.KT * CC, total = S * TAPS;
+  auto issue_patch = [&](int s, int r) {            // piece r of this wave for stage s
+    const int dt = s / CC, cc = s - dt * CC;
+    const int f = A.in_slot[to + dt];
+    const unsigned short* base = A.x + (long long)f * A.in_frame_stride + cc * 32;
+    const int p = wave + 8 * r;
+    const unsigned short* src = (poff[r] < 0 || f < 0) ? A.zero : base + poff[r];
+    unsigned char* dst = p < G::NPI ? smem + G::P_OFF + (s & 1) * G::P_SLOT + p * 1024 : smem + G::S_OFF + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+  };
+  // ---- weight DMA: one 1 KiB piece per wave per step = rows [16 wave, 16 wave + 16) of the 128-row slot
+  const int wrow = wave * 16 + (lane >> 2);
+  const int woff = min(n_base + wrow, A.Cout - 1) * A.Cin + (((lane & 3) ^ ((wrow >> 2) & 3)) << 3);
+  auto issue_w = [&](int k) {
+    const int s = k / TAPS, tap = k - s * TAPS;
+    const int dt = s / CC, cc = s - dt * CC;
+    const unsigned short* src = A.w + (size_t)(dt * TAPS + tap) * A.Cout * A.Cin + cc * 32 + woff;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + G::W_OFF + (k % WR) * W_SLOT + wave * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: patch of stage 0, weights of steps 0 .. D-1
+#pragma unroll
+  for (int r = 0; r < PPW; ++r) issue_patch(0, r);
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    if (k < total) issue_w(k);
+
+  int b_off[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int n = i * 32 + l31;
+    b_off[i] = n * 64 + (((n >> 2) & 3) << 4);        // row base with the swizzle phase folded in as an XOR operand below
+  }
+
+  for (int s = 0; s < S; ++s) {
+    const bool has_next = s + 1 < S;
+    const unsigned char* pb = smem + G::P_OFF + (s & 1) * G::P_SLOT;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int k = s * TAPS + tap;
+      wait_vm(min(D - 1, total - 1 - k) + (has_next ? G::psum(tap) : 0));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of step k-1 retired
+      __builtin_amdgcn_s_barrier();
+      if (has_next) {
+        if (TAPS == 1) {
+#pragma unroll
+          for (int r = 0; r < PPW; ++r) issue_patch(s + 1, r);
+        } else if (tap < G::NPT) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (2 * tap + q < PPW) issue_patch(s + 1, 2 * tap + q);
+        }
+      }
+      if (k + D < total) issue_w(k + D);
+
+      const int dh = tap / KS, dw = tap - dh * KS;
+      const unsigned char* wb = smem + G::W_OFF + (k % WR) * W_SLOT;
+      bf16x8 fa[2][TJ], fb[2][TI];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        int prow;
+        if (UPS) prow = ((wave + dh + 1) >> 1) * PW + ((j * 32 + l31 + dw + 1) >> 1);
+        else prow = (wave + dh) * PW + (j * 32 + l31 + dw);
+        const int sw = (prow >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fa[ks][j] = *reinterpret_cast<const bf16x8*>(pb + prow * 64 + (((2 * ks + hi) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fb[ks][i] = *reinterpret_cast<const bf16x8*>(wb + (b_off[i] ^ ((2 * ks + hi) << 4)));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane (l31, hi) holds, for pixel l31 of block j, channels i*32 + g*8 + hi*4 + e
+  const int oh = h0 + wave;
+  if (oh >= A.Ho) return;
+  unsigned short* yf = A.y + (long long)A.out_slot[to] * A.out_frame_stride;
+  const unsigned short* rf = A.res ? A.res + (long long)to * A.Ho * A.Wo * A.Cout : nullptr;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int ow = w0 + j * 32 + l31;
+    if (ow >= A.Wo) continue;
+    const size_t pix = ((size_t)oh * A.Wo + ow) * A.Cout;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n_base + i * 32 + g * 8 + hi * 4;
+        if (n >= A.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+        if (n + 3 < A.Cout) {
+          if (A.bias) {
+            const u16x4 bv = *reinterpret_cast<const u16x4*>(A.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+          }
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          if (rf) {
+            const u16x4 rv = *reinterpret_cast<const u16x4*>(rf + pix + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(o[e]) + bf2f(rv[e]));
+          }
+          *reinterpret_cast<u16x4*>(yf + pix + n) = o;
+        } else {
+          for (int e = 0; e < 4 && n + e < A.Cout; ++e) {
+            float t = v[e] + (A.bias ? bf2f(A.bias[n + e]) : 0.f);
+            unsigned short o = f2bf(t);
+            if (rf) o = f2bf(bf2f(o) + bf2f(rf[pix + n + e]));
+            yf[pix + n + e] = o;
+          }
+        }
+      }
+  }
+}
+
+template <int BN, int UPS, int KS>
+static void launch(const ConvArgs& a, hipStream_t s) {
+  using G = Geo<UPS, KS>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_cl_kernel<BN, UPS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_cl_kernel<BN, UPS, KS>), dim3(a.per_xcd * 8), dim3(512), G::LDS, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-pixel channel RMS norm (+ SiLU) on channels-last frames, written into caller-chosen frame slots.
+// Follows the bf16 op chain of `RMS_norm.forward` (vae.py:52-55) + `nn.SiLU`: n = bf16(||x||), y = bf16(x / max(n, eps)),
+// y = bf16(y * sqrt(C)), y = bf16(y * gamma), y = bf16(silu(y)).  G lanes (a power of two >= C / 8) share one pixel.
+struct NormArgs {
+  const unsigned short* x;
+  const unsigned short* gamma;
+  unsigned short* y;
+  long long out_frame_stride;
+  int out_slot[MAXF];
+  int frame_pixels, C, silu;
+  long long pixels;
+  float scale;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void rmsnorm_cl_kernel(NormArgs A) {
+  const int lane_in = threadIdx.x % G;
+  const long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) / G;
+  const bool act = pix < A.pixels && lane_in * 8 < A.C;
+  u16x8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (act) xv = *reinterpret_cast<const u16x8*>(A.x + pix * A.C + lane_in * 8);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = bf2f(xv[e]);
+    ss += f * f;
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (!act) return;
+  const float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
+  const u16x8 gv = *reinterpret_cast<const u16x8*>(A.gamma + lane_in * 8);
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = rbf(bf2f(xv[e]) / n);
+    v = rbf(v * A.scale);
+    v = rbf(v * bf2f(gv[e]));
+    if (A.silu) v = v / (1.f + __expf(-v));
+    o[e] = f2bf(v);
+  }
+  const long long f = pix / A.frame_pixels, pp = pix - f * A.frame_pixels;
+  *reinterpret_cast<u16x8*>(A.y + (long long)A.out_slot[f] * A.out_frame_stride + pp * A.C + lane_in * 8) = o;
+}
+
+// Row softmax of bf16 scores (single-head spatial attention of the VAE middle block, vae.py:250-254): one wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const unsigned short* __restrict__ s, unsigned short* __restrict__ p,
+                                                           int rows, int cols, int ld, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const unsigned short* sr = s + (size_t)row * ld;
+  unsigned short* pr = p + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const u16x8 v = *reinterpret_cast<const u16x8*>(sr + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c + e < cols) m = fmaxf(m, bf2f(v[e]));
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const u16x8 v = *reinterpret_cast<const u16x8*>(sr + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c + e < cols) sum += __expf((bf2f(v[e]) - m) * scale);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const u16x8 v = *reinterpret_cast<const u16x8*>(sr + c);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = c + e < cols ? f2bf(__expf((bf2f(v[e]) - m) * scale) * inv) : (unsigned short)0;
+    *reinterpret_cast<u16x8*>(pr + c) = o;
+  }
+}
+
+}  // namespace conv
+}  // namespace ifx
+
+using namespace ifx;
+using namespace ifx::conv;
+
+extern "C" int ifx_conv3d_cl(const ifx_conv3d_desc* d, void* stream) {
+  IFX_REQUIRE(d && d->x && d->w && d->y && d->zero_page, "ifx_conv3d_cl: null argument");
+  IFX_REQUIRE(d->kt == 1 || d->kt == 3, "ifx_conv3d_cl: temporal kernel %d not built (1 or 3)", d->kt);
+  IFX_REQUIRE(d->ks == 1 || d->ks == 3, "ifx_conv3d_cl: spatial kernel %d not built (1 or 3)", d->ks);
+  IFX_REQUIRE(d->upsample == 0 || (d->upsample == 1 && d->ks == 3), "ifx_conv3d_cl: upsample needs the 3x3 kernel");
+  IFX_REQUIRE(d->cin > 0 && d->cin % 32 == 0, "ifx_conv3d_cl: cin %d must be a multiple of 32", d->cin);
+  IFX_REQUIRE(d->cout > 0 && (d->cout % 4 == 0 || d->cout < 4), "ifx_conv3d_cl: cout %d must be a multiple of 4 (or < 4)", d->cout);
+  IFX_REQUIRE(d->t_out >= 1 && d->t_out + d->kt - 1 <= MAXF, "ifx_conv3d_cl: %d output frames per call (max %d inputs)",
+              d->t_out, MAXF);
+  IFX_REQUIRE(d->hs > 0 && d->ws > 0, "ifx_conv3d_cl: empty frame");
+  IFX_REQUIRE((long long)d->hs * d->ws * d->cin < (1ll << 31) && (long long)d->hs * d->ws * d->cout * (d->upsample ? 4 : 1) < (1ll << 31),
+              "ifx_conv3d_cl: frame too large for 32-bit pixel offsets");
+  ConvArgs a;
+  a.x = d->x;
+  a.w = d->w;
+  a.bias = d->bias;
+  a.res = d->residual;
+  a.zero = (const unsigned short*)d->zero_page;
+  a.y = d->y;
+  a.in_frame_stride = d->in_frame_stride;
+  a.out_frame_stride = d->out_frame_stride;
+  for (int i = 0; i < MAXF; ++i) {
+    a.in_slot[i] = i < d->t_out + d->kt - 1 ? d->in_slots[i] : -1;
+    a.out_slot[i] = i < d->t_out ? d->out_slots[i] : 0;
+  }
+  a.Hs = d->hs;
+  a.Ws = d->ws;
+  a.Cin = d->cin;
+  a.Ho = d->hs << d->upsample;
+  a.Wo = d->ws << d->upsample;
+  a.Cout = d->cout;
+  a.KT = d->kt;
+  a.t_out = d->t_out;
+  const int bn = d->cout <= 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 96 == 0 ? 96 : (d->cout <= 64 ? 64 : 128)));
+  a.tiles_w = (a.Wo + TW - 1) / TW;
+  a.tiles_h = (a.Ho + TH - 1) / TH;
+  a.tiles_n = (d->cout + bn - 1) / bn;
+  a.total = a.tiles_w * a.tiles_h * a.tiles_n * d->t_out;
+  a.per_xcd = (a.total + 7) / 8;
+  hipStream_t s = (hipStream_t)stream;
+#define IFX_CONV_BN(UPS, KS)                              \
+  switch (bn) {                                           \
+    case 32: launch<32, UPS, KS>(a, s); break;            \
+    case 64: launch<64, UPS, KS>(a, s); break;            \
+    case 96: launch<96, UPS, KS>(a, s); break;            \
+    default: launch<128, UPS, KS>(a, s); break;           \
+  }
+  if (d->ks == 1) {
+    IFX_CONV_BN(0, 1)
+  } else if (d->upsample) {
+    IFX_CONV_BN(1, 3)
+  } else {
+    IFX_CONV_BN(0, 3)
+  }
+#undef IFX_CONV_BN
+  return check_launch("ifx_conv3d_cl");
+}
+
+extern "C" int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16* y, int64_t out_frame_stride,
+                              const int32_t* out_slots, int32_t frames, int32_t frame_pixels, int32_t channels,
+                              int32_t silu, void* stream) {
+  IFX_REQUIRE(x && gamma && y && out_slots, "ifx_rmsnorm_cl: null argument");
+  IFX_REQUIRE(frames >= 1 && frames <= MAXF && frame_pixels > 0, "ifx_rmsnorm_cl: %d frames per call (max %d)", frames, MAXF);
+  IFX_REQUIRE(channels % 8 == 0 && channels >= 8 && channels <= 512, "ifx_rmsnorm_cl: channels %d not in [8, 512] step 8", channels);
+  NormArgs a;
+  a.x = x;
+  a.gamma = gamma;
+  a.y = y;
+  a.out_frame_stride = out_frame_stride;
+  for (int i = 0; i < MAXF; ++i) a.out_slot[i] = i < frames ? out_slots[i] : 0;
+  a.frame_pixels = frame_pixels;
+  a.C = channels;
+  a.silu = silu;
+  a.pixels = (long long)frames * frame_pixels;
+  a.scale = sqrtf((float)channels);
+  const int chunks = channels / 8;
+  hipStream_t s = (hipStream_t)stream;
+#define IFX_NORM_G(GG)                                                                                         \
+  {                                                                                                            \
+    const long long blocks = (a.pixels * GG + 255) / 256;                                                      \
+    hipLaunchKernelGGL((rmsnorm_cl_kernel<GG>), dim3((unsigned)blocks), dim3(256), 0, s, a);                   \
+  }
+  if (chunks <= 1) IFX_NORM_G(1)
+  else if (chunks <= 2) IFX_NORM_G(2)
+  else if (chunks <= 4) IFX_NORM_G(4)
+  else if (chunks <= 8) IFX_NORM_G(8)
+  else if (chunks <= 16) IFX_NORM_G(16)
+  else if (chunks <= 32) IFX_NORM_G(32)
+  else IFX_NORM_G(64)
+#undef IFX_NORM_G
+  return check_launch("ifx_rmsnorm_cl");
+}
+
+extern "C" int ifx_softmax_rows(const ifx_bf16* scores, ifx_bf16* probs, int32_t rows, int32_t cols, int32_t ld, float scale,
+                                void* stream) {
+  IFX_REQUIRE(scores && probs && rows > 0 && cols > 0 && ld >= cols && ld % 8 == 0, "ifx_softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, scores, probs, rows, cols, ld,
+                     scale);
+  return check_launch("ifx_softmax_rows");
+}

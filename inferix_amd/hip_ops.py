@@ -361,3 +361,66 @@ def kv_roll(kv: KvCacheView, sink_tokens: int, evicted: int, rolled: int, scratc
     assert scratch.numel() >= rolled * kv.k.shape[1] * kv.k.shape[2]
     _hip.check(lib.ifx_kv_roll(C.byref(ks), sink_tokens, evicted, rolled, _dev(scratch, "scratch"), _stream()),
                "ifx_kv_roll")
+
+
+# ---- VAE decoder ops (channels-last frames) ----------------------------------------------------------------------
+_ZERO_PAGE = {}
+
+
+def _zero_page(dev: torch.device) -> torch.Tensor:
+    z = _ZERO_PAGE.get(dev)
+    if z is None:
+        z = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.uint8, device=dev)
+    return z
+
+
+def _slots(v) -> "C.Array":
+    return (C.c_int32 * len(v))(*[int(i) for i in v])
+
+
+def conv3d_cl(x: torch.Tensor, in_slots, w: torch.Tensor, bias: Optional[torch.Tensor], *, kt: int, ks: int,
+              y: torch.Tensor, out_slots, upsample: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal conv on channels-last frames (ifx_conv3d_cl).  `x` `[slots, hs, ws, cin]`, logical input frame f at
+    `x[in_slots[f]]` (negative slot = zero frame; `t_out + kt - 1` entries); `w` `[kt*ks*ks, cout, cin]`; output frame t
+    goes to `y[out_slots[t]]` `[ho, wo, cout]`; `residual` `[t_out, ho, wo, cout]`."""
+    t_out = len(out_slots)
+    assert len(in_slots) == t_out + kt - 1, (len(in_slots), t_out, kt)
+    _, hs, ws, cin = x.shape
+    taps, cout, cin_w = w.shape
+    assert taps == kt * ks * ks and cin_w == cin and x.is_contiguous() and y.is_contiguous() and w.is_contiguous()
+    ho, wo = (hs * 2, ws * 2) if upsample else (hs, ws)
+    assert tuple(y.shape[1:]) == (ho, wo, cout), (tuple(y.shape), ho, wo, cout)
+    assert max(out_slots) < y.shape[0] and max(in_slots) < x.shape[0]
+    if residual is not None:
+        assert residual.is_contiguous() and tuple(residual.shape) == (t_out, ho, wo, cout)
+    ins, outs = _slots(in_slots), _slots(out_slots)
+    d = _hip.Conv3dDesc(_dev(x, "x"), hs * ws * cin, ins, hs, ws, cin, 1 if upsample else 0, _dev(w, "w"),
+                        _dev(bias, "bias") if bias is not None else None, kt, ks, _dev(y, "y"), ho * wo * cout, outs, cout,
+                        t_out, _dev(residual, "residual") if residual is not None else None,
+                        _zero_page(x.device).data_ptr())
+    flops = 2.0 * t_out * ho * wo * cout * cin * taps
+    with _timed("conv3d", flops, 0.0):
+        _hip.check(_hip.load().ifx_conv3d_cl(C.byref(d), _stream()), "ifx_conv3d_cl")
+    return y
+
+
+def rmsnorm_cl(x: torch.Tensor, gamma: torch.Tensor, y: torch.Tensor, out_slots, silu: bool) -> torch.Tensor:
+    """Per-pixel channel RMS norm (+ SiLU) of `x` `[frames, h, w, c]` into `y[out_slots[f]]` (ifx_rmsnorm_cl)."""
+    frames, h, w_, c = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and tuple(y.shape[1:]) == (h, w_, c) and len(out_slots) == frames
+    assert gamma.numel() == c and max(out_slots) < y.shape[0]
+    with _timed("rmsnorm_cl", 0.0, 4.0 * x.numel()):
+        _hip.check(_hip.load().ifx_rmsnorm_cl(_dev(x, "x"), _dev(gamma, "gamma"), _dev(y, "y"), h * w_ * c, _slots(out_slots),
+                                              frames, h * w_, c, 1 if silu else 0, _stream()), "ifx_rmsnorm_cl")
+    return y
+
+
+def softmax_rows(scores: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(scores * scale) over the last dim of a 2-D bf16 tensor whose row pitch is a multiple of 8."""
+    rows, cols = scores.shape
+    ld = scores.stride(0)
+    out = torch.empty_like(scores) if out is None else out
+    assert scores.stride(1) == 1 and out.stride() == scores.stride()
+    _hip.check(_hip.load().ifx_softmax_rows(_dev(scores, "scores"), _dev(out, "probs"), rows, cols, ld, float(scale),
+                                            _stream()), "ifx_softmax_rows")
+    return out

@@ -1,0 +1,336 @@
+"""Wan2.1 VAE decoder on MI355X — the per-block decode of the streaming pipelines.
+
+Drop-in for the decode half of `WanVAEWrapper` (inferix/models/self_forcing/wrapper.py:62-168) and the decoder of `WanVAE_`
+(inferix/models/wan_base/vae.py:380-466, 543-611): same state-dict keys, same `decode_to_pixel(latent, use_cache,
+chunk_size)` / `model.clear_cache()` surface, same streaming semantics (two-frame causal feature cache per conv, the 'Rep'
+first-chunk rule of the temporal upsamplers), bf16 like the reference's `model.to(dtype=torch.bfloat16)`.
+
+MI355X-first differences in HOW (not in what is computed):
+  * activations are channels-last frames `[t, h, w, c]`; every conv is `ifx_conv3d_cl` (LDS-tiled direct convolution on MFMA).
+  * the feature cache is not a list of cloned tensors that get concatenated in front of the next chunk (vae.py:207-216):
+    each causal conv owns a frame ring `[2 + T, h, w, c]`; its producer (`ifx_rmsnorm_cl`, or the previous conv's epilogue)
+    writes new frames straight into free slots, the conv reads [two history slots | new slots] through a slot table, and
+    "updating the cache" is relabelling the last two slots.  Nothing is copied, concatenated or padded.
+  * nearest-2x upsample + conv2d is one launch (the upsampled frame is never materialised); the temporal upsampler's channel
+    halves are written directly to the even / odd output frames.
+  * the reference feeds one latent frame per decoder call (vae.py:581-592, sized for 24 GB GPUs); with 288 GB of HBM the
+    frames of a block go through together after the first chunk — the same function of the stream (causal convs commute
+    with chunking; pinned in oracle/gen_golden_vae.py), 3x fewer launches and 3x larger grids.
+  * the single-head 384-wide spatial attention of the middle block is two `ifx_gemm_bf16` launches around `ifx_softmax_rows`.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip
+from . import hip_ops as ops
+
+BF16 = torch.bfloat16
+
+VAE_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+            0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]     # wrapper.py:65-72
+VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+           3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+def _repack_conv(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
+    """torch conv weight `[cout, cin, (kt,) kh, kw]` -> tap-major `[taps, cout, cin]` bf16 (ifx_conv3d_cl layout)."""
+    cout, cin = w.shape[:2]
+    t = w.reshape(cout, cin, -1).permute(2, 0, 1)
+    if cin_pad > cin:
+        t = torch.nn.functional.pad(t, (0, cin_pad - cin))
+    return t.contiguous().to(BF16)
+
+
+class FrameRing:
+    """Input frames of one causal conv: `2 + cap` physical slots; `hist` = slots of the last two frames of the stream
+    (-1 = a zero frame in front of the stream)."""
+
+    def __init__(self, cap: int, h: int, w: int, c: int, device):
+        self.buf = torch.empty(cap + 2, h, w, c, dtype=BF16, device=device)
+        self.cap = cap
+        self.hist = [-1, -1]
+
+    def reset(self) -> None:
+        self.hist = [-1, -1]
+
+    def new_slots(self, t: int) -> List[int]:
+        assert t <= self.cap, f"{t} frames per call, ring built for {self.cap}"
+        free = [s for s in range(self.cap + 2) if s not in self.hist]
+        return free[:t]
+
+    def commit(self, new: Sequence[int]) -> List[int]:
+        """-> in_slots for the conv over `new`; afterwards the history is the last two frames of the stream."""
+        ins = self.hist + list(new)
+        self.hist = ins[-2:]
+        return ins
+
+
+class HipWanVAEDecoder:
+    """`Decoder3d` + `conv2` of `WanVAE_` with the streaming cache (`cached_decode` / `decode` / `clear_cache`)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, dim: int = 96, z_dim: int = 16,
+                 dim_mult: Sequence[int] = (1, 2, 4, 4), num_res_blocks: int = 2,
+                 temperal_downsample: Sequence[bool] = (False, True, True), device="cuda", max_frames_per_call: int = 3):
+        _hip.load()                                         # fail loudly without the HIP library
+        self.device = torch.device(device)
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, tuple(dim_mult)
+        self.num_res_blocks = num_res_blocks
+        self.temperal_upsample = tuple(temperal_downsample[::-1])
+        self.max_frames = max_frames_per_call
+        self.plan = self._plan()
+        self._load(state_dict)
+        self.mean = torch.tensor(VAE_MEAN[:z_dim], dtype=torch.float32, device=self.device)
+        self.std = torch.tensor(VAE_STD[:z_dim], dtype=torch.float32, device=self.device)
+        self._rings: Dict[Tuple[str, int, int], FrameRing] = {}
+        self._scratch: Dict[Tuple, torch.Tensor] = {}
+        self._started = False
+        self._rep: Dict[str, bool] = {}
+
+    # ---- structure (vae.py:381-413) ---------------------------------------------------------------------------------
+    def _plan(self) -> List[tuple]:
+        dims = [self.dim * u for u in [self.dim_mult[-1]] + list(self.dim_mult[::-1])]
+        plan = [("res", "decoder.middle.0", dims[0], dims[0]), ("attn", "decoder.middle.1", dims[0]),
+                ("res", "decoder.middle.2", dims[0], dims[0])]
+        n = 0
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            if i in (1, 2, 3):
+                cin = cin // 2
+            for _ in range(self.num_res_blocks + 1):
+                plan.append(("res", f"decoder.upsamples.{n}", cin, cout))
+                cin = cout
+                n += 1
+            if i != len(self.dim_mult) - 1:
+                plan.append(("up3d" if self.temperal_upsample[i] else "up2d", f"decoder.upsamples.{n}", cout))
+                n += 1
+        self.head_dim = dims[-1]
+        self.dims0 = dims[0]
+        return plan
+
+    def _load(self, sd: Dict[str, torch.Tensor]) -> None:
+        dev = self.device
+        g = lambda k: sd[k].to(dev)
+        W: Dict[str, torch.Tensor] = {}
+        self.zpad = max(32, (self.z_dim + 31) // 32 * 32)
+        W["conv2.w"] = _repack_conv(g("conv2.weight"), self.zpad)
+        W["conv2.b"] = g("conv2.bias").to(BF16).contiguous()
+        W["decoder.conv1.w"] = _repack_conv(g("decoder.conv1.weight"), self.zpad)
+        W["decoder.conv1.b"] = g("decoder.conv1.bias").to(BF16).contiguous()
+        for item in self.plan:
+            kind, p = item[0], item[1]
+            if kind == "res":
+                for n in ("residual.2", "residual.6"):
+                    W[f"{p}.{n}.w"] = _repack_conv(g(f"{p}.{n}.weight"))
+                    W[f"{p}.{n}.b"] = g(f"{p}.{n}.bias").to(BF16).contiguous()
+                W[f"{p}.residual.0.gamma"] = g(f"{p}.residual.0.gamma").reshape(-1).to(BF16).contiguous()
+                W[f"{p}.residual.3.gamma"] = g(f"{p}.residual.3.gamma").reshape(-1).to(BF16).contiguous()
+                if item[2] != item[3]:
+                    W[f"{p}.shortcut.w"] = _repack_conv(g(f"{p}.shortcut.weight"))
+                    W[f"{p}.shortcut.b"] = g(f"{p}.shortcut.bias").to(BF16).contiguous()
+            elif kind == "attn":
+                c = item[2]
+                W[f"{p}.norm.gamma"] = g(f"{p}.norm.gamma").reshape(-1).to(BF16).contiguous()
+                W[f"{p}.to_qkv.w"] = g(f"{p}.to_qkv.weight").reshape(3 * c, c).to(BF16).contiguous()
+                W[f"{p}.to_qkv.b"] = g(f"{p}.to_qkv.bias").to(BF16).contiguous()
+                W[f"{p}.proj.w"] = g(f"{p}.proj.weight").reshape(c, c).to(BF16).contiguous()
+                W[f"{p}.proj.b"] = g(f"{p}.proj.bias").to(BF16).contiguous()
+            else:
+                c = item[2]
+                W[f"{p}.resample.w"] = _repack_conv(g(f"{p}.resample.1.weight"))
+                W[f"{p}.resample.b"] = g(f"{p}.resample.1.bias").to(BF16).contiguous()
+                if kind == "up3d":
+                    tw = g(f"{p}.time_conv.weight")                  # [2c, c, 3, 1, 1]: halves -> even / odd frames
+                    tb = g(f"{p}.time_conv.bias").to(BF16)
+                    for half in (0, 1):
+                        W[f"{p}.time_conv.w{half}"] = _repack_conv(tw[half * c:(half + 1) * c])
+                        W[f"{p}.time_conv.b{half}"] = tb[half * c:(half + 1) * c].contiguous()
+        W["decoder.head.0.gamma"] = g("decoder.head.0.gamma").reshape(-1).to(BF16).contiguous()
+        W["decoder.head.2.w"] = _repack_conv(g("decoder.head.2.weight"))
+        W["decoder.head.2.b"] = g("decoder.head.2.bias").to(BF16).contiguous()
+        self.W = W
+
+    # ---- buffers ----------------------------------------------------------------------------------------------------
+    def _ring(self, name: str, cap: int, h: int, w: int, c: int) -> FrameRing:
+        key = (name, h, w)
+        r = self._rings.get(key)
+        if r is None or r.cap < cap:
+            hist = r.hist if r is not None else None
+            assert hist is None or hist == [-1, -1], "frame ring would have to grow mid-stream: raise max_frames_per_call"
+            r = self._rings[key] = FrameRing(cap, h, w, c, self.device)
+        return r
+
+    def _tmp(self, tag: str, *shape) -> torch.Tensor:
+        key = (tag,) + tuple(shape)
+        t = self._scratch.get(key)
+        if t is None:
+            t = self._scratch[key] = torch.empty(*shape, dtype=BF16, device=self.device)
+        return t
+
+    def clear_cache(self) -> None:                                    # vae.py:603-611
+        for r in self._rings.values():
+            r.reset()
+        self._rep.clear()
+        self._started = False
+
+    # ---- layers -----------------------------------------------------------------------------------------------------
+    def _causal_conv(self, name: str, src: torch.Tensor, gamma: Optional[str], out: torch.Tensor,
+                     residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[norm + SiLU ->] ring -> 3x3x3 causal conv.  `src` plain `[t, h, w, cin]`; `out` plain `[t, h, w, cout]`."""
+        t, h, w, c = src.shape
+        ring = self._ring(name, self._cap(h), h, w, c)
+        new = ring.new_slots(t)
+        if gamma is not None:
+            ops.rmsnorm_cl(src, self.W[gamma], ring.buf, new, silu=True)
+        else:
+            ring.buf[new] = src
+        ins = ring.commit(new)
+        return ops.conv3d_cl(ring.buf, ins, self.W[name + ".w"], self.W[name + ".b"], kt=3, ks=3, y=out,
+                             out_slots=list(range(t)), residual=residual)
+
+    def _cap(self, h: int) -> int:
+        """Frames per call a ring at this resolution must hold: temporal upsampling doubles them twice."""
+        return self.max_frames * 4
+
+    def _res(self, p: str, x: torch.Tensor, cin: int, cout: int) -> torch.Tensor:
+        """`ResidualBlock.forward` (vae.py:201-219).  The block's output overwrites its shortcut operand in place (every
+        output element is produced by the thread that read that element of the residual)."""
+        t, h, w, _ = x.shape
+        if cin != cout:
+            hres = self._tmp("res.short", t, h, w, cout)
+            ops.conv3d_cl(x, list(range(t)), self.W[p + ".shortcut.w"], self.W[p + ".shortcut.b"], kt=1, ks=1, y=hres,
+                          out_slots=list(range(t)))
+        else:
+            hres = x
+        y1 = self._tmp("res.y1", t, h, w, cout)
+        self._causal_conv(p + ".residual.2", x, p + ".residual.0.gamma", y1)
+        return self._causal_conv(p + ".residual.6", y1, p + ".residual.3.gamma", hres, residual=hres)
+
+    def _attn(self, p: str, x: torch.Tensor) -> torch.Tensor:
+        t, h, w, c = x.shape
+        hw = h * w
+        kpad = (hw + 63) // 64 * 64
+        xn = self._tmp("attn.xn", t, h, w, c)
+        ops.rmsnorm_cl(x, self.W[p + ".norm.gamma"], xn, list(range(t)), silu=False)
+        qkv = ops.linear(xn.view(t * hw, c), self.W[p + ".to_qkv.w"], self.W[p + ".to_qkv.b"],
+                         out=self._tmp("attn.qkv", t * hw, 3 * c)).view(t, hw, 3 * c)
+        key = ("attn.s", hw, kpad)
+        if key not in self._scratch:                              # pad columns stay zero for the K % 64 rule of the GEMM
+            self._scratch[key] = torch.zeros(2, hw, kpad, dtype=BF16, device=self.device)
+            self._scratch[("attn.vt", c, kpad)] = torch.zeros(c, kpad, dtype=BF16, device=self.device)
+        s_buf, p_buf = self._scratch[key][0], self._scratch[key][1]
+        vt = self._scratch[("attn.vt", c, kpad)]
+        o = self._tmp("attn.o", t, hw, c)
+        out = self._tmp("attn.out", t, h, w, c)
+        for f in range(t):
+            q = qkv[f, :, :c]
+            k = self._tmp("attn.k", hw, c)
+            k.copy_(qkv[f, :, c:2 * c])
+            vt[:, :hw].copy_(qkv[f, :, 2 * c:].t())
+            ops.linear(q, k, None, out=s_buf[:, :hw])
+            ops.softmax_rows(s_buf[:, :hw], c ** -0.5, out=p_buf[:, :hw])
+            ops.linear(p_buf, vt, None, out=o[f])
+        ops.linear(o.view(t * hw, c), self.W[p + ".proj.w"], self.W[p + ".proj.b"], epilogue=_hip.IFX_EPI_RESIDUAL,
+                   residual=x.view(t * hw, c), out=out.view(t * hw, c))
+        return out
+
+    def _upsample(self, kind: str, p: str, x: torch.Tensor) -> torch.Tensor:
+        t, h, w, c = x.shape
+        if kind == "up3d":
+            if not self._rep.get(p):                            # first chunk: no temporal upsampling (vae.py:107-109)
+                self._rep[p] = True
+            else:
+                ring = self._ring(p + ".time_conv", self._cap(h), h, w, c)
+                new = ring.new_slots(t)
+                ring.buf[new] = x
+                ins = ring.commit(new)
+                y = self._tmp(p + ".tc", 2 * t, h, w, c)
+                for half in (0, 1):
+                    ops.conv3d_cl(ring.buf, ins, self.W[f"{p}.time_conv.w{half}"], self.W[f"{p}.time_conv.b{half}"], kt=3, ks=1,
+                                  y=y, out_slots=[2 * i + half for i in range(t)])
+                x, t = y, 2 * t
+        out = self._tmp(p + ".up", t, 2 * h, 2 * w, c // 2)
+        return ops.conv3d_cl(x, list(range(t)), self.W[p + ".resample.w"], self.W[p + ".resample.b"], kt=1, ks=3, y=out,
+                             out_slots=list(range(t)), upsample=True)
+
+    def _decoder_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """`Decoder3d.forward` (vae.py:415-466) on `t` latent frames `[t, h, w, zpad]` (already through `conv2`)."""
+        t, h, w, _ = x.shape
+        y = self._tmp("conv1.out", t, h, w, self.dims0)
+        x = self._causal_conv("decoder.conv1", x, None, y)
+        for item in self.plan:
+            if item[0] == "res":
+                x = self._res(item[1], x, item[2], item[3])
+            elif item[0] == "attn":
+                x = self._attn(item[1], x)
+            else:
+                x = self._upsample(item[0], item[1], x)
+        t, h, w, _ = x.shape
+        out = self._tmp("head.out", t, h, w, 3)
+        return self._causal_conv("decoder.head.2", x, "decoder.head.0.gamma", out)
+
+    # ---- entry points -----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def cached_decode(self, z: torch.Tensor) -> torch.Tensor:
+        """vae.py:573-594: `z` `[1, z_dim, T, h, w]` (latent dtype) -> `[1, 3, T_out, 8h, 8w]` bf16, continuing the stream."""
+        assert z.dim() == 5 and z.shape[0] == 1 and z.shape[1] == self.z_dim, tuple(z.shape)
+        z = z.to(self.device)
+        scale0 = self.mean.to(z.dtype).view(1, -1, 1, 1, 1)
+        scale1 = (1.0 / self.std.to(z.dtype)).view(1, -1, 1, 1, 1)
+        z = (z / scale1 + scale0).to(BF16)                                   # wrapper.py:117-118, vae.py:575-579
+        T, h, w = z.shape[2:]
+        zc = torch.zeros(T, h, w, self.zpad, dtype=BF16, device=self.device)
+        zc[..., :self.z_dim] = z[0].permute(1, 2, 3, 0)
+        x = torch.empty(T, h, w, self.zpad, dtype=BF16, device=self.device)
+        x[..., self.z_dim:] = 0
+        x16 = self._tmp("conv2.out", T, h, w, self.z_dim)
+        ops.conv3d_cl(zc, list(range(T)), self.W["conv2.w"], self.W["conv2.b"], kt=1, ks=1, y=x16, out_slots=list(range(T)))
+        x[..., :self.z_dim] = x16
+        outs, i = [], 0
+        while i < T:
+            n = 1 if not self._started else min(self.max_frames, T - i)      # first chunk alone ('Rep' rule)
+            self._started = True
+            outs.append(self._decoder_frames(x[i:i + n]).clone())
+            i += n
+        y = torch.cat(outs, dim=0)                                           # [T_out, H, W, 3]
+        return y.permute(3, 0, 1, 2).unsqueeze(0)
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:                       # vae.py:543-566
+        self.clear_cache()
+        out = self.cached_decode(z)
+        self.clear_cache()
+        return out
+
+
+class HipWanVAEWrapper:
+    """The decode half of `WanVAEWrapper` (wrapper.py:62-168): `decode_to_pixel(latent, use_cache, chunk_size)` and
+    `.model.clear_cache()`, so that the pipelines' `vae=` seam takes it unchanged.  Encoding (image-to-video start frames)
+    is not on the hot path and is not built: pass the reference's wrapper for that."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, device="cuda", max_frames_per_call: int = 3, **cfg):
+        self.model = HipWanVAEDecoder(state_dict, device=device, max_frames_per_call=max_frames_per_call, **cfg)
+
+    def encode_to_latent(self, pixel: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("HipWanVAEWrapper decodes only (SURVEY.md §8(f)1); the encoder runs once per request, "
+                                  "use the reference's WanVAEWrapper for image-to-video start frames")
+
+    @torch.no_grad()
+    def decode_to_pixel(self, latent: torch.Tensor, use_cache: bool = False, chunk_size: int = 2) -> torch.Tensor:
+        """latent `[B, T, C, H, W]` -> pixels `[B, T_out, 3, 8H, 8W]` float32 in [-1, 1] (wrapper.py:103-168).  All three
+        flows of the reference produce the same pixels (all-at-once `decode` is frame-by-frame internally), so `chunk_size`
+        only bounds how many latent frames go through the decoder together."""
+        zs = latent.permute(0, 2, 1, 3, 4)
+        if use_cache:
+            assert latent.shape[0] == 1, "Batch size must be 1 when using cache"
+        out = []
+        for u in zs:
+            self.model.clear_cache()
+            if use_cache:
+                parts = [self.model.cached_decode(u[:, s:s + chunk_size].unsqueeze(0)) for s in range(0, u.shape[1], chunk_size)]
+                dec = torch.cat(parts, dim=2)
+            else:
+                dec = self.model.cached_decode(u.unsqueeze(0))
+            self.model.clear_cache()
+            out.append(dec.float().clamp_(-1, 1).squeeze(0))
+        return torch.stack(out, dim=0).permute(0, 2, 1, 3, 4)
