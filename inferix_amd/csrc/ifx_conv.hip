@@ -13,9 +13,11 @@
 //     offset — 3.9 patch loads per output pixel-chunk instead of the 27 an implicit GEMM gathers.  The nearest-2x
 //     upsample in front of the `Resample` conv2d is folded into the fragment address (source pixel = (o + d - 1) >> 1),
 //     so the 4x larger upsampled tensor never exists.
-//   * weights [tap][Cout][Cin] stream through a ring of 8 KiB slots (one tap x 32 channels x 128 rows), D steps ahead.
-//   * both DMA streams share the wave's vmcnt; the wait before step k allows exactly the instructions issued after
-//     weights(k): min(D-1, total-1-k) weight pieces + the patch pieces of the next stage issued in the last D-1 steps.
+//   * weights [tap][Cout][Cin] stream through a ring of groups (one kernel row = 3 taps x 32 channels x BN rows), one or
+//     two groups ahead; ONE barrier per group, and inside a group the fragments of tap i+1 are read under the MFMAs of
+//     tap i (a barrier per tap left the matrix pipe idle for the LDS latency of every tap: 845 -> see DESIGN.md).
+//   * both DMA streams share the wave's vmcnt; the wait before group g allows exactly the instructions issued after
+//     weights(g): the weight pieces of the groups issued since + the next stage's patch when it went out last group.
 //   * epilogue: bias, bf16 rounding, optional residual add (second rounding, as `x + h` in bf16 upstream), stores into
 //     caller-chosen frame slots (ring buffers of the next conv, or the even/odd frames of the temporal upsampler).
 #include "ifx_common.h"
@@ -28,7 +30,6 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int TH = 8, TW = 64;          // output tile (pixels)
 constexpr int MAXF = 16;                // frames per call (inputs incl. history / outputs)
-constexpr int W_SLOT = 128 * 64;        // weight ring slot: 128 rows x 32 channels
 
 struct ConvArgs {
   const unsigned short* x;
@@ -61,34 +62,32 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
-template <int UPS, int KS>
+template <int BN, int UPS, int KS>
 struct Geo {
   static constexpr int TAPS = KS * KS;
+  static constexpr int TG = TAPS == 9 ? 3 : 1;          // taps per barrier interval ("group" = one kernel row)
+  static constexpr int GPS = TAPS / TG;                 // groups per stage
   static constexpr int PH = UPS ? TH / 2 + 2 : TH + KS - 1;
   static constexpr int PW = UPS ? TW / 2 + 2 : TW + KS - 1;
   static constexpr int NP = PH * PW;                    // patch pixels
   static constexpr int NPI = (NP + 15) / 16;            // 1 KiB DMA instructions per patch
   static constexpr int PPW = (NPI + 7) / 8;             // per wave
   static constexpr int P_SLOT = NPI * 1024;
-  static constexpr int WR = TAPS == 9 ? 6 : 2;          // weight ring depth
-  static constexpr int D = WR - 1;                      // steps of weight lookahead
-  static constexpr int NPT = TAPS == 9 ? (PPW + 1) / 2 : 1;   // steps of a stage that carry patch pieces of the next stage
-  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WR * W_SLOT, LDS = S_OFF + 8 * 1024;
-  static_assert(TAPS == 1 || D <= TAPS - NPT, "weight lookahead must not overtake the patch of its own stage");
-  // patch pieces issued at tap `t` of a stage (for the next stage)
-  static constexpr int cnt(int t) { return TAPS == 1 ? (t == 0 ? PPW : 0) : (t < 0 || t >= NPT ? 0 : (PPW - 2 * t >= 2 ? 2 : PPW - 2 * t)); }
-  // patch pieces issued in the D-1 steps before tap `t` of the same stage
-  static constexpr int psum(int t) {
-    int s = 0;
-    for (int d = 1; d <= D - 1; ++d) s += cnt(t - d);
-    return s;
-  }
+  static constexpr int WP = BN / 16;                    // 1 KiB weight pieces per tap (16 rows x 32 channels)
+  static constexpr int W_TAP = BN * 64;
+  static constexpr int WPW = (TG * WP + 7) / 8;         // weight pieces per wave per group
+  static constexpr int WRG = TAPS == 9 ? (BN == 128 ? 2 : 3) : 2;   // weight ring depth in groups
+  static constexpr int L = WRG - 1;                     // groups of weight lookahead
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WRG * TG * W_TAP, LDS = S_OFF + 8 * 1024;
+  static constexpr bool PF = BN <= 96;                  // fragments of the next tap prefetched under the MFMAs of this one
+  static_assert(L == 1 || GPS >= 3, "patch of the next stage is issued in group 0 and must precede weights two groups on");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
 template <int BN, int UPS, int KS>
 __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
-  using G = Geo<UPS, KS>;
-  constexpr int TAPS = G::TAPS, PW = G::PW, PPW = G::PPW, D = G::D, WR = G::WR;
+  using G = Geo<BN, UPS, KS>;
+  constexpr int TAPS = G::TAPS, TG = G::TG, GPS = G::GPS, PW = G::PW, PPW = G::PPW, WPW = G::WPW, WRG = G::WRG, L = G::L;
   constexpr int TI = BN / 32, TJ = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     poff[r] = ok ? (sh * A.Ws + sw) * A.Cin + (((lane & 3) ^ ((px >> 2) & 3)) << 3) : -1;
   }
   const int CC = A.Cin >> 5;
-  const int S = A.KT * CC, total = S * TAPS;
+  const int S = A.KT * CC, totalG = S * GPS;
   auto issue_patch = [&](int s, int r) {            // piece r of this wave for stage s
     const int dt = s / CC, cc = s - dt * CC;
     const int f = A.in_slot[to + dt];
@@ -131,14 +130,28 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     unsigned char* dst = p < G::NPI ? smem + G::P_OFF + (s & 1) * G::P_SLOT + p * 1024 : smem + G::S_OFF + wave * 1024;
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
   };
-  // ---- weight DMA: one 1 KiB piece per wave per step = rows [16 wave, 16 wave + 16) of the 128-row slot
-  const int wrow = wave * 16 + (lane >> 2);
-  const int woff = min(n_base + wrow, A.Cout - 1) * A.Cin + (((lane & 3) ^ ((wrow >> 2) & 3)) << 3);
-  auto issue_w = [&](int k) {
-    const int s = k / TAPS, tap = k - s * TAPS;
+  // ---- weight DMA: piece idx = wave + 8 q of a group = (tap idx / WP of the group, rows [16 (idx % WP), +16))
+  int woff[WPW];
+#pragma unroll
+  for (int q = 0; q < WPW; ++q) {
+    const int idx = wave + 8 * q;
+    const int wrow = (idx % G::WP) * 16 + (lane >> 2);
+    woff[q] = min(n_base + wrow, A.Cout - 1) * A.Cin + (((lane & 3) ^ ((wrow >> 2) & 3)) << 3);
+  }
+  auto issue_w = [&](int g) {                       // all weight pieces of this wave for group g
+    const int s = g / GPS, gi = g - s * GPS;
     const int dt = s / CC, cc = s - dt * CC;
-    const unsigned short* src = A.w + (size_t)(dt * TAPS + tap) * A.Cout * A.Cin + cc * 32 + woff;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + G::W_OFF + (k % WR) * W_SLOT + wave * 1024), 16, 0, 0);
+    const unsigned short* wbase = A.w + (size_t)(dt * TAPS + gi * TG) * A.Cout * A.Cin + cc * 32;
+    unsigned char* ring = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+      const int idx = wave + 8 * q;
+      const int tg = idx / G::WP;                   // tap within the group
+      const bool real = idx < TG * G::WP;
+      const unsigned short* src = wbase + (size_t)(real ? tg : 0) * A.Cout * A.Cin + woff[q];
+      unsigned char* dst = real ? ring + tg * G::W_TAP + (idx % G::WP) * 1024 : smem + G::S_OFF + wave * 1024;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    }
   };
 
   f32x16 acc[TI][TJ];
@@ -149,12 +162,12 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prologue: patch of stage 0, weights of steps 0 .. D-1
+  // ---- prologue: patch of stage 0, weights of groups 0 .. L-1
 #pragma unroll
   for (int r = 0; r < PPW; ++r) issue_patch(0, r);
 #pragma unroll
-  for (int k = 0; k < D; ++k)
-    if (k < total) issue_w(k);
+  for (int g = 0; g < L; ++g)
+    if (g < totalG) issue_w(g);
 
   int b_off[TI];
 #pragma unroll
@@ -163,52 +176,68 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     b_off[i] = n * 64 + (((n >> 2) & 3) << 4);        // row base with the swizzle phase folded in as an XOR operand below
   }
 
+  constexpr int NB = G::PF ? 2 : 1;
+  bf16x8 fa[NB][2][TJ], fb[NB][2][TI];
   for (int s = 0; s < S; ++s) {
     const bool has_next = s + 1 < S;
     const unsigned char* pb = smem + G::P_OFF + (s & 1) * G::P_SLOT;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int k = s * TAPS + tap;
-      wait_vm(min(D - 1, total - 1 - k) + (has_next ? G::psum(tap) : 0));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of step k-1 retired
+    for (int gi = 0; gi < GPS; ++gi) {
+      const int g = s * GPS + gi;
+      // in flight after weights(g): the weight groups issued since + the next stage's patch when it was issued last group
+      wait_vm(WPW * min(L - 1, totalG - 1 - g) + ((L == 2 && gi == 1 && has_next) ? PPW : 0));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of group g-1 retired
       __builtin_amdgcn_s_barrier();
-      if (has_next) {
-        if (TAPS == 1) {
+      if (gi == 0 && has_next) {
 #pragma unroll
-          for (int r = 0; r < PPW; ++r) issue_patch(s + 1, r);
-        } else if (tap < G::NPT) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            if (2 * tap + q < PPW) issue_patch(s + 1, 2 * tap + q);
-        }
+        for (int r = 0; r < PPW; ++r) issue_patch(s + 1, r);
       }
-      if (k + D < total) issue_w(k + D);
+      if (g + L < totalG) issue_w(g + L);
 
-      const int dh = tap / KS, dw = tap - dh * KS;
-      const unsigned char* wb = smem + G::W_OFF + (k % WR) * W_SLOT;
-      bf16x8 fa[2][TJ], fb[2][TI];
+      const unsigned char* wg = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
+      auto load = [&](int buf, int tg) {
+        const int tap = gi * TG + tg;
+        const int dh = tap / KS, dw = tap - dh * KS;
+        const unsigned char* wb = wg + tg * G::W_TAP;
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        int prow;
-        if (UPS) prow = ((wave + dh + 1) >> 1) * PW + ((j * 32 + l31 + dw + 1) >> 1);
-        else prow = (wave + dh) * PW + (j * 32 + l31 + dw);
-        const int sw = (prow >> 2) & 3;
+        for (int j = 0; j < TJ; ++j) {
+          int prow;
+          if (UPS) prow = ((wave + dh + 1) >> 1) * PW + ((j * 32 + l31 + dw + 1) >> 1);
+          else prow = (wave + dh) * PW + (j * 32 + l31 + dw);
+          const int sw = (prow >> 2) & 3;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          fa[ks][j] = *reinterpret_cast<const bf16x8*>(pb + prow * 64 + (((2 * ks + hi) ^ sw) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          fb[ks][i] = *reinterpret_cast<const bf16x8*>(wb + (b_off[i] ^ ((2 * ks + hi) << 4)));
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+          for (int ks = 0; ks < 2; ++ks)
+            fa[buf][ks][j] = *reinterpret_cast<const bf16x8*>(pb + prow * 64 + (((2 * ks + hi) ^ sw) << 4));
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks)
+            fb[buf][ks][i] = *reinterpret_cast<const bf16x8*>(wb + (b_off[i] ^ ((2 * ks + hi) << 4)));
+      };
+      auto mma = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][ks][i], fa[buf][ks][j], acc[i][j], 0, 0, 0);
+      };
+      if (G::PF) {
+        load(0, 0);
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+          if (tg + 1 < TG) load((tg + 1) & 1, tg + 1);
+          mma(tg & 1);
+        }
+      } else {
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+          load(0, tg);
+          mma(0);
+        }
+      }
     }
   }
 
@@ -260,7 +289,7 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
 
 template <int BN, int UPS, int KS>
 static void launch(const ConvArgs& a, hipStream_t s) {
-  using G = Geo<UPS, KS>;
+  using G = Geo<BN, UPS, KS>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_cl_kernel<BN, UPS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -286,33 +315,51 @@ struct NormArgs {
 
 template <int G>
 __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(NormArgs A) {
-  const int lane_in = threadIdx.x % G;
-  const long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) / G;
-  const bool act = pix < A.pixels && lane_in * 8 < A.C;
-  u16x8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (act) xv = *reinterpret_cast<const u16x8*>(A.x + pix * A.C + lane_in * 8);
-  float ss = 0.f;
+  constexpr int NPX = 4;                    // pixels per lane group: four 16-byte loads in flight per lane
+  constexpr int GPB = 256 / G;              // lane groups per block
+  const int lane_in = threadIdx.x % G, grp = threadIdx.x / G;
+  const bool lane_on = lane_in * 8 < A.C;
+  const int pix0 = blockIdx.x * (GPB * NPX) + grp;          // pixel indices fit 32 bits (checked by the launcher)
+  u16x8 xv[NPX];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float f = bf2f(xv[e]);
-    ss += f * f;
+  for (int i = 0; i < NPX; ++i) {
+    const int pix = pix0 + i * GPB;
+    xv[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane_on && pix < A.pixels) xv[i] = *reinterpret_cast<const u16x8*>(A.x + (long long)pix * A.C + lane_in * 8);
   }
+  u16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lane_on) gv = *reinterpret_cast<const u16x8*>(A.gamma + lane_in * 8);
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  if (!act) return;
-  const float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
-  const u16x8 gv = *reinterpret_cast<const u16x8*>(A.gamma + lane_in * 8);
-  u16x8 o;
+  for (int i = 0; i < NPX; ++i) {
+    float ss = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float v = rbf(bf2f(xv[e]) / n);
-    v = rbf(v * A.scale);
-    v = rbf(v * bf2f(gv[e]));
-    if (A.silu) v = v / (1.f + __expf(-v));
-    o[e] = f2bf(v);
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f(xv[i][e]);
+      ss += f * f;
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const int pix = pix0 + i * GPB;
+    if (!lane_on || pix >= A.pixels) continue;
+    const float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
+    // x / n without the IEEE division sequence (the kernel was VALU-bound on it): reciprocal + one residual step gives
+    // the correctly rounded quotient except for ties no bf16 rounding can see
+    const float rn = __builtin_amdgcn_rcpf(n);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = bf2f(xv[i][e]);
+      float q = x * rn;
+      q = __builtin_fmaf(__builtin_fmaf(-q, n, x), rn, q);
+      float v = rbf(q);
+      v = rbf(v * A.scale);
+      v = rbf(v * bf2f(gv[e]));
+      if (A.silu) v = v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+      o[e] = f2bf(v);
+    }
+    const int f = pix / A.frame_pixels, pp = pix - f * A.frame_pixels;
+    *reinterpret_cast<u16x8*>(A.y + (long long)A.out_slot[f] * A.out_frame_stride + (long long)pp * A.C + lane_in * 8) = o;
   }
-  const long long f = pix / A.frame_pixels, pp = pix - f * A.frame_pixels;
-  *reinterpret_cast<u16x8*>(A.y + (long long)A.out_slot[f] * A.out_frame_stride + pp * A.C + lane_in * 8) = o;
 }
 
 // Row softmax of bf16 scores (single-head spatial attention of the VAE middle block, vae.py:250-254): one wave per row.
@@ -417,6 +464,7 @@ extern "C" int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16
                               int32_t silu, void* stream) {
   IFX_REQUIRE(x && gamma && y && out_slots, "ifx_rmsnorm_cl: null argument");
   IFX_REQUIRE(frames >= 1 && frames <= MAXF && frame_pixels > 0, "ifx_rmsnorm_cl: %d frames per call (max %d)", frames, MAXF);
+  IFX_REQUIRE((long long)frames * frame_pixels < (1ll << 31) - (1 << 16), "ifx_rmsnorm_cl: too many pixels per call");
   IFX_REQUIRE(channels % 8 == 0 && channels >= 8 && channels <= 512, "ifx_rmsnorm_cl: channels %d not in [8, 512] step 8", channels);
   NormArgs a;
   a.x = x;
@@ -433,7 +481,8 @@ extern "C" int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16
   hipStream_t s = (hipStream_t)stream;
 #define IFX_NORM_G(GG)                                                                                         \
   {                                                                                                            \
-    const long long blocks = (a.pixels * GG + 255) / 256;                                                      \
+    const long long per_block = (256 / GG) * 4;                                                               \
+    const long long blocks = (a.pixels + per_block - 1) / per_block;                                           \
     hipLaunchKernelGGL((rmsnorm_cl_kernel<GG>), dim3((unsigned)blocks), dim3(256), 0, s, a);                   \
   }
   if (chunks <= 1) IFX_NORM_G(1)
