@@ -129,6 +129,41 @@ def pmc_traffic(shards):
             "algorithmic_bytes_per_launch": 2 * (2 * 4680 * 1536 + 2 * 18720 * 1536)}
 
 
+def vae_decode_leg():
+    """The other half of the per-block latency, measured AFTER the timed region and not part of `value`:
+    the Wan2.1 VAE decoder (dim 96, synthetic weights) on this GPU, (a) as the streaming pipeline calls it — one block of 3
+    latent frames from a clean cache -> 9 video frames — and (b) a whole 21-frame clip -> 81 frames."""
+    import time
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.vae import HipWanVAEWrapper, synthetic_decoder_state_dict
+    vae = HipWanVAEWrapper(synthetic_decoder_state_dict(seed=0))
+    lat = torch.randn(1, FRAMES, *LATENT, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, out
+
+    blk_ms, blk = timed(lambda: vae.decode_to_pixel(lat[:, :BLOCK], use_cache=True, chunk_size=1), 3)
+    clip_ms, vid = timed(lambda: vae.decode_to_pixel(lat, use_cache=True, chunk_size=BLOCK), 2)
+    t = ops.KernelTimer(names=("conv3d",))
+    ops.set_kernel_timer(t)
+    vae.decode_to_pixel(lat, use_cache=True, chunk_size=BLOCK)
+    ops.set_kernel_timer(None)
+    cs = t.summary()["conv3d"]
+    return {"workload": f"Wan2.1 VAE decoder (dim 96), latent {LATENT[1]}x{LATENT[2]} -> {vid.shape[-2]}x{vid.shape[-1]} px, bf16, "
+                        "synthetic weights; includes the fp32 [-1,1] pixel hand-off",
+            "ms_per_block_streaming": round(blk_ms, 2), "video_frames_per_block": int(blk.shape[1]),
+            "ms_per_clip": round(clip_ms, 1), "video_frames_per_clip": int(vid.shape[1]),
+            "video_frames_per_s": round(vid.shape[1] / clip_ms * 1e3, 1),
+            "conv_launches": cs["launches"], "conv_tflops": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12, 1),
+            "conv_frac_of_bf16_peak": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +174,7 @@ def main():
     ap.add_argument("--quant", choices=["none", "fp8", "int8"], default="none",
                     help="BASELINE config 4: dynamic per-token x per-channel 8-bit linears (not the headline dtype)")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed clip with every kernel timed")
+    ap.add_argument("--no-decode-leg", action="store_true", help="skip the VAE decode measurement after the timed region")
     ap.add_argument("--emulate-sp", type=int, default=0, metavar="P",
                     help="debug: time ONE rank of a P-way sequence-parallel run on one GPU, the K/V all-gather replaced "
                          "by a device copy (makes the result INVALID)")
@@ -292,6 +328,8 @@ def main():
         res["roofline"].update(pmc_traffic(world if world > 1 else max(a.emulate_sp, 1)))
         if breakdown:
             res["kernel_breakdown"] = breakdown
+        if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
+            res["vae_decode"] = vae_decode_leg()
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

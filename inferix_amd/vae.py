@@ -44,6 +44,61 @@ def _repack_conv(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
     return t.contiguous().to(BF16)
 
 
+def synthetic_decoder_state_dict(dim: int = 96, z_dim: int = 16, dim_mult: Sequence[int] = (1, 2, 4, 4),
+                                 num_res_blocks: int = 2, temperal_downsample: Sequence[bool] = (False, True, True),
+                                 seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random decoder weights with the reference's state-dict keys and shapes (vae.py:380-413), variance-preserving so that
+    activations stay O(1) through the 14 residual blocks — for benchmarks and smoke runs (there is no checkpoint here)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, cin, *k):
+        fan = cin
+        for d in k:
+            fan *= d
+        sd[name + ".weight"] = (torch.randn(cout, cin, *k, generator=g) * fan ** -0.5).to(BF16)
+        sd[name + ".bias"] = (0.02 * torch.randn(cout, generator=g)).to(BF16)
+
+    def gamma(name, c, *ones):
+        sd[name] = (1.0 + 0.1 * torch.randn(c, *ones, generator=g)).to(BF16)
+
+    dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+    up = tuple(temperal_downsample[::-1])
+    conv("conv2", z_dim, z_dim, 1, 1, 1)
+    conv("decoder.conv1", dims[0], z_dim, 3, 3, 3)
+
+    def res(p, cin, cout):
+        gamma(p + ".residual.0.gamma", cin, 1, 1, 1)
+        conv(p + ".residual.2", cout, cin, 3, 3, 3)
+        gamma(p + ".residual.3.gamma", cout, 1, 1, 1)
+        conv(p + ".residual.6", cout, cout, 3, 3, 3)
+        if cin != cout:
+            conv(p + ".shortcut", cout, cin, 1, 1, 1)
+
+    res("decoder.middle.0", dims[0], dims[0])
+    gamma("decoder.middle.1.norm.gamma", dims[0], 1, 1)
+    conv("decoder.middle.1.to_qkv", 3 * dims[0], dims[0], 1, 1)
+    conv("decoder.middle.1.proj", dims[0], dims[0], 1, 1)
+    res("decoder.middle.2", dims[0], dims[0])
+    n, last = 0, dims[0]
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(num_res_blocks + 1):
+            res(f"decoder.upsamples.{n}", cin, cout)
+            cin = cout
+            n += 1
+        last = cout
+        if i != len(dim_mult) - 1:
+            conv(f"decoder.upsamples.{n}.resample.1", cout // 2, cout, 3, 3)
+            if up[i]:
+                conv(f"decoder.upsamples.{n}.time_conv", 2 * cout, cout, 3, 1, 1)
+            n += 1
+    gamma("decoder.head.0.gamma", last, 1, 1, 1)
+    conv("decoder.head.2", 3, last, 3, 3, 3)
+    return sd
+
+
 class FrameRing:
     """Input frames of one causal conv: `2 + cap` physical slots; `hist` = slots of the last two frames of the stream
     (-1 = a zero frame in front of the stream)."""

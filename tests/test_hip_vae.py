@@ -210,3 +210,49 @@ def test_decoder_layers_teacher_forced(tiny):
     check("res", "decoder.upsamples.4", 64, 128, 16, 24)          # 1x1x1 shortcut
     check("up2d", "decoder.upsamples.11", 64, 32, 10, 14)
     dec.clear_cache()
+
+
+def test_pipeline_takes_the_hip_vae(tiny, tmp_path):
+    """The pipelines' `vae=` seam with the real decoder: T2V decodes the whole clip (1 + 4 (T - 1) frames), per-block
+    streaming hands 9 uint8 frames per 3-frame block (each `decode_to_pixel(use_cache=True)` call restarts the stream, as
+    upstream, wrapper.py:147-165) and the frames equal the CPU oracle's decode of the same latents within the noise floor."""
+    import yaml
+    import wan_oracle as O
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.pipeline import SelfForcingPipeline
+    g, vcfg, VW, vae = tiny
+    cfg = O.tiny_config()
+    conf = dict(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
+                independent_first_frame=False, context_noise=0, timestep_shift=5.0, kv_cache_tokens=21 * cfg.frame_seqlen,
+                latent_shape=[cfg.in_dim, cfg.latent_h, cfg.latent_w],
+                model_kwargs=dict(patch_size=list(cfg.patch_size), text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
+                                  ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
+                                  num_heads=cfg.num_heads, num_layers=cfg.num_layers, eps=cfg.eps))
+    path = tmp_path / "sf.yaml"
+    path.write_text(yaml.safe_dump(conf))
+    pe = torch.randn(1, cfg.text_len, cfg.text_dim, generator=torch.Generator().manual_seed(5)).to(BF).cuda()
+    pipe = SelfForcingPipeline(str(path), text_encoder=lambda text_prompts: {"prompt_embeds": pe.expand(len(text_prompts), -1, -1)},
+                               vae=vae)
+    W = O.init_weights(cfg, seed=0)
+    ck = tmp_path / "ckpt.pt"
+    torch.save({"generator": {"model." + k: v for k, v in W.items()}}, ck)
+    pipe.load_checkpoint(str(ck), use_ema=False)
+    pipe.setup_devices(low_memory=False, verbose=False)
+
+    torch.manual_seed(3)
+    video = pipe.run_text_to_video(["a prompt"], num_output_frames=6, num_samples=1)
+    assert video.shape == (1, 21, 3, 8 * cfg.latent_h, 8 * cfg.latent_w) and 0.0 <= float(video.min()) <= float(video.max()) <= 1.0
+    torch.manual_seed(3)
+    _, lat = pipe._run_inference(["a prompt"], 6, 1, decode_mode=DecodeMode.NO_DECODE, return_latents=True)
+    orc = V.VaeDecoderOracle(vcfg, VW)
+    ref = (orc.decode_to_pixel(lat.cpu(), use_cache=True, chunk_size=2) * 0.5 + 0.5).clamp(0, 1)
+    assert rel_l2(video.float().cpu(), ref) < 2e-2
+
+    got = []
+    torch.manual_seed(3)
+    streamed = pipe.run_streaming_generation(["p0"], stream_callback=got.append, num_segments=1, segment_length=6, num_samples=1)
+    H, Wd = 8 * cfg.latent_h, 8 * cfg.latent_w
+    assert len(got) == 2 and all(f.dtype == torch.uint8 and tuple(f.shape) == (9, H, Wd, 3) for f in got)
+    assert streamed.shape == (1, 18, H, Wd, 3)
+    blk = (orc.decode_to_pixel(lat[:, :3].cpu(), use_cache=True, chunk_size=1) * 0.5 + 0.5).clamp(0, 1).permute(0, 1, 3, 4, 2)
+    assert rel_l2(streamed[:, :9].float(), blk) < 2e-2

@@ -55,3 +55,12 @@ def test_batching_frames_is_the_same_function_of_the_stream():
     z = g["latent"].permute(0, 2, 1, 3, 4)
     multi = orc.cached_decode(z, frames_per_call=2).float().clamp_(-1, 1).permute(0, 2, 1, 3, 4)
     assert torch.equal(multi, g["pixels"])
+
+
+def test_host_synthetic_state_dict_has_the_reference_keys():
+    """The product-side random-init helper (bench / smoke) produces exactly the decoder's state-dict keys and shapes."""
+    from inferix_amd.vae import synthetic_decoder_state_dict
+    for dim in (32, 96):
+        sd = synthetic_decoder_state_dict(dim=dim)
+        shapes = V.decoder_param_shapes(V.VaeConfig(dim=dim))
+        assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)

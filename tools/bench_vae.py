@@ -13,7 +13,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))      # only for the seeded synthetic weights
 
 
 def main():
@@ -25,11 +24,9 @@ def main():
     ap.add_argument("--dim", type=int, default=96)
     ap.add_argument("--detail", action="store_true", help="per-op event timing (adds launch gaps)")
     a = ap.parse_args()
-    import vae_oracle as V
     from inferix_amd import hip_ops as ops
-    from inferix_amd.vae import HipWanVAEWrapper
-    cfg = V.VaeConfig(dim=a.dim)
-    W = V.make_decoder_params(cfg, 1)
+    from inferix_amd.vae import HipWanVAEWrapper, synthetic_decoder_state_dict
+    W = synthetic_decoder_state_dict(dim=a.dim, seed=1)
     vae = HipWanVAEWrapper(W, dim=a.dim, max_frames_per_call=a.frames_per_call)
     g = torch.Generator().manual_seed(0)
     latent = torch.randn(1, 3 * a.blocks, 16, a.h, a.w, generator=g).to(torch.bfloat16).cuda()
