@@ -20,6 +20,8 @@
 //     weights(g): the weight pieces of the groups issued since + the next stage's patch when it went out last group.
 //   * epilogue: bias, bf16 rounding, optional residual add (second rounding, as `x + h` in bf16 upstream), stores into
 //     caller-chosen frame slots (ring buffers of the next conv, or the even/odd frames of the temporal upsampler).
+#include <stdlib.h>
+
 #include "ifx_common.h"
 
 namespace ifx {
@@ -42,6 +44,7 @@ struct ConvArgs {
   int in_slot[MAXF], out_slot[MAXF];
   int Hs, Ws, Cin, Ho, Wo, Cout, KT, t_out;
   int tiles_w, tiles_h, tiles_n, per_xcd, total;
+  int ablate;      // IFX_CONV_ABLATE bit mask (timing experiments only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no stores
 };
 
 __device__ __forceinline__ void wait_vm(int n) {
@@ -62,6 +65,14 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
+// Timing experiments (tools/ablate_conv.sh): build with -DIFX_CONV_ABLATE_RT=1 to honour IFX_CONV_ABLATE at run time;
+// in normal builds the mask is a compile-time zero and the branches vanish (they cost registers in the main loop).
+#ifdef IFX_CONV_ABLATE_RT
+#define ABL(A) ((A).ablate)
+#else
+#define ABL(A) 0
+#endif
+
 template <int BN, int UPS, int KS>
 struct Geo {
   static constexpr int TAPS = KS * KS;
@@ -78,7 +89,9 @@ struct Geo {
   static constexpr int WPW = (TG * WP + 7) / 8;         // weight pieces per wave per group
   static constexpr int WRG = TAPS == 9 ? (BN == 128 ? 2 : 3) : 2;   // weight ring depth in groups
   static constexpr int L = WRG - 1;                     // groups of weight lookahead
-  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WRG * TG * W_TAP, LDS = S_OFF + 8 * 1024;
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WRG * TG * W_TAP, LDS_MAIN = S_OFF + 8 * 1024;
+  static constexpr int LDS_EPI = 8 * 64 * (BN * 2 + 16);      // per-wave transpose regions of the epilogue (reuse the rings)
+  static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   static constexpr bool PF = BN <= 96;                  // fragments of the next tap prefetched under the MFMAs of this one
   static_assert(L == 1 || GPS >= 3, "patch of the next stage is issued in group 0 and must precede weights two groups on");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -188,14 +201,15 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
       wait_vm(WPW * min(L - 1, totalG - 1 - g) + ((L == 2 && gi == 1 && has_next) ? PPW : 0));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of group g-1 retired
       __builtin_amdgcn_s_barrier();
-      if (gi == 0 && has_next) {
+      if (gi == 0 && has_next && !(ABL(A) & 1)) {
 #pragma unroll
         for (int r = 0; r < PPW; ++r) issue_patch(s + 1, r);
       }
-      if (g + L < totalG) issue_w(g + L);
+      if (g + L < totalG && !(ABL(A) & 1)) issue_w(g + L);
 
       const unsigned char* wg = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
       auto load = [&](int buf, int tg) {
+        if (ABL(A) & 2) return;
         const int tap = gi * TG + tg;
         const int dh = tap / KS, dw = tap - dh * KS;
         const unsigned char* wb = wg + tg * G::W_TAP;
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
             fb[buf][ks][i] = *reinterpret_cast<const bf16x8*>(wb + (b_off[i] ^ ((2 * ks + hi) << 4)));
       };
       auto mma = [&](int buf) {
+        if (ABL(A) & 4) return;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -241,49 +256,68 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     }
   }
 
-  // ---- epilogue: lane (l31, hi) holds, for pixel l31 of block j, channels i*32 + g*8 + hi*4 + e
+  // ---- epilogue.  Lane (l31, hi) holds, for pixel l31 of block j, channels i*32 + g*8 + hi*4 + e: stored directly that is
+  //      8 bytes per lane scattered over 32 pixel rows (measured: a quarter of the 480p launch).  Instead every wave
+  //      transposes its 64 pixels x BN channels of bf16(acc + bias) through its own LDS region (row pitch BN*2 + 16 B:
+  //      16-byte aligned, bank-spread) and moves whole pixel rows: consecutive lanes = consecutive 16-byte chunks, 1 KiB
+  //      contiguous per instruction; the residual comes in the same way.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // everyone is done with the patch / weight rings
+  if (ABL(A) & 8) return;
+  constexpr int PITCH = BN * 2 + 16, CR = BN / 8;
+  unsigned char* tr = smem + wave * (64 * PITCH);
+  const bool vec_bias = A.bias != nullptr && (A.Cout & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = i * 32 + g * 8 + hi * 4;
+      const int n = n_base + nl;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec_bias) {
+        const u16x4 b4 = *reinterpret_cast<const u16x4*>(A.bias + min(n, A.Cout - 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+      } else if (A.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf2f(A.bias[min(n + e, A.Cout - 1)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][4 * g + e] + bv[e]);
+        *reinterpret_cast<u16x4*>(tr + (j * 32 + l31) * PITCH + nl * 2) = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keep the bias loads from piling up in registers
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own region only: no barrier needed
   const int oh = h0 + wave;
   if (oh >= A.Ho) return;
   unsigned short* yf = A.y + (long long)A.out_slot[to] * A.out_frame_stride;
   const unsigned short* rf = A.res ? A.res + (long long)to * A.Ho * A.Wo * A.Cout : nullptr;
 #pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int ow = w0 + j * 32 + l31;
-    if (ow >= A.Wo) continue;
-    const size_t pix = ((size_t)oh * A.Wo + ow) * A.Cout;
+  for (int it = 0; it < CR; ++it) {
+    const int idx = it * 64 + lane;
+    const int p = idx / CR, c = idx - p * CR;
+    const int ow = w0 + p, n = n_base + c * 8;
+    if (ow >= A.Wo || n >= A.Cout) continue;
+    u16x8 v = *reinterpret_cast<const u16x8*>(tr + p * PITCH + c * 16);
+    const size_t off = ((size_t)oh * A.Wo + ow) * A.Cout + n;
+    if (n + 7 < A.Cout && (A.Cout & 7) == 0) {
+      if (rf) {
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(rf + off);
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n_base + i * 32 + g * 8 + hi * 4;
-        if (n >= A.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        if (n + 3 < A.Cout) {
-          if (A.bias) {
-            const u16x4 bv = *reinterpret_cast<const u16x4*>(A.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
-          }
-          u16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-          if (rf) {
-            const u16x4 rv = *reinterpret_cast<const u16x4*>(rf + pix + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(o[e]) + bf2f(rv[e]));
-          }
-          *reinterpret_cast<u16x4*>(yf + pix + n) = o;
-        } else {
-          for (int e = 0; e < 4 && n + e < A.Cout; ++e) {
-            float t = v[e] + (A.bias ? bf2f(A.bias[n + e]) : 0.f);
-            unsigned short o = f2bf(t);
-            if (rf) o = f2bf(bf2f(o) + bf2f(rf[pix + n + e]));
-            yf[pix + n + e] = o;
-          }
-        }
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
       }
+      *reinterpret_cast<u16x8*>(yf + off) = v;
+    } else {
+      for (int e = 0; e < 8 && n + e < A.Cout; ++e) {
+        unsigned short o = v[e];
+        if (rf) o = f2bf(bf2f(o) + bf2f(rf[off + e]));
+        yf[off + e] = o;
+      }
+    }
   }
 }
 
@@ -434,12 +468,20 @@ extern "C" int ifx_conv3d_cl(const ifx_conv3d_desc* d, void* stream) {
   a.Cout = d->cout;
   a.KT = d->kt;
   a.t_out = d->t_out;
-  const int bn = d->cout <= 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 96 == 0 ? 96 : (d->cout <= 64 ? 64 : 128)));
+  // channel tile: 96 wherever it divides (fragment prefetch + two weight groups ahead fit the register / LDS budget,
+  // and 384 = 4 x 96 gives the 60 x 104 level more workgroups), else 128 / 64 / 32
+  const int bn = d->cout <= 32 ? 32 : (d->cout % 96 == 0 ? 96 : (d->cout % 128 == 0 ? 128 : (d->cout <= 64 ? 64 : 128)));
   a.tiles_w = (a.Wo + TW - 1) / TW;
   a.tiles_h = (a.Ho + TH - 1) / TH;
   a.tiles_n = (d->cout + bn - 1) / bn;
   a.total = a.tiles_w * a.tiles_h * a.tiles_n * d->t_out;
   a.per_xcd = (a.total + 7) / 8;
+  static int ablate = -1;
+  if (ablate < 0) {
+    const char* e = getenv("IFX_CONV_ABLATE");
+    ablate = e ? atoi(e) : 0;
+  }
+  a.ablate = ablate;
   hipStream_t s = (hipStream_t)stream;
 #define IFX_CONV_BN(UPS, KS)                              \
   switch (bn) {                                           \
