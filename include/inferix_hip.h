@@ -287,6 +287,27 @@ int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16* y, int64_
 int ifx_softmax_rows(const ifx_bf16* scores, ifx_bf16* probs, int32_t rows, int32_t cols, int32_t ld, float scale,
                      void* stream);
 
+/* ----------------------------------------------------------------------
+ * umT5 text encoder.
+ * ifx_t5_attention: bidirectional self-attention of T5Attention.forward between its q/k/v and o linears
+ * (inferix/models/wan_base/text_encoder/t5.py:96-117), head_dim 64, NO 1/sqrt(d) scaling:
+ *   s = bf16(bf16(q.k) + bias[h][key - query]) ; keys >= seq_lens[b] get finfo(bf16).min ; p = bf16(softmax_fp32(s)) ;
+ *   out = bf16(p v).
+ *   q/k/v/out   rows b*seq_len_padded + t, channels h*64 + c, given row strides (q, k, v may be the column blocks of one
+ *               fused qkv GEMM output)
+ *   rel_bias    [heads][2*seq_len_padded - 1] bf16: the T5RelativeEmbedding value (t5.py:235-266) of relative offset
+ *               (key - query) at index offset + seq_len_padded - 1; the [1, heads, L, L] tensor is never built
+ *   seq_lens    [batch] int32 in device memory
+ * seq_len_padded in [32, 512], multiple of 32 (K and V^T of one head are staged in LDS).
+ * ---------------------------------------------------------------------- */
+int ifx_t5_attention(const ifx_bf16* q, int32_t ldq, const ifx_bf16* k, int32_t ldk, const ifx_bf16* v, int32_t ldv,
+                     ifx_bf16* out, int32_t ldo, const ifx_bf16* rel_bias, const int32_t* seq_lens, int32_t batch,
+                     int32_t seq_len_padded, int32_t heads, void* stream);
+
+/* h[rows][ffn] = fc1 * GELU(gate) with the tanh GELU of t5.py:50-52 evaluated op by op in bf16 (T5FeedForward.forward,
+ * t5.py:138-139); gate_fc1 = [rows][2*ffn], columns [0, ffn) = gate pre-activation, [ffn, 2 ffn) = fc1 (one fused GEMM). */
+int ifx_t5_gated_gelu(const ifx_bf16* gate_fc1, ifx_bf16* h, int32_t rows, int32_t ffn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,8 @@ SIGNATURES = {
     "ifx_conv3d_cl": (C.c_int, [C.POINTER(Conv3dDesc), _vp]),
     "ifx_rmsnorm_cl": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),
     "ifx_softmax_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "ifx_t5_attention": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "ifx_t5_gated_gelu": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "ifx_kv_scatter_shards": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(KvView), _vp]),
     "ifx_attn_fwd_partial": (C.c_int, [_vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp, C.c_int64, _i32,
                                        _i32, C.POINTER(_i32), _vp]),

@@ -424,3 +424,32 @@ def softmax_rows(scores: torch.Tensor, scale: float, out: Optional[torch.Tensor]
     _hip.check(_hip.load().ifx_softmax_rows(_dev(scores, "scores"), _dev(out, "probs"), rows, cols, ld, float(scale),
                                             _stream()), "ifx_softmax_rows")
     return out
+
+
+# ---- umT5 text encoder ops -----------------------------------------------------------------------------------------
+def t5_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel_bias: torch.Tensor, seq_lens: torch.Tensor,
+                 batch: int, heads: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T5 self-attention (ifx_t5_attention): q/k/v `[batch*L, heads*64]` (row-strided views of a fused qkv output are fine),
+    `rel_bias` `[heads, 2L-1]`, `seq_lens` int32 `[batch]` on the device."""
+    rows = q.shape[0]
+    L = rows // batch
+    assert rows == batch * L and q.shape[1] == heads * 64 and k.shape == q.shape and v.shape == q.shape
+    assert tuple(rel_bias.shape) == (heads, 2 * L - 1) and rel_bias.is_contiguous()
+    assert seq_lens.dtype == torch.int32 and seq_lens.is_cuda and seq_lens.numel() == batch
+    out = torch.empty(rows, heads * 64, dtype=BF16, device=q.device) if out is None else out
+    with _timed("attn_t5", 4.0 * batch * heads * L * L * 64, 0.0):
+        _hip.check(_hip.load().ifx_t5_attention(_dev(q, "q"), q.stride(0), _dev(k, "k"), k.stride(0), _dev(v, "v"), v.stride(0),
+                                                _dev(out, "out"), out.stride(0), _dev(rel_bias, "rel_bias"),
+                                                seq_lens.data_ptr(), batch, L, heads, _stream()), "ifx_t5_attention")
+    return out
+
+
+def t5_gated_gelu(gate_fc1: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`fc1 * GELU(gate)` from the fused `[rows, 2*ffn]` GEMM output (ifx_t5_gated_gelu)."""
+    rows, two_ffn = gate_fc1.shape
+    ffn = two_ffn // 2
+    assert gate_fc1.is_contiguous()
+    out = torch.empty(rows, ffn, dtype=BF16, device=gate_fc1.device) if out is None else out
+    _hip.check(_hip.load().ifx_t5_gated_gelu(_dev(gate_fc1, "gate_fc1"), _dev(out, "h"), rows, ffn, _stream()),
+               "ifx_t5_gated_gelu")
+    return out

@@ -1,0 +1,108 @@
+"""GPU parity of the umT5 text-encoder path: `ifx_t5_attention`, `ifx_t5_gated_gelu` per op and
+`HipWanTextEncoder` end to end against the CPU oracle and the reference-generated golden context."""
+import pytest
+import torch
+
+import t5_oracle as T
+from fixture_io import golden, weights_checksum
+from util import assert_bf16_parity, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from inferix_amd import hip_ops
+    return hip_ops
+
+
+def rnd(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("B,L,heads,lens", [(1, 64, 2, [64]), (2, 192, 4, [150, 37]), (1, 512, 3, [301]), (3, 96, 1, [1, 96, 50])])
+def test_t5_attention_against_oracle_math(ops, B, L, heads, lens):
+    from inferix_amd.t5 import relative_position_table
+    g = torch.Generator().manual_seed(L + heads)
+    da = heads * 64
+    qkv = rnd(g, B * L, 3 * da, scale=0.6)
+    emb = rnd(g, 32, heads, scale=0.5)
+    mask = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    # oracle: the middle of t5_oracle.attention (between the q/k/v and o linears)
+    q, k, v = [t.view(B, L, heads, 64) for t in qkv.split(da, dim=1)]
+    bias = q.new_zeros(B, heads, L, L)
+    bias += T.position_bias(emb, L, L, 32, 128)
+    bias.masked_fill_(mask.view(B, 1, 1, -1) == 0, torch.finfo(BF).min)
+    attn = torch.einsum("binc,bjnc->bnij", q, k) + bias
+    attn = torch.softmax(attn.float(), dim=-1).type_as(attn)
+    ref = torch.einsum("bnij,bjnc->binc", attn, v).reshape(B * L, da)
+    qkv_d = qkv.cuda()
+    got = ops.t5_attention(qkv_d[:, :da], qkv_d[:, da:2 * da], qkv_d[:, 2 * da:], relative_position_table(emb, L, 32).cuda(),
+                           mask.sum(1).to(torch.int32).cuda(), B, heads)
+    # Scores are rounded to bf16 BEFORE the softmax on both sides (s = bf16(bf16(q.k) + bias)): where the fp32 accumulation
+    # order flips that rounding, s moves by one bf16 ulp (3 % of exp(s) at |s| ~ 4), and a row whose softmax is dominated by
+    # that key moves with it.  So: almost every element identical (<= 2 % may differ at all), tight tensor error, and a loose
+    # per-element cap for the rare flipped rows.
+    assert_bf16_parity(got.cpu(), ref, max_ulp=8, max_mismatch_frac=0.02, rel=2e-3, floor=1.0, what=f"t5 attention L{L}")
+
+
+def test_t5_gated_gelu_is_the_reference_op_chain(ops):
+    g = torch.Generator().manual_seed(1)
+    gf = rnd(g, 70, 2 * 256, scale=2.0)
+    ref = gf[:, 256:] * T.gelu(gf[:, :256])
+    got = ops.t5_gated_gelu(gf.cuda())
+    # 1 + tanh(.) cancels in the negative tail: a one-ulp difference between the device tanhf and the host one is carried at the
+    # scale of the operands (util.assert_bf16_parity: ops with a cancellation stage are compared with floor=1)
+    assert_bf16_parity(got.cpu(), ref, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what="gated gelu")
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    g = golden("t5_encoder.npz")
+    v, d, da, f, h, n = [int(i) for i in g["cfg"]]
+    cfg = T.T5Config(vocab_size=v, dim=d, dim_attn=da, dim_ffn=f, num_heads=h, num_layers=n)
+    W = T.make_params(cfg, int(g["seed"]))
+    assert weights_checksum(W) == int(g["weights_checksum"])
+    from inferix_amd.t5 import HipWanTextEncoder
+    enc = HipWanTextEncoder(W, tokenizer=lambda texts, return_mask=True, add_special_tokens=True: (g["ids"], g["mask"]),
+                            dim=d, dim_attn=da, dim_ffn=f, num_heads=h, num_layers=n)
+    return g, cfg, W, enc
+
+
+def test_encoder_matches_reference_golden(tiny):
+    g, cfg, W, enc = tiny
+    got = enc(["prompt a", "prompt b"])["prompt_embeds"].cpu()
+    ref = g["context"]
+    assert got.shape == ref.shape and got.dtype == BF
+    lens = g["mask"].sum(1).tolist()
+    assert all(float(got[b, n:].abs().max()) == 0.0 for b, n in enumerate(lens))        # padding rows zeroed (wrapper.py:54-55)
+    # exact answer = the fp32 evaluation of the same encoder; the reference's bf16 run sits `floor` away from it
+    W32 = {k: v.float() for k, v in W.items()}
+    exact = T.text_encoder_forward(cfg, W32, g["ids"], g["mask"])
+    floor, mine, r = rel_l2(ref, exact), rel_l2(got, exact), rel_l2(got, ref)
+    print(f"t5: bf16 noise floor (reference vs fp32) {floor:.3e}; HIP vs fp32 {mine:.3e}; HIP vs reference {r:.3e}")
+    assert mine <= 1.25 * floor and r <= 2.0 * floor
+
+
+def test_encoder_is_deterministic_and_batch_invariant(tiny):
+    g, cfg, W, enc = tiny
+    a = enc.encode_ids(g["ids"], g["mask"])["prompt_embeds"]
+    b = enc.encode_ids(g["ids"], g["mask"])["prompt_embeds"]
+    assert torch.equal(a, b)
+    one = enc.encode_ids(g["ids"][1:], g["mask"][1:])["prompt_embeds"]
+    assert torch.equal(one[0], a[1]), "a prompt's embedding must not depend on what else is in the batch"
+
+
+def test_encoder_errors(tiny):
+    g, cfg, W, enc = tiny
+    from inferix_amd.t5 import HipT5Encoder, HipWanTextEncoder
+    with pytest.raises(ValueError, match="multiple of 32"):
+        enc.encode_ids(g["ids"][:, :100], g["mask"][:, :100])
+    with pytest.raises(NotImplementedError, match="head_dim 64"):
+        HipT5Encoder(W, dim=cfg.dim, dim_attn=cfg.dim_attn, dim_ffn=cfg.dim_ffn, num_heads=8, num_layers=cfg.num_layers)
+    with pytest.raises(RuntimeError, match="tokenizer"):
+        HipWanTextEncoder(W, None, dim=cfg.dim, dim_attn=cfg.dim_attn, dim_ffn=cfg.dim_ffn, num_heads=cfg.num_heads,
+                          num_layers=cfg.num_layers)(["x"])
