@@ -164,6 +164,30 @@ def vae_decode_leg():
             "conv_frac_of_bf16_peak": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
 
+def text_encoder_leg():
+    """Time-to-first-block component of a prompt switch, measured AFTER the timed region and not part of
+    `value`: umT5-XXL encoder (24 layers, dim 4096, synthetic weights generated on the device) on one 512-token prompt."""
+    import time
+    from inferix_amd.t5 import HipWanTextEncoder, synthetic_t5_state_dict
+    enc = HipWanTextEncoder(synthetic_t5_state_dict(device="cuda"), None)
+    ids = torch.randint(1, 256384, (1, 512), generator=torch.Generator().manual_seed(0))
+    mask = torch.zeros(1, 512, dtype=torch.long)
+    mask[:, :60] = 1
+    enc.encode_ids(ids, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out = enc.encode_ids(ids, mask)["prompt_embeds"]
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    flops = 24 * (2.0 * 512 * 4096 * (4 * 4096 + 2 * 10240) + 2.0 * 512 * 10240 * 4096 + 4.0 * 64 * 512 * 512 * 64)
+    del enc
+    torch.cuda.empty_cache()
+    return {"workload": "umT5-XXL encoder (24 layers, dim 4096, 64 heads, ffn 10240), one prompt padded to 512 tokens, bf16, "
+                        "synthetic weights; tokenizer not included", "ms_per_prompt": round(ms, 2),
+            "tflops": round(flops / ms / 1e9, 1), "output": list(out.shape)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +198,7 @@ def main():
     ap.add_argument("--quant", choices=["none", "fp8", "int8"], default="none",
                     help="BASELINE config 4: dynamic per-token x per-channel 8-bit linears (not the headline dtype)")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed clip with every kernel timed")
-    ap.add_argument("--no-decode-leg", action="store_true", help="skip the VAE decode measurement after the timed region")
+    ap.add_argument("--no-decode-leg", action="store_true", help="skip the VAE decode / text encoder measurements after the timed region")
     ap.add_argument("--emulate-sp", type=int, default=0, metavar="P",
                     help="debug: time ONE rank of a P-way sequence-parallel run on one GPU, the K/V all-gather replaced "
                          "by a device copy (makes the result INVALID)")
@@ -330,6 +354,8 @@ def main():
             res["kernel_breakdown"] = breakdown
         if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
             res["vae_decode"] = vae_decode_leg()
+        if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
+            res["text_encoder"] = text_encoder_leg()
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -106,3 +106,41 @@ def test_encoder_errors(tiny):
     with pytest.raises(RuntimeError, match="tokenizer"):
         HipWanTextEncoder(W, None, dim=cfg.dim, dim_attn=cfg.dim_attn, dim_ffn=cfg.dim_ffn, num_heads=cfg.num_heads,
                           num_layers=cfg.num_layers)(["x"])
+
+
+def test_pipeline_takes_the_hip_text_encoder(tiny, tmp_path):
+    """The pipelines' `text_encoder=` seam with the real encoder: `text_encoder(text_prompts=[...])["prompt_embeds"]` feeds the
+    generator's cross-attention (the tiny DiT here reads 256-wide text features of 192 tokens)."""
+    import yaml
+    import wan_oracle as O
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.pipeline import SelfForcingPipeline
+    g, tcfg, TW, enc = tiny
+    cfg = O.tiny_config(text_len=192, text_dim=tcfg.dim)
+    conf = dict(denoising_step_list=[1000, 500], warp_denoising_step=True, num_frame_per_block=3, independent_first_frame=False,
+                context_noise=0, timestep_shift=5.0, kv_cache_tokens=21 * cfg.frame_seqlen,
+                latent_shape=[cfg.in_dim, cfg.latent_h, cfg.latent_w],
+                model_kwargs=dict(patch_size=list(cfg.patch_size), text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
+                                  ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
+                                  num_heads=cfg.num_heads, num_layers=cfg.num_layers, eps=cfg.eps))
+    path = tmp_path / "sf.yaml"
+    path.write_text(yaml.safe_dump(conf))
+    one = type(enc)(TW, tokenizer=lambda texts, return_mask=True, add_special_tokens=True: (g["ids"][:len(texts)], g["mask"][:len(texts)]),
+                    dim=tcfg.dim, dim_attn=tcfg.dim_attn, dim_ffn=tcfg.dim_ffn, num_heads=tcfg.num_heads, num_layers=tcfg.num_layers)
+    pipe = SelfForcingPipeline(str(path), text_encoder=one, vae=None)
+    W = O.init_weights(cfg, seed=0)
+    ck = tmp_path / "ckpt.pt"
+    torch.save({"generator": {"model." + k: v for k, v in W.items()}}, ck)
+    pipe.load_checkpoint(str(ck), use_ema=False)
+    pipe.setup_devices(low_memory=False, verbose=False)
+    torch.manual_seed(3)
+    _, lat = pipe._run_inference(["a prompt"], 3, 1, decode_mode=DecodeMode.NO_DECODE, return_latents=True)
+    assert lat.shape == (1, 3, cfg.in_dim, cfg.latent_h, cfg.latent_w) and torch.isfinite(lat.float()).all()
+    # the same latents when the oracle's context is injected instead
+    ctx = T.text_encoder_forward(tcfg, TW, g["ids"][:1], g["mask"][:1])
+    pipe2 = SelfForcingPipeline(str(path), text_encoder=lambda text_prompts: {"prompt_embeds": ctx.cuda()}, vae=None)
+    pipe2.load_checkpoint(str(ck), use_ema=False)
+    pipe2.setup_devices(low_memory=False, verbose=False)
+    torch.manual_seed(3)
+    _, lat2 = pipe2._run_inference(["a prompt"], 3, 1, decode_mode=DecodeMode.NO_DECODE, return_latents=True)
+    assert rel_l2(lat.float().cpu(), lat2.float().cpu()) < 2e-2
