@@ -17,6 +17,8 @@ MI355X-first differences in HOW (not in what is computed):
     frames of a block go through together after the first chunk — the same function of the stream (causal convs commute
     with chunking; pinned in oracle/gen_golden_vae.py), 3x fewer launches and 3x larger grids.
   * the single-head 384-wide spatial attention of the middle block is two `ifx_gemm_bf16` launches around `ifx_softmax_rows`.
+
+`HipWanVAEEncoder` (image-to-video start frames, once per request) runs on the same kernels.
 """
 from __future__ import annotations
 
@@ -99,6 +101,56 @@ def synthetic_decoder_state_dict(dim: int = 96, z_dim: int = 16, dim_mult: Seque
     return sd
 
 
+def synthetic_encoder_state_dict(dim: int = 96, z_dim: int = 16, dim_mult: Sequence[int] = (1, 2, 4, 4), num_res_blocks: int = 2,
+                                 temperal_downsample: Sequence[bool] = (False, True, True), seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random encoder weights with the reference's keys and shapes (vae.py:264-316) — the counterpart of
+    `synthetic_decoder_state_dict` for smoke runs of `encode_to_latent`."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, cin, *k):
+        fan = cin
+        for d in k:
+            fan *= d
+        sd[name + ".weight"] = (torch.randn(cout, cin, *k, generator=g) * fan ** -0.5).to(BF16)
+        sd[name + ".bias"] = (0.02 * torch.randn(cout, generator=g)).to(BF16)
+
+    def gamma(name, c, *ones):
+        sd[name] = (1.0 + 0.1 * torch.randn(c, *ones, generator=g)).to(BF16)
+
+    def res(p, cin, cout):
+        gamma(p + ".residual.0.gamma", cin, 1, 1, 1)
+        conv(p + ".residual.2", cout, cin, 3, 3, 3)
+        gamma(p + ".residual.3.gamma", cout, 1, 1, 1)
+        conv(p + ".residual.6", cout, cout, 3, 3, 3)
+        if cin != cout:
+            conv(p + ".shortcut", cout, cin, 1, 1, 1)
+
+    dims = [dim * u for u in [1] + list(dim_mult)]
+    conv("conv1", 2 * z_dim, 2 * z_dim, 1, 1, 1)
+    conv("encoder.conv1", dims[0], 3, 3, 3, 3)
+    n = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(num_res_blocks):
+            res(f"encoder.downsamples.{n}", cin, cout)
+            cin = cout
+            n += 1
+        if i != len(dim_mult) - 1:
+            conv(f"encoder.downsamples.{n}.resample.1", cout, cout, 3, 3)
+            if temperal_downsample[i]:
+                conv(f"encoder.downsamples.{n}.time_conv", cout, cout, 3, 1, 1)
+            n += 1
+    top = dims[-1]
+    res("encoder.middle.0", top, top)
+    gamma("encoder.middle.1.norm.gamma", top, 1, 1)
+    conv("encoder.middle.1.to_qkv", 3 * top, top, 1, 1)
+    conv("encoder.middle.1.proj", top, top, 1, 1)
+    res("encoder.middle.2", top, top)
+    gamma("encoder.head.0.gamma", top, 1, 1, 1)
+    conv("encoder.head.2", 2 * z_dim, top, 3, 3, 3)
+    return sd
+
+
 class FrameRing:
     """Input frames of one causal conv: `2 + cap` physical slots; `hist` = slots of the last two frames of the stream
     (-1 = a zero frame in front of the stream)."""
@@ -123,88 +175,36 @@ class FrameRing:
         return ins
 
 
-class HipWanVAEDecoder:
-    """`Decoder3d` + `conv2` of `WanVAE_` with the streaming cache (`cached_decode` / `decode` / `clear_cache`)."""
+class _VaeLayers:
+    """What encoder and decoder share: scratch / frame-ring management and the residual, attention and causal-conv layers."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], *, dim: int = 96, z_dim: int = 16,
-                 dim_mult: Sequence[int] = (1, 2, 4, 4), num_res_blocks: int = 2,
-                 temperal_downsample: Sequence[bool] = (False, True, True), device="cuda", max_frames_per_call: int = 3):
+    def _init_layers(self, device, max_frames_per_call: int) -> None:
         _hip.load()                                         # fail loudly without the HIP library
         self.device = torch.device(device)
-        self.dim, self.z_dim, self.dim_mult = dim, z_dim, tuple(dim_mult)
-        self.num_res_blocks = num_res_blocks
-        self.temperal_upsample = tuple(temperal_downsample[::-1])
         self.max_frames = max_frames_per_call
-        self.plan = self._plan()
-        self._load(state_dict)
-        self.mean = torch.tensor(VAE_MEAN[:z_dim], dtype=torch.float32, device=self.device)
-        self.std = torch.tensor(VAE_STD[:z_dim], dtype=torch.float32, device=self.device)
         self._rings: Dict[Tuple[str, int, int], FrameRing] = {}
         self._scratch: Dict[Tuple, torch.Tensor] = {}
         self._started = False
         self._rep: Dict[str, bool] = {}
+        self.mean = torch.tensor(VAE_MEAN[:self.z_dim], dtype=torch.float32, device=self.device)
+        self.std = torch.tensor(VAE_STD[:self.z_dim], dtype=torch.float32, device=self.device)
 
-    # ---- structure (vae.py:381-413) ---------------------------------------------------------------------------------
-    def _plan(self) -> List[tuple]:
-        dims = [self.dim * u for u in [self.dim_mult[-1]] + list(self.dim_mult[::-1])]
-        plan = [("res", "decoder.middle.0", dims[0], dims[0]), ("attn", "decoder.middle.1", dims[0]),
-                ("res", "decoder.middle.2", dims[0], dims[0])]
-        n = 0
-        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
-            if i in (1, 2, 3):
-                cin = cin // 2
-            for _ in range(self.num_res_blocks + 1):
-                plan.append(("res", f"decoder.upsamples.{n}", cin, cout))
-                cin = cout
-                n += 1
-            if i != len(self.dim_mult) - 1:
-                plan.append(("up3d" if self.temperal_upsample[i] else "up2d", f"decoder.upsamples.{n}", cout))
-                n += 1
-        self.head_dim = dims[-1]
-        self.dims0 = dims[0]
-        return plan
+    def _load_res(self, W: Dict[str, torch.Tensor], g, p: str, cin: int, cout: int) -> None:
+        for n in ("residual.2", "residual.6"):
+            W[f"{p}.{n}.w"] = _repack_conv(g(f"{p}.{n}.weight"))
+            W[f"{p}.{n}.b"] = g(f"{p}.{n}.bias").to(BF16).contiguous()
+        W[f"{p}.residual.0.gamma"] = g(f"{p}.residual.0.gamma").reshape(-1).to(BF16).contiguous()
+        W[f"{p}.residual.3.gamma"] = g(f"{p}.residual.3.gamma").reshape(-1).to(BF16).contiguous()
+        if cin != cout:
+            W[f"{p}.shortcut.w"] = _repack_conv(g(f"{p}.shortcut.weight"))
+            W[f"{p}.shortcut.b"] = g(f"{p}.shortcut.bias").to(BF16).contiguous()
 
-    def _load(self, sd: Dict[str, torch.Tensor]) -> None:
-        dev = self.device
-        g = lambda k: sd[k].to(dev)
-        W: Dict[str, torch.Tensor] = {}
-        self.zpad = max(32, (self.z_dim + 31) // 32 * 32)
-        W["conv2.w"] = _repack_conv(g("conv2.weight"), self.zpad)
-        W["conv2.b"] = g("conv2.bias").to(BF16).contiguous()
-        W["decoder.conv1.w"] = _repack_conv(g("decoder.conv1.weight"), self.zpad)
-        W["decoder.conv1.b"] = g("decoder.conv1.bias").to(BF16).contiguous()
-        for item in self.plan:
-            kind, p = item[0], item[1]
-            if kind == "res":
-                for n in ("residual.2", "residual.6"):
-                    W[f"{p}.{n}.w"] = _repack_conv(g(f"{p}.{n}.weight"))
-                    W[f"{p}.{n}.b"] = g(f"{p}.{n}.bias").to(BF16).contiguous()
-                W[f"{p}.residual.0.gamma"] = g(f"{p}.residual.0.gamma").reshape(-1).to(BF16).contiguous()
-                W[f"{p}.residual.3.gamma"] = g(f"{p}.residual.3.gamma").reshape(-1).to(BF16).contiguous()
-                if item[2] != item[3]:
-                    W[f"{p}.shortcut.w"] = _repack_conv(g(f"{p}.shortcut.weight"))
-                    W[f"{p}.shortcut.b"] = g(f"{p}.shortcut.bias").to(BF16).contiguous()
-            elif kind == "attn":
-                c = item[2]
-                W[f"{p}.norm.gamma"] = g(f"{p}.norm.gamma").reshape(-1).to(BF16).contiguous()
-                W[f"{p}.to_qkv.w"] = g(f"{p}.to_qkv.weight").reshape(3 * c, c).to(BF16).contiguous()
-                W[f"{p}.to_qkv.b"] = g(f"{p}.to_qkv.bias").to(BF16).contiguous()
-                W[f"{p}.proj.w"] = g(f"{p}.proj.weight").reshape(c, c).to(BF16).contiguous()
-                W[f"{p}.proj.b"] = g(f"{p}.proj.bias").to(BF16).contiguous()
-            else:
-                c = item[2]
-                W[f"{p}.resample.w"] = _repack_conv(g(f"{p}.resample.1.weight"))
-                W[f"{p}.resample.b"] = g(f"{p}.resample.1.bias").to(BF16).contiguous()
-                if kind == "up3d":
-                    tw = g(f"{p}.time_conv.weight")                  # [2c, c, 3, 1, 1]: halves -> even / odd frames
-                    tb = g(f"{p}.time_conv.bias").to(BF16)
-                    for half in (0, 1):
-                        W[f"{p}.time_conv.w{half}"] = _repack_conv(tw[half * c:(half + 1) * c])
-                        W[f"{p}.time_conv.b{half}"] = tb[half * c:(half + 1) * c].contiguous()
-        W["decoder.head.0.gamma"] = g("decoder.head.0.gamma").reshape(-1).to(BF16).contiguous()
-        W["decoder.head.2.w"] = _repack_conv(g("decoder.head.2.weight"))
-        W["decoder.head.2.b"] = g("decoder.head.2.bias").to(BF16).contiguous()
-        self.W = W
+    def _load_attn(self, W: Dict[str, torch.Tensor], g, p: str, c: int) -> None:
+        W[f"{p}.norm.gamma"] = g(f"{p}.norm.gamma").reshape(-1).to(BF16).contiguous()
+        W[f"{p}.to_qkv.w"] = g(f"{p}.to_qkv.weight").reshape(3 * c, c).to(BF16).contiguous()
+        W[f"{p}.to_qkv.b"] = g(f"{p}.to_qkv.bias").to(BF16).contiguous()
+        W[f"{p}.proj.w"] = g(f"{p}.proj.weight").reshape(c, c).to(BF16).contiguous()
+        W[f"{p}.proj.b"] = g(f"{p}.proj.bias").to(BF16).contiguous()
 
     # ---- buffers ----------------------------------------------------------------------------------------------------
     def _ring(self, name: str, cap: int, h: int, w: int, c: int) -> FrameRing:
@@ -290,6 +290,70 @@ class HipWanVAEDecoder:
                    residual=x.view(t * hw, c), out=out.view(t * hw, c))
         return out
 
+
+class HipWanVAEDecoder(_VaeLayers):
+    """`Decoder3d` + `conv2` of `WanVAE_` with the streaming cache (`cached_decode` / `decode` / `clear_cache`)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, dim: int = 96, z_dim: int = 16,
+                 dim_mult: Sequence[int] = (1, 2, 4, 4), num_res_blocks: int = 2,
+                 temperal_downsample: Sequence[bool] = (False, True, True), device="cuda", max_frames_per_call: int = 3):
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, tuple(dim_mult)
+        self._init_layers(device, max_frames_per_call)
+        self.num_res_blocks = num_res_blocks
+        self.temperal_upsample = tuple(temperal_downsample[::-1])
+        self.plan = self._plan()
+        self._load(state_dict)
+
+    # ---- structure (vae.py:381-413) ---------------------------------------------------------------------------------
+    def _plan(self) -> List[tuple]:
+        dims = [self.dim * u for u in [self.dim_mult[-1]] + list(self.dim_mult[::-1])]
+        plan = [("res", "decoder.middle.0", dims[0], dims[0]), ("attn", "decoder.middle.1", dims[0]),
+                ("res", "decoder.middle.2", dims[0], dims[0])]
+        n = 0
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            if i in (1, 2, 3):
+                cin = cin // 2
+            for _ in range(self.num_res_blocks + 1):
+                plan.append(("res", f"decoder.upsamples.{n}", cin, cout))
+                cin = cout
+                n += 1
+            if i != len(self.dim_mult) - 1:
+                plan.append(("up3d" if self.temperal_upsample[i] else "up2d", f"decoder.upsamples.{n}", cout))
+                n += 1
+        self.head_dim = dims[-1]
+        self.dims0 = dims[0]
+        return plan
+
+    def _load(self, sd: Dict[str, torch.Tensor]) -> None:
+        dev = self.device
+        g = lambda k: sd[k].to(dev)
+        W: Dict[str, torch.Tensor] = {}
+        self.zpad = max(32, (self.z_dim + 31) // 32 * 32)
+        W["conv2.w"] = _repack_conv(g("conv2.weight"), self.zpad)
+        W["conv2.b"] = g("conv2.bias").to(BF16).contiguous()
+        W["decoder.conv1.w"] = _repack_conv(g("decoder.conv1.weight"), self.zpad)
+        W["decoder.conv1.b"] = g("decoder.conv1.bias").to(BF16).contiguous()
+        for item in self.plan:
+            kind, p = item[0], item[1]
+            if kind == "res":
+                self._load_res(W, g, p, item[2], item[3])
+            elif kind == "attn":
+                self._load_attn(W, g, p, item[2])
+            else:
+                c = item[2]
+                W[f"{p}.resample.w"] = _repack_conv(g(f"{p}.resample.1.weight"))
+                W[f"{p}.resample.b"] = g(f"{p}.resample.1.bias").to(BF16).contiguous()
+                if kind == "up3d":
+                    tw = g(f"{p}.time_conv.weight")                  # [2c, c, 3, 1, 1]: halves -> even / odd frames
+                    tb = g(f"{p}.time_conv.bias").to(BF16)
+                    for half in (0, 1):
+                        W[f"{p}.time_conv.w{half}"] = _repack_conv(tw[half * c:(half + 1) * c])
+                        W[f"{p}.time_conv.b{half}"] = tb[half * c:(half + 1) * c].contiguous()
+        W["decoder.head.0.gamma"] = g("decoder.head.0.gamma").reshape(-1).to(BF16).contiguous()
+        W["decoder.head.2.w"] = _repack_conv(g("decoder.head.2.weight"))
+        W["decoder.head.2.b"] = g("decoder.head.2.bias").to(BF16).contiguous()
+        self.W = W
+
     def _upsample(self, kind: str, p: str, x: torch.Tensor) -> torch.Tensor:
         t, h, w, c = x.shape
         if kind == "up3d":
@@ -358,17 +422,148 @@ class HipWanVAEDecoder:
         return out
 
 
+class HipWanVAEEncoder(_VaeLayers):
+    """`Encoder3d` + `conv1` of `WanVAE_` (vae.py:264-377, 512-541): the start frames of image-to-video, once per request.
+    Not a throughput path, so it reuses the decoder's kernels as they are: the stride-2 `Conv2d` behind `ZeroPad2d((0,1,0,1))`
+    (vae.py:91-94) is the pad-1 stride-1 convolution sampled at the odd positions (`y[1::2, 1::2]`, computed at full
+    resolution and sliced — 4x the arithmetic of a strided kernel, on a handful of frames), and the stride-2 temporal conv of
+    `downsample3d` (vae.py:98-99, 143-156) is one launch per output frame with its three input frames named in the slot table."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, dim: int = 96, z_dim: int = 16,
+                 dim_mult: Sequence[int] = (1, 2, 4, 4), num_res_blocks: int = 2,
+                 temperal_downsample: Sequence[bool] = (False, True, True), device="cuda"):
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, tuple(dim_mult)
+        self.num_res_blocks = num_res_blocks
+        self.temperal_downsample = tuple(temperal_downsample)
+        self._init_layers(device, 1)                       # rings hold the 4-frame chunks of `encode` (cap = 4 x max_frames)
+        self.plan = self._plan()
+        self._load(state_dict)
+        self._last: Dict[str, torch.Tensor] = {}           # last frame in front of each temporal downsampler
+
+    def _plan(self) -> List[tuple]:                         # vae.py:283-316
+        dims = [self.dim * u for u in [1] + list(self.dim_mult)]
+        plan, n = [], 0
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(self.num_res_blocks):
+                plan.append(("res", f"encoder.downsamples.{n}", cin, cout))
+                cin = cout
+                n += 1
+            if i != len(self.dim_mult) - 1:
+                plan.append(("down3d" if self.temperal_downsample[i] else "down2d", f"encoder.downsamples.{n}", cout))
+                n += 1
+        top = dims[-1]
+        self.top = top
+        return plan + [("res", "encoder.middle.0", top, top), ("attn", "encoder.middle.1", top), ("res", "encoder.middle.2", top, top)]
+
+    def _load(self, sd: Dict[str, torch.Tensor]) -> None:
+        dev = self.device
+        g = lambda k: sd[k].to(dev)
+        W: Dict[str, torch.Tensor] = {}
+        W["conv1.w"] = _repack_conv(g("conv1.weight"))
+        W["conv1.b"] = g("conv1.bias").to(BF16).contiguous()
+        W["encoder.conv1.w"] = _repack_conv(g("encoder.conv1.weight"), 32)       # RGB padded to one 32-channel chunk
+        W["encoder.conv1.b"] = g("encoder.conv1.bias").to(BF16).contiguous()
+        for item in self.plan:
+            kind, p = item[0], item[1]
+            if kind == "res":
+                self._load_res(W, g, p, item[2], item[3])
+            elif kind == "attn":
+                self._load_attn(W, g, p, item[2])
+            else:
+                W[f"{p}.resample.w"] = _repack_conv(g(f"{p}.resample.1.weight"))
+                W[f"{p}.resample.b"] = g(f"{p}.resample.1.bias").to(BF16).contiguous()
+                if kind == "down3d":
+                    W[f"{p}.time_conv.w"] = _repack_conv(g(f"{p}.time_conv.weight"))
+                    W[f"{p}.time_conv.b"] = g(f"{p}.time_conv.bias").to(BF16).contiguous()
+        W["encoder.head.0.gamma"] = g("encoder.head.0.gamma").reshape(-1).to(BF16).contiguous()
+        W["encoder.head.2.w"] = _repack_conv(g("encoder.head.2.weight"))
+        W["encoder.head.2.b"] = g("encoder.head.2.bias").to(BF16).contiguous()
+        self.W = W
+
+    def clear_cache(self) -> None:
+        super().clear_cache()
+        self._last.clear()
+
+    def _downsample(self, kind: str, p: str, x: torch.Tensor) -> torch.Tensor:
+        t, h, w, c = x.shape
+        full = self._tmp(p + ".full", t, h, w, c)
+        ops.conv3d_cl(x, list(range(t)), self.W[p + ".resample.w"], self.W[p + ".resample.b"], kt=1, ks=3, y=full,
+                      out_slots=list(range(t)))
+        x = full[:, 1::2, 1::2].contiguous()
+        if kind == "down3d":
+            last = self._last.get(p)
+            if last is None:                                     # first chunk: no temporal conv (vae.py:146-148)
+                self._last[p] = x[-1:].clone()
+            else:
+                seq = torch.cat([last, x], 0)                    # [1 + t, h/2, w/2, c]
+                n_out = (t - 2) // 2 + 1
+                y = self._tmp(p + ".tc", n_out, x.shape[1], x.shape[2], c)
+                for j in range(n_out):
+                    ops.conv3d_cl(seq, [2 * j, 2 * j + 1, 2 * j + 2], self.W[p + ".time_conv.w"], self.W[p + ".time_conv.b"],
+                                  kt=3, ks=1, y=y, out_slots=[j])
+                self._last[p] = x[-1:].clone()
+                x = y
+        return x
+
+    def _encoder_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """`Encoder3d.forward` (vae.py:318-377) on a chunk `[t, H, W, 32]` (RGB in the first three channels)."""
+        t, h, w, _ = x.shape
+        x = self._causal_conv("encoder.conv1", x, None, self._tmp("conv1.out", t, h, w, self.dim))
+        for item in self.plan:
+            if item[0] == "res":
+                x = self._res(item[1], x, item[2], item[3])
+            elif item[0] == "attn":
+                x = self._attn(item[1], x)
+            else:
+                x = self._downsample(item[0], item[1], x)
+        t, h, w, _ = x.shape
+        out = self._tmp("head.out", t, h, w, 2 * self.z_dim)
+        return self._causal_conv("encoder.head.2", x, "encoder.head.0.gamma", out)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """vae.py:512-541: `[1, 3, T, H, W]` (T = 1 + 4k) -> normalised mu `[1, z, 1 + k, H/8, W/8]` in the input dtype."""
+        assert x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3, tuple(x.shape)
+        self.clear_cache()
+        x = x.to(self.device)
+        T, H, Wd = x.shape[2:]
+        xc = torch.zeros(T, H, Wd, 32, dtype=BF16, device=self.device)
+        xc[..., :3] = x[0].permute(1, 2, 3, 0)
+        outs = [self._encoder_frames(xc[:1]).clone()]
+        for i in range(1, 1 + (T - 1) // 4):
+            outs.append(self._encoder_frames(xc[1 + 4 * (i - 1):1 + 4 * i]).clone())
+        out = torch.cat(outs, 0)                                          # [T', h, w, 2z]
+        t2 = out.shape[0]
+        mu32 = self._tmp("conv1x1.out", t2, out.shape[1], out.shape[2], 2 * self.z_dim)
+        ops.conv3d_cl(out, list(range(t2)), self.W["conv1.w"], self.W["conv1.b"], kt=1, ks=1, y=mu32, out_slots=list(range(t2)))
+        mu = mu32[..., :self.z_dim].permute(3, 0, 1, 2).unsqueeze(0).to(x.dtype)
+        scale0 = self.mean.to(x.dtype).view(1, -1, 1, 1, 1)
+        scale1 = (1.0 / self.std.to(x.dtype)).view(1, -1, 1, 1, 1)
+        mu = (mu - scale0) * scale1                                       # vae.py:533-538, wrapper.py:91-92
+        self.clear_cache()
+        return mu
+
+
 class HipWanVAEWrapper:
-    """The decode half of `WanVAEWrapper` (wrapper.py:62-168): `decode_to_pixel(latent, use_cache, chunk_size)` and
-    `.model.clear_cache()`, so that the pipelines' `vae=` seam takes it unchanged.  Encoding (image-to-video start frames)
-    is not on the hot path and is not built: pass the reference's wrapper for that."""
+    """`WanVAEWrapper` (wrapper.py:62-168): `decode_to_pixel(latent, use_cache, chunk_size)`, `encode_to_latent(pixel)` and
+    `.model.clear_cache()`, so that the pipelines' `vae=` seam takes it unchanged.  The encoder is built lazily from the same
+    state dict on the first `encode_to_latent` (text-to-video never needs it)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, device="cuda", max_frames_per_call: int = 3, **cfg):
         self.model = HipWanVAEDecoder(state_dict, device=device, max_frames_per_call=max_frames_per_call, **cfg)
+        self._encoder: Optional[HipWanVAEEncoder] = None
+        self._enc_args = (state_dict, device, cfg)
 
+    @torch.no_grad()
     def encode_to_latent(self, pixel: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("HipWanVAEWrapper decodes only (SURVEY.md §8(f)1); the encoder runs once per request, "
-                                  "use the reference's WanVAEWrapper for image-to-video start frames")
+        """pixel `[B, 3, T, H, W]` in [-1, 1] -> latent `[B, 1 + (T-1)/4, 16, H/8, W/8]` float32 (wrapper.py:88-101)."""
+        if self._encoder is None:
+            sd, device, cfg = self._enc_args
+            if "encoder.conv1.weight" not in sd:
+                raise RuntimeError("HipWanVAEWrapper.encode_to_latent: the state dict has no encoder.* weights")
+            self._encoder = HipWanVAEEncoder(sd, device=device, **cfg)
+        out = [self._encoder.encode(u.unsqueeze(0)).float().squeeze(0) for u in pixel]
+        return torch.stack(out, dim=0).permute(0, 2, 1, 3, 4)
 
     @torch.no_grad()
     def decode_to_pixel(self, latent: torch.Tensor, use_cache: bool = False, chunk_size: int = 2) -> torch.Tensor:

@@ -83,6 +83,31 @@ def main():
     multi = orc.cached_decode(z, frames_per_call=2).float().clamp_(-1, 1)
     print("  oracle, 2 latent frames per call vs 1:", (multi.permute(0, 2, 1, 3, 4) - ref_all).abs().max().item())
 
+    # ---- encoder: the reference's encode() on a 5-frame and a 1-frame (image-to-video) clip
+    enc_seed = 4343
+    EW = V.make_encoder_params(cfg, enc_seed)
+    model2 = vae.WanVAE_(dim=cfg.dim, z_dim=cfg.z_dim, dim_mult=list(cfg.dim_mult), num_res_blocks=cfg.num_res_blocks,
+                         attn_scales=[], temperal_downsample=list(cfg.temperal_downsample), dropout=0.0).eval()
+    model2.load_state_dict({k: v.float() for k, v in {**W, **EW}.items()}, strict=True)
+    model2 = model2.to(BF)
+    video = (torch.rand(1, 3, 5, 64, 96, generator=g) * 2 - 1).to(BF)
+    mean = torch.tensor(V.VAE_MEAN, dtype=torch.float32)
+    std = torch.tensor(V.VAE_STD, dtype=torch.float32)
+    scale = [mean.to(BF), 1.0 / std.to(BF)]
+    ref_lat = torch.stack([model2.encode(u.unsqueeze(0), scale).float().squeeze(0) for u in video]).permute(0, 2, 1, 3, 4)
+    ref_img = torch.stack([model2.encode(u[:, :1].unsqueeze(0), scale).float().squeeze(0) for u in video]).permute(0, 2, 1, 3, 4)
+    eorc = V.VaeEncoderOracle(cfg, EW)
+    for name, ref, x in (("5 frames", ref_lat, video), ("1 frame", ref_img, video[:, :, :1])):
+        mine = eorc.encode_to_latent(x)
+        d = (mine - ref).abs().max().item()
+        print(f"  encoder oracle vs reference [{name}]: shape {tuple(ref.shape)} max diff {d:.3e}, std {ref.std():.3f}")
+        if d != 0.0:
+            raise SystemExit("encoder oracle disagrees with the reference")
+    save_npz(os.path.join(GOLDEN_DIR, "vae_encode.npz"), {
+        "cfg_dim": cfg.dim, "seed": enc_seed, "weights_checksum": weights_checksum(EW), "video": video, "latent": ref_lat,
+        "latent_first_frame": ref_img})
+    print("wrote tests/golden/vae_encode.npz")
+
     save_npz(os.path.join(GOLDEN_DIR, "vae_decode.npz"), {
         "cfg_dim": cfg.dim, "seed": seed, "weights_checksum": weights_checksum(W), "latent": latent, "pixels": ref_all,
         "pixels_std": float(ref_all.std())})

@@ -13,7 +13,10 @@ runs the VAE under `model.to(dtype=torch.bfloat16)`, inferix/pipeline/self_forci
   * `CausalConv3d.forward`                   vae.py:26-34     (two frames of causal padding, shortened by the cache)
   * `RMS_norm.forward`                       vae.py:52-55
 
-Pinned by `oracle/gen_golden_vae.py` against the reference's own `WanVAE_` run on CPU (tests/golden/vae_decode.npz).
+  * encoder (image-to-video start frames): `WanVAEWrapper.encode_to_latent` wrapper.py:88-101, `WanVAE_.encode` vae.py:512-541
+    (chunks of 1, 4, 4, ... frames), `Encoder3d.forward` vae.py:318-377, `Resample` downsample2d/3d vae.py:91-100, 143-156.
+
+Pinned by `oracle/gen_golden_vae.py` against the reference's own `WanVAE_` run on CPU (tests/golden/vae_decode.npz, vae_encode.npz).
 
 The feature cache is restated as "the last two input frames of every causal conv" keyed by layer name instead of the
 reference's positional list; `None` = nothing cached yet, `REP` = the first-chunk marker of the temporal upsamplers.
@@ -263,4 +266,142 @@ class VaeDecoderOracle:
                 dec = torch.cat(parts, dim=1)
                 self.clear_cache()
             out.append(dec)
+        return torch.stack(out, dim=0).permute(0, 2, 1, 3, 4)
+
+
+# ==================================================================================================================
+# Encoder (vae.py:264-377, 512-541)
+# ==================================================================================================================
+def encoder_plan(cfg: VaeConfig) -> List[tuple]:
+    """Execution order of `Encoder3d` (vae.py:283-316): ('res', prefix, cin, cout) | ('down2d' | 'down3d', prefix, c) | ('attn', prefix, c)."""
+    dims = [cfg.dim * u for u in [1] + list(cfg.dim_mult)]
+    plan, n = [], 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(cfg.num_res_blocks):
+            plan.append(("res", f"encoder.downsamples.{n}", cin, cout))
+            cin = cout
+            n += 1
+        if i != len(cfg.dim_mult) - 1:
+            plan.append(("down3d" if cfg.temperal_downsample[i] else "down2d", f"encoder.downsamples.{n}", cout))
+            n += 1
+    top = dims[-1]
+    plan += [("res", "encoder.middle.0", top, top), ("attn", "encoder.middle.1", top), ("res", "encoder.middle.2", top, top)]
+    return plan
+
+
+def encoder_param_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
+    z2 = 2 * cfg.z_dim
+    s: Dict[str, Tuple[int, ...]] = {"conv1.weight": (z2, z2, 1, 1, 1), "conv1.bias": (z2,),
+                                     "encoder.conv1.weight": (cfg.dim, 3, 3, 3, 3), "encoder.conv1.bias": (cfg.dim,)}
+    last = cfg.dim
+    for item in encoder_plan(cfg):
+        kind, p = item[0], item[1]
+        if kind == "res":
+            cin, cout = item[2], item[3]
+            s[f"{p}.residual.0.gamma"] = (cin, 1, 1, 1)
+            s[f"{p}.residual.2.weight"] = (cout, cin, 3, 3, 3)
+            s[f"{p}.residual.2.bias"] = (cout,)
+            s[f"{p}.residual.3.gamma"] = (cout, 1, 1, 1)
+            s[f"{p}.residual.6.weight"] = (cout, cout, 3, 3, 3)
+            s[f"{p}.residual.6.bias"] = (cout,)
+            if cin != cout:
+                s[f"{p}.shortcut.weight"] = (cout, cin, 1, 1, 1)
+                s[f"{p}.shortcut.bias"] = (cout,)
+            last = cout
+        elif kind == "attn":
+            c = item[2]
+            s[f"{p}.norm.gamma"] = (c, 1, 1)
+            s[f"{p}.to_qkv.weight"] = (3 * c, c, 1, 1)
+            s[f"{p}.to_qkv.bias"] = (3 * c,)
+            s[f"{p}.proj.weight"] = (c, c, 1, 1)
+            s[f"{p}.proj.bias"] = (c,)
+        else:
+            c = item[2]
+            s[f"{p}.resample.1.weight"] = (c, c, 3, 3)
+            s[f"{p}.resample.1.bias"] = (c,)
+            if kind == "down3d":
+                s[f"{p}.time_conv.weight"] = (c, c, 3, 1, 1)
+                s[f"{p}.time_conv.bias"] = (c,)
+    s["encoder.head.0.gamma"] = (last, 1, 1, 1)
+    s["encoder.head.2.weight"] = (z2, last, 3, 3, 3)
+    s["encoder.head.2.bias"] = (z2,)
+    return s
+
+
+def make_encoder_params(cfg: VaeConfig, seed: int) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic encoder weights (bf16), same recipe as `make_decoder_params`."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for name, shape in encoder_param_shapes(cfg).items():
+        if name.endswith("gamma"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+        W[name] = t.to(BF)
+    return W
+
+
+class VaeEncoderOracle(VaeDecoderOracle):
+    """`Encoder3d` + `WanVAE_.encode` with the streaming cache; reuses the residual / attention / cached-conv restatements."""
+
+    def __init__(self, cfg: VaeConfig, W: Dict[str, torch.Tensor], dtype=BF):
+        self.cfg, self.dtype = cfg, dtype
+        self.W = {k: v.to(dtype) for k, v in W.items()}
+        self.plan = encoder_plan(cfg)
+        self.mean = torch.tensor(VAE_MEAN[:cfg.z_dim], dtype=torch.float32)
+        self.std = torch.tensor(VAE_STD[:cfg.z_dim], dtype=torch.float32)
+        self.clear_cache()
+
+    def _downsample(self, kind: str, p: str, x: torch.Tensor) -> torch.Tensor:
+        b, c, t, h, w = x.shape
+        y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        y = F.conv2d(F.pad(y, (0, 1, 0, 1)), self.W[p + ".resample.1.weight"], self.W[p + ".resample.1.bias"], stride=2)   # vae.py:91-94
+        x = y.reshape(b, t, c, y.shape[-2], y.shape[-1]).permute(0, 2, 1, 3, 4)
+        if kind == "down3d":                                                      # vae.py:143-156
+            name = p + ".time_conv"
+            old = self.cache.get(name)
+            if old is None:
+                self.cache[name] = x.clone()
+            else:
+                cache_x = x[:, :, -1:].clone()
+                x = F.conv3d(torch.cat([old[:, :, -1:], x], 2), self.W[name + ".weight"], self.W[name + ".bias"], stride=(2, 1, 1))
+                self.cache[name] = cache_x
+        return x
+
+    def encoder_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """`Encoder3d.forward` on a chunk `[1, 3, t, H, W]`."""
+        x = self._cached_conv("encoder.conv1", x)
+        for item in self.plan:
+            if item[0] == "res":
+                x = self._res(item[1], x, item[2], item[3])
+            elif item[0] == "attn":
+                x = self._attn(item[1], x)
+            else:
+                x = self._downsample(item[0], item[1], x)
+        x = F.silu(rms_norm(x, self.W["encoder.head.0.gamma"]))
+        return self._cached_conv("encoder.head.2", x)
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """vae.py:512-541: `[1, 3, T, H, W]` (T = 1 + 4k) -> normalised mu `[1, z, 1 + k, H/8, W/8]`."""
+        self.clear_cache()
+        T = x.shape[2]
+        outs = [self.encoder_frames(x[:, :, :1])]
+        for i in range(1, 1 + (T - 1) // 4):
+            outs.append(self.encoder_frames(x[:, :, 1 + 4 * (i - 1):1 + 4 * i]))
+        out = torch.cat(outs, 2)
+        mu, _ = causal_conv3d(out, self.W["conv1.weight"], self.W["conv1.bias"], None).chunk(2, dim=1)
+        scale0 = self.mean.to(x.dtype).view(1, -1, 1, 1, 1)
+        scale1 = (1.0 / self.std.to(x.dtype)).view(1, -1, 1, 1, 1)
+        mu = (mu - scale0) * scale1
+        self.clear_cache()
+        return mu
+
+    def encode_to_latent(self, pixel: torch.Tensor) -> torch.Tensor:
+        """wrapper.py:88-101: pixel `[B, 3, T, H, W]` -> latent `[B, T', z, H/8, W/8]` float32."""
+        out = [self.encode(u.unsqueeze(0)).float().squeeze(0) for u in pixel]
         return torch.stack(out, dim=0).permute(0, 2, 1, 3, 4)

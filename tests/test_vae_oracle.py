@@ -64,3 +64,19 @@ def test_host_synthetic_state_dict_has_the_reference_keys():
         sd = synthetic_decoder_state_dict(dim=dim)
         shapes = V.decoder_param_shapes(V.VaeConfig(dim=dim))
         assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+
+
+def test_encoder_oracle_matches_reference_golden():
+    g = golden("vae_encode.npz")
+    cfg = V.VaeConfig(dim=int(g["cfg_dim"]))
+    EW = V.make_encoder_params(cfg, int(g["seed"]))
+    assert weights_checksum(EW) == int(g["weights_checksum"])
+    orc = V.VaeEncoderOracle(cfg, EW)
+    assert torch.equal(orc.encode_to_latent(g["video"]), g["latent"])                       # 5 frames -> 2 latent frames
+    assert torch.equal(orc.encode_to_latent(g["video"][:, :, :1]), g["latent_first_frame"])  # the image-to-video case
+    assert tuple(g["latent"].shape) == (1, 2, 16, 8, 12)
+    from inferix_amd.vae import synthetic_encoder_state_dict
+    for dim in (32, 96):
+        sd = synthetic_encoder_state_dict(dim=dim)
+        shapes = V.encoder_param_shapes(V.VaeConfig(dim=dim))
+        assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)
