@@ -334,3 +334,44 @@ def test_encoder_downsamplers_teacher_forced():
             ref = orc._downsample(kind, p, x)
             got = enc._downsample(kind, p, cl(x).cuda())
             assert_bf16_parity(got.cpu(), cl(ref), max_ulp=1, floor=1.0, what=f"{kind} {h}x{w} chunk of {t}")
+
+
+def test_all_hip_image_to_video(tmp_path):
+    """Image-to-video through the plugin class with nothing but HIP components on the data path: the start image goes through
+    `HipWanVAEWrapper.encode_to_latent`, becomes the first latent frame (prefilled at t = 0, `independent_first_frame`), three
+    more frames are denoised behind it and the clip is decoded: 4 latent frames -> 13 video frames."""
+    import yaml
+    import wan_oracle as O
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.pipeline import SelfForcingPipeline
+    from inferix_amd.vae import HipWanVAEWrapper
+    vcfg = V.VaeConfig(dim=32)
+    VW = {**V.make_decoder_params(vcfg, 4242), **V.make_encoder_params(vcfg, 4343)}
+    vae = HipWanVAEWrapper(VW, dim=vcfg.dim)
+    cfg = O.tiny_config()
+    conf = dict(denoising_step_list=[1000, 500], warp_denoising_step=True, num_frame_per_block=3, independent_first_frame=True,
+                context_noise=0, timestep_shift=5.0, kv_cache_tokens=22 * cfg.frame_seqlen,
+                latent_shape=[cfg.in_dim, cfg.latent_h, cfg.latent_w],
+                model_kwargs=dict(patch_size=list(cfg.patch_size), text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
+                                  ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
+                                  num_heads=cfg.num_heads, num_layers=cfg.num_layers, eps=cfg.eps))
+    path = tmp_path / "sf_i2v.yaml"
+    path.write_text(yaml.safe_dump(conf))
+    pe = torch.randn(1, cfg.text_len, cfg.text_dim, generator=torch.Generator().manual_seed(5)).to(BF).cuda()
+    pipe = SelfForcingPipeline(str(path), text_encoder=lambda text_prompts: {"prompt_embeds": pe.expand(len(text_prompts), -1, -1)},
+                               vae=vae)
+    W = O.init_weights(cfg, seed=0)
+    ck = tmp_path / "ckpt.pt"
+    torch.save({"generator": {"model." + k: v for k, v in W.items()}}, ck)
+    pipe.load_checkpoint(str(ck), use_ema=False)
+    pipe.setup_devices(low_memory=False, verbose=False)
+    image = (torch.rand(1, 3, 1, 8 * cfg.latent_h, 8 * cfg.latent_w, generator=torch.Generator().manual_seed(8)) * 2 - 1).to(BF)
+    torch.manual_seed(4)
+    video = pipe.run_image_to_video(["a prompt"], None, num_output_frames=4, image=image.cuda())
+    assert video.shape == (1, 13, 3, 8 * cfg.latent_h, 8 * cfg.latent_w) and torch.isfinite(video).all()
+    # the first latent frame of the clip IS the encoded image: decoding it alone reproduces the clip's first video frame
+    lat0 = vae.encode_to_latent(image.cuda()).to(BF)
+    first = (vae.decode_to_pixel(lat0.cuda(), use_cache=True, chunk_size=1) * 0.5 + 0.5).clamp(0, 1)
+    assert torch.equal(video[:, :1].float().cpu(), first.float().cpu())
+    ref0 = V.VaeEncoderOracle(vcfg, VW).encode_to_latent(image)
+    assert rel_l2(lat0.float().cpu(), ref0) < 2e-2
