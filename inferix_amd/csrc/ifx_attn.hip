@@ -390,7 +390,7 @@ int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsi
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
 int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt);
 // wave groups of the multi-wave kernel for a launch: 3 (384-row tiles) when variant 3 is forced or chosen, else 2
-static int attn_groups(int variant) { return variant == 3 ? 3 : 2; }
+static int attn_groups(int variant) { return variant == 3 ? 3 : (variant == 4 ? 4 : 2); }
 
 }  // namespace ifx
 
@@ -459,7 +459,7 @@ extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv
                                        int64_t* workspace_bytes) {
   int splits = 1;
   if (q_rows > 0 && heads > 0 && kv_len > kv_start)
-    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, 128 * attn_groups(attn_variant()));
+    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_variant() == 3 ? 384 : 256);
   if (workspace_bytes) *workspace_bytes = (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits);
   return splits;
 }

@@ -41,6 +41,9 @@
 #ifndef PP_PRIO
 #define PP_PRIO 2      // 1: raised priority around the MFMA step, 2: around the softmax step (measured best)
 #endif
+#ifndef PP_RING
+#define PP_RING 6      // fragment-ring slots of the MFMA steps with two waves per SIMD (reads PP_RING - 1 batches ahead)
+#endif
 #ifndef PP_GROUP
 #define PP_GROUP 0     // 0: groups = waves 0-3 / 4-7 (waves w, w+4 share a SIMD); 1: even / odd waves
 #endif
@@ -127,7 +130,10 @@ __device__ __forceinline__ void pp_wait_tiles(int tiles) {
 // ~15 cycles, TWO other waves get one every ~8 (tools/probe_overlap.hip).  The softmax of a tile is ~110 VALU
 // instructions against 32 MFMAs (1024 cycles): with one softmax wave per SIMD the step takes ~2000 cycles and the
 // matrix pipe idles half the time (step trace, tools/trace_attn.sh); with two it fits in two MFMA steps.
-template <bool PAGED, bool SPLIT, int NG>
+// FR = 1: free-running schedule (attn_variant 4): every wave runs QK(t) -> softmax(t) -> PV(t) for its own 32 queries with ONE
+// workgroup barrier per tile and no phase assignment — the two waves of a SIMD drift apart by themselves, the older one takes
+// the matrix pipe first and its softmax then overlaps with the younger wave's MFMAs (tools/probe_roles.hip).
+template <bool PAGED, bool SPLIT, int NG, int FR = 0>
 __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   using namespace pp;
   constexpr int QT = 128 * NG;
@@ -227,7 +233,11 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   f32x16 s[2];
   bf16x8 pb[2][2];
   bf16x8 fA[4], fB[4];     // drain only
-  bf16x8 fr[3][2];         // operand-fragment ring of step M
+  // operand-fragment ring of the MFMA steps: RD slots of two fragments, LDS reads issued LA = RD - 1 batches (2 LA MFMAs) ahead.
+  // Three groups (three waves per SIMD, 170 VGPRs) can afford three slots; with two waves per SIMD six slots fit, and the
+  // step trace shows why they are needed: with reads two batches ahead every MFMA still waited for its own LDS round trip.
+  constexpr int RD = NG == 3 ? 3 : PP_RING, LA = RD - 1;
+  bf16x8 fr[RD][2];
   pb[0][0] = pb[0][1] = pb[1][0] = pb[1][1] = bf16x8{};      // P(-1) = 0 for the unconditional PV of tile 0
   if (PP_ABLATE) {
 #pragma unroll
@@ -261,12 +271,11 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   //      which is what did not fit next to O (64) + Q (32) + S (32) at three waves per SIMD.)
   //        PV batch j = (block b = j>>2, k-slot s2 = (j>>1)&1, d pair dh = j&1)     j = 0..7
   //        QK batch j = (block b = j>>2, k-steps 2*(j&3), 2*(j&3)+1)                 j = 0..7
-  auto stepM = [&](int t) {
+  // phase: 0 = everything, 1 = only the first LA fragment reads (issued ahead of time), 2 = the rest (reads already issued)
+  auto stepJ = [&](int t, int vt, auto j0c, auto j1c, auto phasec) {   // batches [J0, J1) of the list below, K from tile t, V from tile vt
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value, PHASE = decltype(phasec)::value;
     const unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
-    // PV(t-1).  At t == 0 there is no previous tile: P is all zero and the V fragments are read from tile 0, whose
-    // DMA has landed — O += V^T * 0.  Unconditional on purpose: a branch here made the O accumulators a phi and
-    // cost 32 v_mov_b64 per tile.
-    const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
+    const unsigned char* vb = smem + V_OFF + (vt % RV) * 16384;
     // lane-derived address terms are RECOMPUTED here from an opaque lane id (a handful of VALU ops): kept live across
     // the loop they were spilled at three waves per SIMD, and a scratch reload drains the DMA queue (shared vmcnt)
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
     auto load = [&](int j) {
       if (PP_ABLATE & 4) return;
-      bf16x8(&f)[2] = fr[j % 3];
+      bf16x8(&f)[2] = fr[j % RD];
       if (j < 8) {
         const int bb = j >> 2, s2 = (j >> 1) & 1, dh = j & 1;
         const unsigned char* vr0 = vb + (32 * bb + 16 * s2 + 4 * hi + v_rowq) * 256 + v_in;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     };
     auto mma = [&](int j) {
       if (PP_ABLATE & 8) return;
-      bf16x8(&f)[2] = fr[j % 3];
+      bf16x8(&f)[2] = fr[j % RD];
       if (j < 8) {
         const int bb = j >> 2, s2 = (j >> 1) & 1, dh = j & 1;
 #pragma unroll
@@ -313,15 +322,30 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
         for (int e = 0; e < 2; ++e) s[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], s[bb], 0, 0, 0);
       }
     };
-    load(0);
-    load(1);
+    if (PHASE != 2) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+      for (int j = J0; j < J0 + LA && j < J1; ++j) load(j);
+    }
+    if (PHASE == 1) return;
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
       PP_SB();
-      if (j + 2 < 16) load(j + 2);
+      if (j + LA < J1) load(j + LA);
       mma(j);
     }
   };
+  // PV(t-1) + QK(t).  At t == 0 there is no previous tile: P is all zero and the V fragments are read from tile 0, whose
+  // DMA has landed — O += V^T * 0.  Unconditional on purpose: a branch here made the O accumulators a phi and cost
+  // 32 v_mov_b64 per tile.
+  using ic0 = std::integral_constant<int, 0>;
+  using ic1 = std::integral_constant<int, 1>;
+  using ic2 = std::integral_constant<int, 2>;
+  using ic8 = std::integral_constant<int, 8>;
+  using ic16 = std::integral_constant<int, 16>;
+  auto stepM = [&](int t) { stepJ(t, t > 0 ? t - 1 : 0, ic0{}, ic16{}, ic0{}); };
+  auto stepQK = [&](int t) { stepJ(t, 0, ic8{}, ic16{}, ic0{}); };
+  auto prePV = [&](int t) { stepJ(t, t, ic0{}, ic8{}, ic1{}); };        // first V fragments, issued before the softmax
+  auto stepPV = [&](int t) { stepJ(t, t, ic0{}, ic8{}, ic2{}); };
 
   // ---- step V(t): online softmax of the 64-key tile; P -> pb (bf16), in-place rescale of O when a max grew.
   //      Two halves (one per 32-key block of exponentials) so that the three-group schedule can put a phase
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   auto stepV1 = [&](int t) {
     // DMA of tile t+PD is issued HERE: an LDS-DMA instruction costs its issuing wave ~100+ cycles, which a
     // VALU step can afford and the MFMA step cannot
-    if (loader && t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+    if (!FR && loader && t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
     if (t == NT - 1 && (nkeys & (KT - 1))) {     // ragged last tile (wave-uniform, executed once)
       const int kidx = t * KT + 4 * hi;
 #pragma unroll
@@ -420,7 +444,44 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   for (int i = 0; i < PD; ++i)
     if (loader && i < NT) issue(i);
 
-  if (NG == 2) {
+  if (FR) {
+    for (int t = 0; t < NT; ++t) {
+      long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
+      pp_wait_tiles(min(NT - 1 - t, PD - 1));          // own pieces of tile t landed (t+1 may stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_barrier();                    // tile t complete for everyone; everyone is done with tile t-1
+      if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
+      // an LDS-DMA instruction stalls its issuing wave for ~100 cycles: the older wave of each SIMD issues its pieces now,
+      // while the younger one starts the matrix pipe, and the younger one after its QK, while the older one computes
+      if (wave < 4 && t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+      if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
+      stepQK(t);
+      if (wave >= 4 && t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+      prePV(t);
+      if (PP_TRACE) {
+        asm volatile("" ::"v"(s[1][15]));
+        tr[4] = __builtin_readcyclecounter();
+      }
+      if (!(PP_ABLATE & 2)) {
+        stepV1(t);
+        stepV2(t);
+      }
+      if (PP_TRACE) {
+        asm volatile("" ::"v"(l_run), "v"(pb[1][1]));
+        tr[5] = __builtin_readcyclecounter();
+      }
+      stepPV(t);
+      if (PP_TRACE && t < 64 && lane == 0) {
+        asm volatile("" ::"v"(o[3][15]));
+        long long* tp = reinterpret_cast<long long*>(smem + LDS_BYTES) + (t * 8 + wave) * 8;
+        tr[6] = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tp[i] = tr[i];
+      }
+    }
+  } else if (NG == 2) {
     // barrier index :   2t            2t+1          2t+2
     // G0            :   M(t)          V(t)          M(t+1)
     // G1            :   V(t-1)        M(t)          V(t)
@@ -515,7 +576,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     for (int i = tid; i < 64 * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
   }
   // ---- drain: PV of the last tile
-  {
+  if (!FR) {
     const unsigned char* vb = smem + V_OFF + ((NT - 1) % RV) * 16384;
     ldV(fA, vb, 0, 0);
     ldV(fB, vb, 0, 1);
@@ -612,6 +673,26 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt) {
   return best;
 }
 
+static void launch_pp_fr(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
+  using namespace pp;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    attr_set = true;
+  }
+  const dim3 block(512);
+  if (split) {
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 2, 1>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 2, 1>), grid, block, LDS_ALLOC, stream, a);
+  } else {
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2, 1>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 2, 1>), grid, block, LDS_ALLOC, stream, a);
+  }
+}
+
 template <int NG>
 static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   using namespace pp;
@@ -633,7 +714,7 @@ static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid,
   }
 }
 
-// groups: 2 = ping-pong (256 query rows per workgroup), 3 = three-phase (384 rows).
+// groups: 2 = ping-pong (256 query rows per workgroup), 3 = three-phase (384 rows), 4 = free-running (256 rows).
 // slot_cap == 0: self-contained launch (partials in slots [0, splits) of `workspace`, merged here when splits > 1).
 // slot_cap  > 0: PARTIAL launch for a workspace laid out for slot_cap slots: always writes fp32 partials, into slots
 //                [slot_base, slot_base + splits), no merge; *slots_used reports how many chunks were written.
@@ -641,6 +722,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
                    hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr) {
   using namespace pp;
+  const bool free_running = groups == 4;           // attn_variant 4: two groups' worth of waves, free-running schedule
+  if (free_running) groups = 2;
   const int QT = 128 * groups;
   AttnArgsPP a;
   a.q = q;
@@ -680,7 +763,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
     set_error("ifx_attn_fwd_paged_split: split / partial launches need a workspace");
     return IFX_EINVAL;
   }
-  if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, write_partials, grid, stream);
+  if (free_running) launch_pp_fr(a, kv->page_table != nullptr, write_partials, grid, stream);
+  else if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, write_partials, grid, stream);
   else launch_pp_ng<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
   if (slots_used) *slots_used = a.splits;
   if (!partial && a.splits > 1) {

@@ -216,6 +216,7 @@ int main() {
   T(2, 1) T(6, 0) T(6, 2) T(7, 0) T(7, 2) T(2, 7)
   T(3, 1) T(4, 1) T(3, 7) T(2, 6)
   T(8, 0) T(9, 0) T(10, 0) T(8, 10) T(10, 8) T(8, 9) T(9, 8) T(8, 8)
+  T(6, 3) T(3, 6) T(6, 4) T(4, 6) T(6, 8) T(8, 6) T(9, 9) T(6, 6)
   time_prio<1, 2>(d, it, names);
   time_prio<1, 3>(d, it, names);
   time_prio<1, 4>(d, it, names);

@@ -23,18 +23,26 @@ q, k, v = rnd(4680, 12, 128), rnd(L, 12, 128), rnd(L, 12, 128)
 for _ in range(2):
     out, lse = ops.attention(q, ops.KvCacheView(k, v), L, return_lse=True, splits=1)
 torch.cuda.synchronize()
+FR = NG == 4
+if FR:
+    NG = 2
 W = 4 * NG
 tr = lse.reshape(-1).view(torch.int64)[:64 * W * 8].view(64, W, 8).cpu()
 import numpy as np
 np.set_printoptions(linewidth=200)
 t = tr.numpy().astype(np.int64)
-if NG == 2:
+if FR:
+    names = ["wait DMA      ", "barrier       ", "DMA issue     ", "QK            ", "softmax       ", "PV            "]
+elif NG == 2:
     names = ["wait DMA (G0) ", "barrier A     ", "M step        ", "wait DMA (G1) ", "barrier B     ", "V step        "]
 else:
     names = ["wait+barrier M", "M step        ", "barrier V1    ", "V1 (+DMA wait)", "barrier V2    ", "V2 step       "]
 print(f"mean cycles over tiles 8..56, per wave 0..{W-1} (waves w, w+4, w+8 share a SIMD)")
 for i, n in enumerate(names):
     print(n, (t[8:56, :, i + 1] - t[8:56, :, i]).mean(0).round(0))
+if FR:
+    print("one tile, absolute cycle stamps relative to wave 0's start (tile 20): rows = wave, cols = stamps")
+    print(t[20, :, :7] - t[20, 0, 0])
 print("tile period   ", (t[9:57, :, 0] - t[8:56, :, 0]).mean(0).round(0))
 PY
 fi
