@@ -390,7 +390,8 @@ int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsi
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
 int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt);
 // wave groups of the multi-wave kernel for a launch: 3 (384-row tiles) when variant 3 is forced or chosen, else 2
-static int attn_groups(int variant) { return variant == 3 ? 3 : (variant == 4 ? 4 : 2); }
+// 0 (auto) and 5: software-pipelined schedule; 2: phase-locked ping-pong; 3: three groups; 4: free-running
+static int attn_groups(int variant) { return variant == 3 ? 3 : (variant == 4 ? 4 : (variant == 2 ? 2 : 5)); }
 
 }  // namespace ifx
 
@@ -487,8 +488,8 @@ extern "C" int ifx_attn_fwd_partial(const ifx_bf16* q, const ifx_kv_view* kv, in
   IFX_REQUIRE(workspace_bytes >= (int64_t)slot_cap * q_rows * heads * 129 * (int64_t)sizeof(float),
               "ifx_attn_fwd_partial: workspace of %lld B too small for %d slots", (long long)workspace_bytes, slot_cap);
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_partial: page_size must be > 0");
-  return launch_attn_pp(q, nullptr, nullptr, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, 2,
-                        (hipStream_t)stream, slot_base, slot_cap, slots_used);
+  return launch_attn_pp(q, nullptr, nullptr, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace,
+                        attn_groups(attn_variant()), (hipStream_t)stream, slot_base, slot_cap, slots_used);
 }
 
 extern "C" int ifx_attn_merge_partials(const void* workspace, int32_t slot_cap, int32_t slots_used, ifx_bf16* out,

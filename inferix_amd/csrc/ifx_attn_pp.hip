@@ -60,7 +60,8 @@ constexpr int PD = PP_PD;
 constexpr int RK = PD + 1, RV = PD + 2;
 constexpr int K_OFF = 0, V_OFF = RK * 16384;
 constexpr int LDS_BYTES = (RK + RV) * 16384;   // 114688
-constexpr int LDS_ALLOC = LDS_BYTES + (PP_TRACE ? 49152 : 0);
+constexpr int LDS_SWP = 8 * 16384;              // software-pipelined schedule (FR = 2): 3 K tiles + 5 V tiles
+constexpr int LDS_ALLOC = PP_TRACE ? LDS_BYTES + 49152 : (LDS_BYTES > LDS_SWP ? LDS_BYTES : LDS_SWP);
 }  // namespace pp
 
 struct AttnArgsPP {
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   using namespace pp;
   constexpr int QT = 128 * NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // DMA prefetch distance and LDS rings of this schedule (FR = 2 reads K one tile ahead and V one tile behind)
+  constexpr int PD = FR == 2 ? 3 : pp::PD, RK = FR == 2 ? 3 : pp::RK, RV = FR == 2 ? 5 : pp::RV, V_OFF = RK * 16384;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = (NG == 2 && PP_GROUP) ? (wave & 1) : (wave >> 2);
@@ -234,9 +237,9 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   bf16x8 pb[2][2];
   bf16x8 fA[4], fB[4];     // drain only
   // operand-fragment ring of the MFMA steps: RD slots of two fragments, LDS reads issued LA = RD - 1 batches (2 LA MFMAs) ahead.
-  // Three groups (three waves per SIMD, 170 VGPRs) can afford three slots; with two waves per SIMD six slots fit, and the
-  // step trace shows why they are needed: with reads two batches ahead every MFMA still waited for its own LDS round trip.
-  constexpr int RD = NG == 3 ? 3 : PP_RING, LA = RD - 1;
+  // Three slots in the phase-locked schedules (deeper measured slower there: 992 -> 946 TFLOP/s); six in the free-running one,
+  // whose step trace showed every MFMA waiting for its own LDS round trip with reads only two batches ahead.
+  constexpr int RD = FR == 1 ? PP_RING : 3, LA = RD - 1;
   bf16x8 fr[RD][2];
   pb[0][0] = pb[0][1] = pb[1][0] = pb[1][1] = bf16x8{};      // P(-1) = 0 for the unconditional PV of tile 0
   if (PP_ABLATE) {
@@ -440,11 +443,203 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   };
 
   // ---- prologue: tiles 0 .. PD-1 in flight
+  if (FR != 2) {
 #pragma unroll
-  for (int i = 0; i < PD; ++i)
-    if (loader && i < NT) issue(i);
+    for (int i = 0; i < PD; ++i)
+      if (loader && i < NT) issue(i);
+  }
 
-  if (FR) {
+  if (FR == 2) {
+    // ================= software-pipelined schedule (attn_variant 5) =================================================
+    // One wave keeps BOTH pipes busy by itself: iteration t interleaves, instruction by instruction, the 16 MFMAs of
+    // PV(t-1), the 16 MFMAs of QK(t+1) and the ~110 VALU instructions of softmax(t) — three mutually independent streams
+    // (P(t-1) and S(t) were finished last iteration, S(t+1) and P(t) are for the next one).  An MFMA holds the matrix pipe
+    // for 32 cycles after issue; the wave uses them for the 3-4 VALU instructions placed behind it, so the wave-age
+    // arbitration between the two waves of a SIMD (tools/probe_overlap.hip) no longer decides whether softmax and MFMA
+    // overlap.  Costs: two S and two P register sets (parity-unrolled), K ring read one tile ahead, V ring one behind.
+    f32x16 s2[2];
+    bf16x8 pb2[2][2];
+    pb2[0][0] = pb2[0][1] = pb2[1][0] = pb2[1][1] = bf16x8{};          // P(-1) = 0
+    auto qk_plain = [&](int t, f32x16(&sx)[2]) {
+      const unsigned char* kb = smem + K_OFF + (t % RK) * 16384;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sx[bb][r] = 0.f;
+        const unsigned char* krow = kb + (32 * bb + l31) * 256;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          sx[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hi) ^ kswz) << 4)),
+                                                           qf[ks], sx[bb], 0, 0, 0);
+      }
+    };
+    auto mask_ragged = [&](int t, f32x16(&sx)[2]) {
+      const int kidx = t * KT + 4 * hi;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kidx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) sx[b][r] = -INFINITY;
+    };
+    auto true_max = [&](f32x16(&sx)[2]) -> float {
+      float mx = pp_max3(__builtin_fmaxf(sx[0][0], sx[1][0]), m_run, m_run);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = pp_max3(mx, sx[0][r], sx[1][r]);
+      return pp_half_max(mx);
+    };
+    auto exp_plain = [&](f32x16(&sx)[2], bf16x8(&px)[2][2], float mc) -> float {      // non-interleaved (tile 0 redo path)
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float p0 = __builtin_amdgcn_exp2f(sx[b][2 * i] * c2 - mc);
+          const float p1 = __builtin_amdgcn_exp2f(sx[b][2 * i + 1] * c2 - mc);
+          a0 += p0;
+          a1 += p1;
+          px[b][i >> 2][(2 * i) & 7] = static_cast<__bf16>(p0);
+          px[b][i >> 2][(2 * i + 1) & 7] = static_cast<__bf16>(p1);
+        }
+      return a0 + a1;
+    };
+    // iteration t: sC = S(t) -> pC = P(t) (softmax), pP = P(t-1) -> O (PV), sN = S(t+1) (QK)
+    auto body = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) -> float {
+      const unsigned char* kb = smem + K_OFF + ((t + 1) % RK) * 16384;
+      const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
+      int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(ln));
+      const int hi = ln >> 5, l31 = ln & 31, kswz = ln & 15, v_rowq = (ln >> 2) & 3;
+      const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
+      constexpr int RDs = 4, LAs = RDs - 1;            // fragment ring of this schedule (registers are tight)
+      bf16x8 fs[RDs][2];
+      auto load = [&](int j) {
+        bf16x8(&f)[2] = fs[j % RDs];
+        if (j < 8) {
+          const int bb = j >> 2, sl = (j >> 1) & 1, dh = j & 1;
+          const unsigned char* vr0 = vb + (32 * bb + 16 * sl + 4 * hi + v_rowq) * 256 + v_in;
+          const unsigned char* vr1 = vr0 + 8 * 256;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int ch = ((2 * dh + e) ^ v_rowq) << 6;
+            const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr0 + ch));
+            const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vr1 + ch));
+            f[e] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        } else {
+          const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
+          const unsigned char* krow = kb + (32 * bb + l31) * 256;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) f[e] = *reinterpret_cast<const bf16x8*>(krow + (((2 * (ks0 + e) + hi) ^ kswz) << 4));
+        }
+      };
+      auto mma1 = [&](int j, int e) {
+        bf16x8(&f)[2] = fs[j % RDs];
+        if (j < 8) {
+          const int bb = j >> 2, sl = (j >> 1) & 1, dh = j & 1;
+          o[2 * dh + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], pP[bb][sl], o[2 * dh + e], 0, 0, 0);
+        } else {
+          const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
+          if ((q & 3) == 0 && e == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sN[bb][r] = 0.f;
+          }
+          sN[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], sN[bb], 0, 0, 0);
+        }
+      };
+      float p0 = 0.f, p1 = 0.f;
+      float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+      u32x4 pw[2][2];                                  // P(t) as packed bf16 pairs: pw[b][half][k] = keys 2k, 2k+1 of that half
+      const float mc = v_mcv[0];
+#pragma unroll
+      for (int j = 0; j < LAs; ++j) load(j);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int b = j >> 3, i = j & 7;               // softmax piece j = pair i of block b
+        PP_SB();
+        if (j + LAs < 16 && !(PP_ABLATE & 4)) load(j + LAs);
+        if (!(PP_ABLATE & 8)) mma1(j, 0);
+        if (PP_ABLATE & 16) {                          // timing experiments: no transcendental
+          p0 = __builtin_fmaf(sC[b][2 * i], c2, -mc);
+          p1 = __builtin_fmaf(sC[b][2 * i + 1], c2, -mc);
+        } else {
+          p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i], c2, -mc));
+          p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i + 1], c2, -mc));
+        }
+        PP_SB();
+        if (!(PP_ABLATE & 8)) mma1(j, 1);
+        if (!(PP_ABLATE & 64)) {                       // four independent row-sum chains, pinned behind this MFMA
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j) & 3]) : "v"(p0));
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j + 1) & 3]) : "v"(p1));
+        }
+        if (!(PP_ABLATE & 32)) {
+          unsigned pk;
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(p0), "v"(p1));
+          pw[b][i >> 2][i & 3] = pk;
+        } else if (j == 0) {
+          pw[0][0][0] = __builtin_bit_cast(unsigned, p0);
+        }
+      }
+      PP_SB();
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) pC[b][h2] = __builtin_bit_cast(bf16x8, pw[b][h2]);
+      return (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    };
+    auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) {
+      pp_wait_tiles(t + 2 < NT ? 1 : 0);               // own pieces of tile t+1 landed (t+2 may stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // tile t+1 complete for everyone; K(t) and V(t-2) are free
+      if (t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+      if (t == NT - 1 && (nkeys & (KT - 1))) mask_ragged(t, sC);
+      const float mc0 = m_run * c2;
+      v_mcv = pp_f32x2{mc0, mc0};
+      float tile_sum = body(t, sC, sN, pC, pP);
+      if (__any(!(tile_sum < kLazyLimit))) {           // rare: this tile outgrew the reference maximum
+        const float m_new = true_max(sC);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+        m_run = m_new;
+        tile_sum = exp_plain(sC, pC, m_new * c2);
+        l_run *= alpha;
+        rescale_o(alpha);
+      }
+      l_run += tile_sum;
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+      if (i < NT) issue(i);
+    pp_wait_tiles(min(NT, PD) - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    qk_plain(0, s);
+    if (NT == 1 && (nkeys & (KT - 1))) mask_ragged(0, s);
+    m_run = true_max(s);
+    for (int t = 0; t < NT; t += 2) {
+      iteration(t, s, s2, pb, pb2);
+      if (t + 1 < NT) iteration(t + 1, s2, s, pb2, pb);
+    }
+    if (NT & 1) {                                      // P(NT-1) lives in pb when the last iteration had even parity
+    } else {
+      pb[0][0] = pb2[0][0];
+      pb[0][1] = pb2[0][1];
+      pb[1][0] = pb2[1][0];
+      pb[1][1] = pb2[1][1];
+    }
+    {   // drain: PV(NT-1)
+      const unsigned char* vb = smem + V_OFF + ((NT - 1) % RV) * 16384;
+      ldV(fA, vb, 0, 0);
+      ldV(fB, vb, 0, 1);
+      PP_SB();
+      mmaV(fA, pb[0][0]);
+      ldV(fA, vb, 1, 0);
+      PP_SB();
+      mmaV(fB, pb[0][1]);
+      ldV(fB, vb, 1, 1);
+      PP_SB();
+      mmaV(fA, pb[1][0]);
+      mmaV(fB, pb[1][1]);
+    }
+  } else if (FR) {
     for (int t = 0; t < NT; ++t) {
       long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
       if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
@@ -576,7 +771,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     for (int i = tid; i < 64 * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
   }
   // ---- drain: PV of the last tile
-  if (!FR) {
+  if (FR == 0) {
     const unsigned char* vb = smem + V_OFF + ((NT - 1) % RV) * 16384;
     ldV(fA, vb, 0, 0);
     ldV(fB, vb, 0, 1);
@@ -673,23 +868,24 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt) {
   return best;
 }
 
+template <int FR>
 static void launch_pp_fr(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   using namespace pp;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
     attr_set = true;
   }
   const dim3 block(512);
   if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 2, 1>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 2, 1>), grid, block, LDS_ALLOC, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 2, FR>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 2, FR>), grid, block, LDS_ALLOC, stream, a);
   } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2, 1>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 2, 1>), grid, block, LDS_ALLOC, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2, FR>), grid, block, LDS_ALLOC, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 2, FR>), grid, block, LDS_ALLOC, stream, a);
   }
 }
 
@@ -722,8 +918,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
                    hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr) {
   using namespace pp;
-  const bool free_running = groups == 4;           // attn_variant 4: two groups' worth of waves, free-running schedule
-  if (free_running) groups = 2;
+  const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : 0);   // attn_variant 4 / 5: free-running / software-pipelined
+  if (fr_mode) groups = 2;
   const int QT = 128 * groups;
   AttnArgsPP a;
   a.q = q;
@@ -763,7 +959,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
     set_error("ifx_attn_fwd_paged_split: split / partial launches need a workspace");
     return IFX_EINVAL;
   }
-  if (free_running) launch_pp_fr(a, kv->page_table != nullptr, write_partials, grid, stream);
+  if (fr_mode == 2) launch_pp_fr<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
+  else if (fr_mode == 1) launch_pp_fr<1>(a, kv->page_table != nullptr, write_partials, grid, stream);
   else if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, write_partials, grid, stream);
   else launch_pp_ng<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
   if (slots_used) *slots_used = a.splits;

@@ -103,6 +103,70 @@ __device__ __forceinline__ float run_role(int iters, float seed) {
     float s = d0[0] + d1[1] + d2[2] + d3[3];
     for (int i = 0; i < 8; ++i) s += c[i][0];
     return s;
+  } else if (ROLE == 11 || ROLE == 12 || ROLE == 13) {
+    // ONE wave interleaving MFMAs with its own VALU work: per iteration 4 x { MFMA 32x32x16 ; NV x (v_fma + v_exp) }
+    // 11: 2 fma + 2 exp per MFMA (the softmax's ratio), 12: 4 plain fma per MFMA, 13: 2 exp only per MFMA
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = seed * 0.001f + i * 0.01f;
+    for (int it = 0; it < iters; ++it) {
+#define STEP(C, I)                                                                        \
+      C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, C, 0, 0, 0);                      \
+      if (ROLE == 11) {                                                                   \
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[2 * I]) : "v"(seed));            \
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x[2 * I]));                                \
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[2 * I + 1]) : "v"(seed));        \
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x[2 * I + 1]));                            \
+      } else if (ROLE == 12) {                                                            \
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[2 * I]) : "v"(seed));            \
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[2 * I + 1]) : "v"(seed));        \
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[2 * I]) : "v"(seed));            \
+        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[2 * I + 1]) : "v"(seed));        \
+      } else {                                                                            \
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x[2 * I]));                                \
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x[2 * I + 1]));                            \
+      }
+      STEP(c0, 0) STEP(c1, 1) STEP(c2, 2) STEP(c3, 3)
+#undef STEP
+    }
+    float s = c0[0] + c1[1] + c2[2] + c3[3];
+    for (int i = 0; i < 8; ++i) s += x[i];
+    return s;
+  } else if (ROLE == 14 || ROLE == 15) {
+    // as 12 (4 plain fma behind every MFMA) but the fma READ registers an MFMA wrote half an iteration earlier
+    // (ROLE 14: two accumulator sets ping-pong, like S(t) / S(t+1) of the software-pipelined attention loop);
+    // ROLE 15: the fma read the accumulators of the set the in-flight MFMAs are NOT touching, values never consumed
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    f32x16 c[4] = {}, d[4] = {};
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[i], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = d[i][4 * e];
+          asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(v), "v"(seed));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d[i], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = c[i][4 * e];
+          asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(v), "v"(seed));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float s = acc;
+    for (int i = 0; i < 4; ++i) s += c[i][0] + d[i][1];
+    return s;
   } else if (ROLE == 2) {
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = seed + i;
@@ -210,12 +274,14 @@ static float time_it(float* d, int iters) {
 int main() {
   float* d; hipMalloc(&d, 8192);
   const int it = 20000;
-  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4", "softmax mix 24", "M16+lds", "M32+lds"};
+  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4", "softmax mix 24", "M16+lds", "M32+lds", "M+2fma2exp", "M+4fma", "M+2exp", "M+4fma(acc)", "x"};
 #define T(A, B) { float us = time_it<A, B>(d, it); printf("A=%-12s B=%-12s : %8.1f us   role A %8.1f us  role B %8.1f us\n", names[A], names[B], us, g_ta * 0.01f, g_tb * 0.01f); }
   T(1, 0) T(5, 0) T(0, 2) T(0, 3) T(0, 4) T(1, 1) T(2, 2) T(3, 3) T(1, 2) T(1, 3) T(1, 4) T(5, 2) T(5, 3) T(2, 3)
   T(2, 1) T(6, 0) T(6, 2) T(7, 0) T(7, 2) T(2, 7)
   T(3, 1) T(4, 1) T(3, 7) T(2, 6)
   T(8, 0) T(9, 0) T(10, 0) T(8, 10) T(10, 8) T(8, 9) T(9, 8) T(8, 8)
+  T(14, 0) T(14, 14)
+  T(11, 0) T(12, 0) T(13, 0) T(11, 11) T(12, 12) T(13, 13)
   T(6, 3) T(3, 6) T(6, 4) T(4, 6) T(6, 8) T(8, 6) T(9, 9) T(6, 6)
   time_prio<1, 2>(d, it, names);
   time_prio<1, 3>(d, it, names);
