@@ -61,7 +61,7 @@ constexpr int RK = PD + 1, RV = PD + 2;
 constexpr int K_OFF = 0, V_OFF = RK * 16384;
 constexpr int LDS_BYTES = (RK + RV) * 16384;   // 114688
 constexpr int LDS_SWP = 8 * 16384;              // software-pipelined schedule (FR = 2): 3 K tiles + 5 V tiles
-constexpr int LDS_ALLOC = PP_TRACE ? LDS_BYTES + 49152 : (LDS_BYTES > LDS_SWP ? LDS_BYTES : LDS_SWP);
+constexpr int LDS_ALLOC = PP_TRACE ? LDS_SWP + 24576 : (LDS_BYTES > LDS_SWP ? LDS_BYTES : LDS_SWP);   // trace: 24 KiB of stamps behind the rings
 }  // namespace pp
 
 struct AttnArgsPP {
@@ -510,7 +510,10 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       asm volatile("" : "+v"(ln));
       const int hi = ln >> 5, l31 = ln & 31, kswz = ln & 15, v_rowq = (ln >> 2) & 3;
       const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
-      constexpr int RDs = 4, LAs = RDs - 1;            // fragment ring of this schedule (registers are tight)
+#ifndef PP_SWP_RING
+#define PP_SWP_RING 4
+#endif
+      constexpr int RDs = PP_SWP_RING, LAs = RDs - 1;  // fragment ring of this schedule (registers are tight)
       bf16x8 fs[RDs][2];
       auto load = [&](int j) {
         bf16x8(&f)[2] = fs[j % RDs];
@@ -587,14 +590,25 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       return (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     };
     auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) {
+      long long tr[6] = {0, 0, 0, 0, 0, 0};
+      if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
       pp_wait_tiles(t + 2 < NT ? 1 : 0);               // own pieces of tile t+1 landed (t+2 may stay in flight)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
       __builtin_amdgcn_s_barrier();                    // tile t+1 complete for everyone; K(t) and V(t-2) are free
+      if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
+      // (the four pieces were also tried behind MFMAs 2 / 6 / 10 / 14 of the body: 1045 -> 991 TFLOP/s — an LDS-DMA
+      //  instruction stalls its wave for ~100 cycles and inside the body that stall also holds back the wave's MFMAs)
       if (t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+      if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
       if (t == NT - 1 && (nkeys & (KT - 1))) mask_ragged(t, sC);
       const float mc0 = m_run * c2;
       v_mcv = pp_f32x2{mc0, mc0};
       float tile_sum = body(t, sC, sN, pC, pP);
+      if (PP_TRACE) {
+        asm volatile("" ::"v"(tile_sum), "v"(sN[1][15]), "v"(o[3][15]));
+        tr[4] = __builtin_readcyclecounter();
+      }
       if (__any(!(tile_sum < kLazyLimit))) {           // rare: this tile outgrew the reference maximum
         const float m_new = true_max(sC);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
@@ -604,6 +618,12 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
         rescale_o(alpha);
       }
       l_run += tile_sum;
+      if (PP_TRACE && t < 48 && lane == 0) {           // stamps of the first 48 tiles, staged in LDS behind the rings
+        long long* tp = reinterpret_cast<long long*>(smem + LDS_SWP) + (t * 8 + wave) * 8;
+        tr[5] = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tp[i] = tr[i];
+      }
     };
 #pragma unroll
     for (int i = 0; i < PD; ++i)
@@ -767,8 +787,8 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   }
   if (PP_TRACE && wi == 0 && A.lse != nullptr) {
     __syncthreads();
-    const long long* tp = reinterpret_cast<const long long*>(smem + LDS_BYTES);
-    for (int i = tid; i < 64 * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
+    const long long* tp = reinterpret_cast<const long long*>(smem + (FR == 2 ? LDS_SWP : LDS_BYTES));
+    for (int i = tid; i < (FR == 2 ? 48 : 64) * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
   }
   // ---- drain: PV of the last tile
   if (FR == 0) {

@@ -24,13 +24,24 @@ for _ in range(2):
     out, lse = ops.attention(q, ops.KvCacheView(k, v), L, return_lse=True, splits=1)
 torch.cuda.synchronize()
 FR = NG == 4
-if FR:
+SWP = NG == 5
+if FR or SWP:
     NG = 2
 W = 4 * NG
-tr = lse.reshape(-1).view(torch.int64)[:64 * W * 8].view(64, W, 8).cpu()
+NTR = 48 if SWP else 64
+tr = lse.reshape(-1).view(torch.int64)[:NTR * W * 8].view(NTR, W, 8).cpu()
 import numpy as np
 np.set_printoptions(linewidth=200)
 t = tr.numpy().astype(np.int64)
+if SWP:
+    names = ["wait DMA      ", "barrier       ", "DMA issue     ", "body (PV|softmax|QK)", "lazy check + tail"]
+    print("software-pipelined schedule, mean cycles over tiles 8..40, per wave 0..7 (waves w, w+4 share a SIMD)")
+    for i, n in enumerate(names):
+        print(n, (t[8:40, :, i + 1] - t[8:40, :, i]).mean(0).round(0))
+    print("tile period   ", (t[9:41, :, 0] - t[8:40, :, 0]).mean(0).round(0))
+    print("tile 20, stamps relative to wave 0's start: rows = wave")
+    print(t[20, :, :6] - t[20, 0, 0])
+    sys.exit(0)
 if FR:
     names = ["wait DMA      ", "barrier       ", "DMA issue     ", "QK            ", "softmax       ", "PV            "]
 elif NG == 2:
