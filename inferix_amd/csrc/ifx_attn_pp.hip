@@ -193,12 +193,13 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   const unsigned nrec = (valid_rows - 1) * (unsigned)row_bytes + 256u;
   const pp_v4i krs = pp_make_rsrc(A.k + kvh * HD, nrec);
   const pp_v4i vrs = pp_make_rsrc(A.v + kvh * HD, nrec);
-  const unsigned lds0 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem + wave * 1024;
+  const unsigned lds00 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem;
   const int last_key = kv_e - 1;
-  auto issue = [&](int t) {
+  auto issue_w = [&](int t, int wv) {               // the four pieces that belong to wave `wv` (rows 4 wv .. 4 wv + 3 of each half)
+    const unsigned lds0 = lds00 + wv * 1024;
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(ln));                    // recomputed, not kept live (see stepM)
-    const int d_pc = ln & 15, d_row0 = wave * 4 + (ln >> 4);
+    const int d_pc = ln & 15, d_row0 = wv * 4 + (ln >> 4);
     const int k_voff = d_row0 * row_bytes + ((d_pc ^ (d_row0 & 15)) << 4);
     const int v_voff = d_row0 * row_bytes + (((((d_pc >> 2) ^ (d_row0 & 3)) << 2) | (d_pc & 3)) << 4);
     const unsigned kb = lds0 + K_OFF + (t % RK) * 16384;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       }
     }
   };
+  auto issue = [&](int t) { issue_w(t, wave); };
 
   f32x16 o[4];
 #pragma unroll
@@ -592,14 +594,21 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) {
       long long tr[6] = {0, 0, 0, 0, 0, 0};
       if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
-      pp_wait_tiles(t + 2 < NT ? 1 : 0);               // own pieces of tile t+1 landed (t+2 may stay in flight)
+      // own pieces of tile t+1 landed (t+2 may stay in flight); only waves 0-3 have any (8 per tile, see below)
+      if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
       __builtin_amdgcn_s_barrier();                    // tile t+1 complete for everyone; K(t) and V(t-2) are free
       if (PP_TRACE) tr[2] = __builtin_readcyclecounter();
       // (the four pieces were also tried behind MFMAs 2 / 6 / 10 / 14 of the body: 1045 -> 991 TFLOP/s — an LDS-DMA
       //  instruction stalls its wave for ~100 cycles and inside the body that stall also holds back the wave's MFMAs)
-      if (t + PD < NT && !(PP_ABLATE & 1)) issue(t + PD);
+      // LDS-DMA issue stalls a wave for ~80 cycles per instruction: the OLDER wave of each SIMD issues the pieces of both
+      // (8 per tile) while the younger one starts the matrix pipe at once — which also staggers the two waves' bodies
+      if (wave < 4 && t + PD < NT && !(PP_ABLATE & 1)) {
+        issue_w(t + PD, wave);
+        issue_w(t + PD, wave + 4);
+      }
       if (PP_TRACE) tr[3] = __builtin_readcyclecounter();
       if (t == NT - 1 && (nkeys & (KT - 1))) mask_ragged(t, sC);
       const float mc0 = m_run * c2;
@@ -627,8 +636,16 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     };
 #pragma unroll
     for (int i = 0; i < PD; ++i)
-      if (i < NT) issue(i);
-    pp_wait_tiles(min(NT, PD) - 1);
+      if (i < NT && wave < 4) {
+        issue_w(i, wave);
+        issue_w(i, wave + 4);
+      }
+    {
+      const int fl = min(NT, PD) - 1;                  // tiles that may stay in flight behind tile 0 (8 pieces each)
+      if (fl <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (fl == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     qk_plain(0, s);
