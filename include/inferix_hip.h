@@ -42,7 +42,8 @@ const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */
 /* Kernel-selection override for benchmarking and tests (default 0 = choose by shape):
  *   "gemm_variant": 1 register-staged 128x128, 2 / 3 / 4 LDS-DMA 256x128 / 128x128 / 64x64 tiles
- *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong kernel, 3 twelve-wave three-phase kernel
+ *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
+ *                   4 free-running schedule, 5 software-pipelined schedule (what 0 = auto picks for large launches)
  * Results are identical across variants up to fp32 summation order.  Returns IFX_EINVAL for unknown keys. */
 int ifx_set_option(const char* key, int32_t value);
 

@@ -58,7 +58,7 @@ struct KvAddr {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 int gemm_variant();   // 0 auto, 1 register-staged 128x128, 2/3/4 LDS-DMA 256x128 / 128x128 / 64x64
-int attn_variant();   // 0 auto, 1 four-wave kernel, 2 ping-pong kernel (2 wave groups), 3 three-phase kernel (3 groups)
+int attn_variant();   // 0 auto (= 5 for large launches), 1 four-wave kernel, 2 ping-pong, 3 three groups, 4 free-running, 5 software-pipelined
 
 }  // namespace ifx
 
