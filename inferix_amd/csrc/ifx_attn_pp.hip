@@ -508,12 +508,20 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     auto body = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) -> float {
       const unsigned char* kb = smem + K_OFF + ((t + 1) % RK) * 16384;
       const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
+#if PP_SWP_RECOMPUTE
       int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(ln));
       const int hi = ln >> 5, l31 = ln & 31, kswz = ln & 15, v_rowq = (ln >> 2) & 3;
       const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
+#endif
 #ifndef PP_SWP_RING
 #define PP_SWP_RING 4
+#endif
+#ifndef PP_SWP_YIELD
+#define PP_SWP_YIELD 0
+#endif
+#ifndef PP_SWP_RECOMPUTE
+#define PP_SWP_RECOMPUTE 1   // 1: lane-derived LDS address terms recomputed every tile; 0 keeps them live: 256 VGPRs + 170 B of spills, 1078 -> 783 TFLOP/s
 #endif
       constexpr int RDs = PP_SWP_RING, LAs = RDs - 1;  // fragment ring of this schedule (registers are tight)
       bf16x8 fs[RDs][2];
@@ -561,6 +569,9 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       for (int j = 0; j < 16; ++j) {
         const int b = j >> 3, i = j & 7;               // softmax piece j = pair i of block b
         PP_SB();
+#if PP_SWP_YIELD
+        if ((j & 3) == 3 && wave < 4) __builtin_amdgcn_s_sleep(PP_SWP_YIELD);   // the older wave yields issue slots (experiment)
+#endif
         if (j + LAs < 16 && !(PP_ABLATE & 4)) load(j + LAs);
         if (!(PP_ABLATE & 8)) mma1(j, 0);
         if (PP_ABLATE & 16) {                          // timing experiments: no transcendental
