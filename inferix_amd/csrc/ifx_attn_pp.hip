@@ -44,6 +44,16 @@
 #ifndef PP_RING
 #define PP_RING 6      // fragment-ring slots of the MFMA steps with two waves per SIMD (reads PP_RING - 1 batches ahead)
 #endif
+// software-pipelined schedule (FR = 2) knobs
+#ifndef PP_SWP_RING
+#define PP_SWP_RING 4
+#endif
+#ifndef PP_SWP_YIELD
+#define PP_SWP_YIELD 0
+#endif
+#ifndef PP_SWP_RECOMPUTE
+#define PP_SWP_RECOMPUTE 1   // 1: lane-derived LDS address terms recomputed every tile; 0 keeps them live: 256 VGPRs + 170 B of spills, 1078 -> 783 TFLOP/s
+#endif
 #ifndef PP_GROUP
 #define PP_GROUP 0     // 0: groups = waves 0-3 / 4-7 (waves w, w+4 share a SIMD); 1: even / odd waves
 #endif
@@ -513,15 +523,6 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       asm volatile("" : "+v"(ln));
       const int hi = ln >> 5, l31 = ln & 31, kswz = ln & 15, v_rowq = (ln >> 2) & 3;
       const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
-#endif
-#ifndef PP_SWP_RING
-#define PP_SWP_RING 4
-#endif
-#ifndef PP_SWP_YIELD
-#define PP_SWP_YIELD 0
-#endif
-#ifndef PP_SWP_RECOMPUTE
-#define PP_SWP_RECOMPUTE 1   // 1: lane-derived LDS address terms recomputed every tile; 0 keeps them live: 256 VGPRs + 170 B of spills, 1078 -> 783 TFLOP/s
 #endif
       constexpr int RDs = PP_SWP_RING, LAs = RDs - 1;  // fragment ring of this schedule (registers are tight)
       bf16x8 fs[RDs][2];
