@@ -51,6 +51,9 @@
 #ifndef PP_SWP_YIELD
 #define PP_SWP_YIELD 0
 #endif
+#ifndef PP_SWP_PACKED
+#define PP_SWP_PACKED 0
+#endif
 #ifndef PP_SWP_RECOMPUTE
 #define PP_SWP_RECOMPUTE 1   // 1: lane-derived LDS address terms recomputed every tile; 0 keeps them live: 256 VGPRs + 170 B of spills, 1078 -> 783 TFLOP/s
 #endif
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       };
       float p0 = 0.f, p1 = 0.f;
       float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+      pp_f32x2 accp[2] = {pp_f32x2{0.f, 0.f}, pp_f32x2{0.f, 0.f}};
       u32x4 pw[2][2];                                  // P(t) as packed bf16 pairs: pw[b][half][k] = keys 2k, 2k+1 of that half
       const float mc = v_mcv[0];
 #pragma unroll
@@ -578,6 +582,10 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
         if (PP_ABLATE & 16) {                          // timing experiments: no transcendental
           p0 = __builtin_fmaf(sC[b][2 * i], c2, -mc);
           p1 = __builtin_fmaf(sC[b][2 * i + 1], c2, -mc);
+        } else if (PP_SWP_PACKED) {                    // one v_pk_fma_f32 for the two exponent arguments
+          const pp_f32x2 e2 = pp_f32x2{sC[b][2 * i], sC[b][2 * i + 1]} * c2v - v_mcv;
+          p0 = __builtin_amdgcn_exp2f(e2[0]);
+          p1 = __builtin_amdgcn_exp2f(e2[1]);
         } else {
           p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i], c2, -mc));
           p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i + 1], c2, -mc));
@@ -585,8 +593,14 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
         PP_SB();
         if (!(PP_ABLATE & 8)) mma1(j, 1);
         if (!(PP_ABLATE & 64)) {                       // four independent row-sum chains, pinned behind this MFMA
-          asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j) & 3]) : "v"(p0));
-          asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j + 1) & 3]) : "v"(p1));
+          if (PP_SWP_PACKED) {
+            pp_f32x2& a2 = (j & 1) ? accp[1] : accp[0];
+            const pp_f32x2 pv = {p0, p1};
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2) : "v"(pv));
+          } else {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j) & 3]) : "v"(p0));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j + 1) & 3]) : "v"(p1));
+          }
         }
         if (!(PP_ABLATE & 32)) {
           unsigned pk;
@@ -601,6 +615,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) pC[b][h2] = __builtin_bit_cast(bf16x8, pw[b][h2]);
+      if (PP_SWP_PACKED) return (accp[0][0] + accp[0][1]) + (accp[1][0] + accp[1][1]);
       return (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     };
     auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) {
