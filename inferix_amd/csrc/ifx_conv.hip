@@ -48,22 +48,19 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ void wait_vm(int n) {
+#define IFX_WV(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    IFX_WV(0) IFX_WV(1) IFX_WV(2) IFX_WV(3) IFX_WV(4) IFX_WV(5) IFX_WV(6) IFX_WV(7) IFX_WV(8) IFX_WV(9) IFX_WV(10) IFX_WV(11)
+    IFX_WV(12) IFX_WV(13) IFX_WV(14) IFX_WV(15) IFX_WV(16) IFX_WV(17) IFX_WV(18) IFX_WV(19) IFX_WV(20) IFX_WV(21) IFX_WV(22)
+    IFX_WV(23) IFX_WV(24)
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
   }
+#undef IFX_WV
 }
+
+#ifndef IFX_CONV_LOADER_WAVES
+#define IFX_CONV_LOADER_WAVES 4
+#endif
 
 // Timing experiments (tools/ablate_conv.sh): build with -DIFX_CONV_ABLATE_RT=1 to honour IFX_CONV_ABLATE at run time;
 // in normal builds the mask is a compile-time zero and the branches vanish (they cost registers in the main loop).
@@ -82,14 +79,18 @@ struct Geo {
   static constexpr int PW = UPS ? TW / 2 + 2 : TW + KS - 1;
   static constexpr int NP = PH * PW;                    // patch pixels
   static constexpr int NPI = (NP + 15) / 16;            // 1 KiB DMA instructions per patch
-  static constexpr int PPW = (NPI + 7) / 8;             // per wave
+  // LDS-DMA costs its issuing wave ~65 cycles per instruction and is serialised per SIMD, but does not hold back the other
+  // wave of the SIMD (tools/probe_overlap.hip): only waves 0 .. LW-1 (the older wave of each SIMD) issue DMA, the younger
+  // ones go straight to the matrix pipe after the barrier.
+  static constexpr int LW = IFX_CONV_LOADER_WAVES;
+  static constexpr int PPW = (NPI + LW - 1) / LW;       // patch pieces per loader wave
   static constexpr int P_SLOT = NPI * 1024;
   static constexpr int WP = BN / 16;                    // 1 KiB weight pieces per tap (16 rows x 32 channels)
   static constexpr int W_TAP = BN * 64;
-  static constexpr int WPW = (TG * WP + 7) / 8;         // weight pieces per wave per group
+  static constexpr int WPW = (TG * WP + LW - 1) / LW;    // weight pieces per loader wave per group
   static constexpr int WRG = TAPS == 9 ? (BN == 128 ? 2 : 3) : 2;   // weight ring depth in groups
   static constexpr int L = WRG - 1;                     // groups of weight lookahead
-  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WRG * TG * W_TAP, LDS_MAIN = S_OFF + 8 * 1024;
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, S_OFF = W_OFF + WRG * TG * W_TAP, LDS_MAIN = S_OFF + LW * 1024;
   static constexpr int LDS_EPI = 8 * 64 * (BN * 2 + 16);      // per-wave transpose regions of the epilogue (reuse the rings)
   static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   static constexpr bool PF = BN <= 96;                  // fragments of the next tap prefetched under the MFMAs of this one
@@ -100,7 +101,7 @@ struct Geo {
 template <int BN, int UPS, int KS>
 __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
   using G = Geo<BN, UPS, KS>;
-  constexpr int TAPS = G::TAPS, TG = G::TG, GPS = G::GPS, PW = G::PW, PPW = G::PPW, WPW = G::WPW, WRG = G::WRG, L = G::L;
+  constexpr int TAPS = G::TAPS, TG = G::TG, GPS = G::GPS, PW = G::PW, PPW = G::PPW, WPW = G::WPW, WRG = G::WRG, L = G::L, LW = G::LW;
   constexpr int TI = BN / 32, TJ = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,12 +121,13 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
   const int to = rem / A.tiles_h;
   const int h0 = th * TH, w0 = tw * TW, n_base = nt * BN;
 
-  // ---- patch DMA sources: piece p = wave + 8 r covers patch pixels [16 p, 16 p + 16) x 4 chunks of 16 B
+  const bool loader = wave < LW;
+  // ---- patch DMA sources: piece p = wave + LW r covers patch pixels [16 p, 16 p + 16) x 4 chunks of 16 B
   const int ph0 = UPS ? h0 / 2 - 1 : h0 - KS / 2, pw0 = UPS ? w0 / 2 - 1 : w0 - KS / 2;
   int poff[PPW];
 #pragma unroll
   for (int r = 0; r < PPW; ++r) {
-    const int p = wave + 8 * r;
+    const int p = wave + LW * r;
     const int px = p * 16 + (lane >> 2);
     const int pr = px / PW, pc = px - pr * PW;
     const int sh = ph0 + pr, sw = pw0 + pc;
@@ -138,16 +140,16 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     const int dt = s / CC, cc = s - dt * CC;
     const int f = A.in_slot[to + dt];
     const unsigned short* base = A.x + (long long)f * A.in_frame_stride + cc * 32;
-    const int p = wave + 8 * r;
+    const int p = wave + LW * r;
     const unsigned short* src = (poff[r] < 0 || f < 0) ? A.zero : base + poff[r];
     unsigned char* dst = p < G::NPI ? smem + G::P_OFF + (s & 1) * G::P_SLOT + p * 1024 : smem + G::S_OFF + wave * 1024;
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
   };
-  // ---- weight DMA: piece idx = wave + 8 q of a group = (tap idx / WP of the group, rows [16 (idx % WP), +16))
+  // ---- weight DMA: piece idx = wave + LW q of a group = (tap idx / WP of the group, rows [16 (idx % WP), +16))
   int woff[WPW];
 #pragma unroll
   for (int q = 0; q < WPW; ++q) {
-    const int idx = wave + 8 * q;
+    const int idx = wave + LW * q;
     const int wrow = (idx % G::WP) * 16 + (lane >> 2);
     woff[q] = min(n_base + wrow, A.Cout - 1) * A.Cin + (((lane & 3) ^ ((wrow >> 2) & 3)) << 3);
   }
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     unsigned char* ring = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {
-      const int idx = wave + 8 * q;
+      const int idx = wave + LW * q;
       const int tg = idx / G::WP;                   // tap within the group
       const bool real = idx < TG * G::WP;
-      const unsigned short* src = wbase + (size_t)(real ? tg : 0) * A.Cout * A.Cin + woff[q];
+      const unsigned short* src = wbase + (size_t)(real ? min(tg, TG - 1) : 0) * A.Cout * A.Cin + woff[q];
       unsigned char* dst = real ? ring + tg * G::W_TAP + (idx % G::WP) * 1024 : smem + G::S_OFF + wave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     }
@@ -176,11 +178,13 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- prologue: patch of stage 0, weights of groups 0 .. L-1
+  if (loader) {
 #pragma unroll
-  for (int r = 0; r < PPW; ++r) issue_patch(0, r);
+    for (int r = 0; r < PPW; ++r) issue_patch(0, r);
 #pragma unroll
-  for (int g = 0; g < L; ++g)
-    if (g < totalG) issue_w(g);
+    for (int g = 0; g < L; ++g)
+      if (g < totalG) issue_w(g);
+  }
 
   int b_off[TI];
 #pragma unroll
@@ -201,11 +205,11 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
       wait_vm(WPW * min(L - 1, totalG - 1 - g) + ((L == 2 && gi == 1 && has_next) ? PPW : 0));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of group g-1 retired
       __builtin_amdgcn_s_barrier();
-      if (gi == 0 && has_next && !(ABL(A) & 1)) {
+      if (loader && gi == 0 && has_next && !(ABL(A) & 1)) {
 #pragma unroll
         for (int r = 0; r < PPW; ++r) issue_patch(s + 1, r);
       }
-      if (g + L < totalG && !(ABL(A) & 1)) issue_w(g + L);
+      if (loader && g + L < totalG && !(ABL(A) & 1)) issue_w(g + L);
 
       const unsigned char* wg = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
       auto load = [&](int buf, int tg) {

@@ -9,6 +9,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+__device__ const unsigned char* g_dma_src;
+
 template <int ROLE>
 __device__ __forceinline__ float run_role(int iters, float seed) {
   if (ROLE == 1 || ROLE == 5) {
@@ -167,6 +169,21 @@ __device__ __forceinline__ float run_role(int iters, float seed) {
     float s = acc;
     for (int i = 0; i < 4; ++i) s += c[i][0] + d[i][1];
     return s;
+  } else if (ROLE == 16) {
+    // four LDS-DMA instructions (64 lanes x 16 B, L2-resident source) per iteration, nothing else
+    __shared__ __attribute__((aligned(16))) unsigned char dlds[8 * 4096];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    const unsigned char* src = g_dma_src + ((blockIdx.x & 7) * 64) * 4096 + (threadIdx.x & 63) * 16;
+    const int w = threadIdx.x >> 6;
+    for (int it = 0; it < iters; ++it) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((it & 63) * 4 + i) * 1024), (lds_ptr_t)(dlds + w * 4096 + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return dlds[0];
   } else if (ROLE == 2) {
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = seed + i;
@@ -274,12 +291,19 @@ static float time_it(float* d, int iters) {
 int main() {
   float* d; hipMalloc(&d, 8192);
   const int it = 20000;
-  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4", "softmax mix 24", "M16+lds", "M32+lds", "M+2fma2exp", "M+4fma", "M+2exp", "M+4fma(acc)", "x"};
+  const char* names[] = {"idle", "mfma(4 acc)", "v_fma x16", "v_exp x16", "v_pk_fma x8", "mfma(1 acc)", "mfma16x16x32 x8", "mfma32x32x8 x4", "softmax mix 24", "M16+lds", "M32+lds", "M+2fma2exp", "M+4fma", "M+2exp", "M+4fma(acc)", "x", "4 LDS-DMA"};
 #define T(A, B) { float us = time_it<A, B>(d, it); printf("A=%-12s B=%-12s : %8.1f us   role A %8.1f us  role B %8.1f us\n", names[A], names[B], us, g_ta * 0.01f, g_tb * 0.01f); }
   T(1, 0) T(5, 0) T(0, 2) T(0, 3) T(0, 4) T(1, 1) T(2, 2) T(3, 3) T(1, 2) T(1, 3) T(1, 4) T(5, 2) T(5, 3) T(2, 3)
   T(2, 1) T(6, 0) T(6, 2) T(7, 0) T(7, 2) T(2, 7)
   T(3, 1) T(4, 1) T(3, 7) T(2, 6)
   T(8, 0) T(9, 0) T(10, 0) T(8, 10) T(10, 8) T(8, 9) T(9, 8) T(8, 8)
+  {
+    unsigned char* g;
+    hipMalloc(&g, 8 * 64 * 4096 + 65536);
+    hipMemset(g, 0, 8 * 64 * 4096 + 65536);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_dma_src), &g, sizeof(g));
+  }
+  T(16, 0) T(0, 16) T(16, 16) T(16, 1) T(1, 16) T(16, 2) T(2, 16)
   T(14, 0) T(14, 14)
   T(11, 0) T(12, 0) T(13, 0) T(11, 11) T(12, 12) T(13, 13)
   T(6, 3) T(3, 6) T(6, 4) T(4, 6) T(6, 8) T(8, 6) T(9, 9) T(6, 6)
