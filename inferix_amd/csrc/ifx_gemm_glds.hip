@@ -22,6 +22,10 @@
 
 #include "ifx_common.h"
 
+#ifndef IFX_GEMM_LOADERS
+#define IFX_GEMM_LOADERS 8   // 4 (older waves only) measured neutral here: FFN up 171.8 vs 170 us — this kernel is bound by operand delivery, not by DMA issue
+#endif
+
 namespace ifx {
 
 namespace g2 {
@@ -451,7 +455,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   constexpr int A_OFF = 0, B_OFF = BM * BK * 2;          // x tile [BM][64 B], W tile [BN][64 B]
   constexpr int WAVES_N = 8 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TJ = WM / 32, TI = WN / 32;
-  constexpr int PA = BM / 128, PB = BN / 128, P = PA + PB;   // DMA instructions per wave per K-tile (16 rows each)
+  // LDS-DMA issue costs the issuing wave ~65 cycles per instruction and serialises per SIMD, but leaves the other wave of the
+  // SIMD free (tools/probe_overlap.hip): with IFX_GEMM_LOADERS = 4 only waves 0-3 (the older wave of each SIMD) issue the
+  // pieces of both waves, the younger ones go straight to the matrix pipe after the barrier.
+  constexpr int LW = IFX_GEMM_LOADERS, LM = 8 / LW;      // loader waves, wave-slots per loader
+  constexpr int PA = BM / 128 * LM, PB = BN / 128 * LM, P = PA + PB;   // DMA instructions per LOADER wave per K-tile (16 rows each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -472,14 +480,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   const int r16 = lane >> 2, pc = lane & 3;
   const unsigned short* src_a[PA];
   const unsigned short* src_b[PB];
+  const bool loader = wave < LW;
+  // piece index of (r, wave): r * LW + wave, covering rows [16 piece, 16 piece + 16)
 #pragma unroll
   for (int r = 0; r < PA; ++r) {
-    const int row = (r * 8 + wave) * 16 + r16;
+    const int row = (r * LW + wave) * 16 + r16;
     src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 2) & 3)) * 8;
   }
 #pragma unroll
   for (int r = 0; r < PB; ++r) {
-    const int row = (r * 8 + wave) * 16 + r16;
+    const int row = (r * LW + wave) * 16 + r16;
     src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 2) & 3)) * 8;
   }
   auto issue = [&](int kt) {
@@ -487,10 +497,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
     const size_t ko = (size_t)kt * BK;
 #pragma unroll
     for (int r = 0; r < PA; ++r)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * LW + wave) * 1024), 16, 0, 0);
 #pragma unroll
     for (int r = 0; r < PB; ++r)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko), (lds_ptr_t)(st + B_OFF + (r * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko), (lds_ptr_t)(st + B_OFF + (r * LW + wave) * 1024), 16, 0, 0);
   };
 
   f32x16 acc[TI][TJ];
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
   const int KT = K / BK;
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i)
-    if (i < KT) issue(i);
+    if (i < KT && loader) issue(i);
 
   const int l31 = lane & 31, hi = lane >> 5;
   int a_off[TJ], b_off[TI], a_swz[TJ], b_swz[TI];
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __r
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + NST - 1 < KT) issue(kt + NST - 1);
+    if (kt + NST - 1 < KT && loader) issue(kt + NST - 1);
     const unsigned char* st = smem + (kt % NST) * STAGE;
     bf16x8 fa[2][TJ], fb[2][TI];
 #pragma unroll
