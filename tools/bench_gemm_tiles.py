@@ -1,0 +1,27 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from inferix_amd import hip_ops as ops, _hip
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+M, d, f = 4680, 1536, 8960
+def timeit(fn, iters=10, inner=10):
+    for _ in range(3): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(iters):
+        s.record()
+        for _ in range(inner): fn()
+        e.record(); e.synchronize(); ts.append(s.elapsed_time(e) / inner)
+    ts.sort(); return ts[len(ts) // 2]
+x = rnd(M, d); res = rnd(M, d); mod = rnd(3, 6, d)
+shapes = [("o/q-cross N=1536 K=1536", x, rnd(d, d) * 0.03, rnd(d), dict(epilogue=_hip.IFX_EPI_RESIDUAL, residual=res)),
+          ("qkv N=4608 K=1536", x, rnd(3 * d, d) * 0.03, rnd(3 * d), dict())]
+for name, a, w, b, kw in shapes:
+    out = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=dev)
+    row = []
+    for v in (0, 2, 3, 4, 5, 6):
+        ops.set_option("gemm_variant", v)
+        row.append(f"v{v}: {timeit(lambda: ops.linear(a, w, b, out=out, **kw))*1e3:6.1f}")
+    ops.set_option("gemm_variant", 0)
+    print(name, " ".join(row), " (v2 256x128x64, v3 128x128, v4 64x64, v5 256x256x32, v6 128x64)")
