@@ -185,7 +185,9 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
 //   tile 3 = 256x256x32, 0 = 256x128x64, 1 = 128x128, 4 = 128x64, 2 = 64x64   (bench: tools/bench_kernels.py gemm M)
 static int pick_tile(int M, int N) {
   struct Cand { int tile, bm, bn, slots; float base; };
-  static const Cand cands[] = {{3, 256, 256, 256, 1.00f}, {0, 256, 128, 256, 0.85f}, {1, 128, 128, 256, 0.75f},
+  // 128x128 runs double-buffered with TWO workgroups per CU (64 KiB of LDS each): the co-resident workgroup hides the operand
+  // latency better than the deep rings of the big tiles do — QKV 92 -> 83 us, O 38 -> 35, FFN down 150 -> 137 (tools/bench_gemm_tiles.py)
+  static const Cand cands[] = {{3, 256, 256, 256, 1.00f}, {0, 256, 128, 256, 0.85f}, {1, 128, 128, 512, 0.95f},
                                {4, 128, 64, 512, 0.78f},  {2, 64, 64, 512, 0.50f}};
   int best = 2;
   float best_score = -1.f;
@@ -200,7 +202,8 @@ static int pick_tile(int M, int N) {
 }
 
 // kernel selection: 0 = auto (LDS-DMA kernels, tile by shape), 1 = force the register-staged 128x128 kernel,
-// 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32, 6 = force LDS-DMA 128x64
+// 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32, 6 = force LDS-DMA 128x64,
+// 7 / 8 = the two-per-CU 256x128x32 and eight-wave 128x128x32 experiments (slower than 3, kept selectable)
 }  // namespace ifx
 
 using namespace ifx;

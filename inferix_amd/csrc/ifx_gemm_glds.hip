@@ -22,6 +22,12 @@
 
 #include "ifx_common.h"
 
+#ifndef IFX_SMALL_NST64
+#define IFX_SMALL_NST64 3
+#endif
+#ifndef IFX_SMALL_NST
+#define IFX_SMALL_NST 2     // stages of the 128x128 tile: 2 = 64 KiB of LDS -> two workgroups per CU (4 stages, one per CU: 15-35 % slower)
+#endif
 #ifndef IFX_GEMM_LOADERS
 #define IFX_GEMM_LOADERS 8   // 4 (older waves only) measured neutral here: FFN up 171.8 vs 170 us — this kernel is bound by operand delivery, not by DMA issue
 #endif
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
 // (pick_tile in ifx_gemm.hip); same operand roles, swizzled DMA and LDS-transposed epilogue as above.
 //   LDS rows are 64 B (32 bf16): physical 16-byte chunk = logical chunk XOR ((row >> 2) & 3).
 template <int BM, int BN, int WAVES_M, int NST, int EPI>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
+__global__ __launch_bounds__(512, (BM * BN <= 128 * 128 && NST <= 2) ? 3 : ((BM * BN <= 256 * 128 && NST <= 2) ? 2 : 1)) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
                                                        const unsigned short* __restrict__ w,
                                                        unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                        int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
@@ -627,7 +633,8 @@ static int launch_big(const unsigned short* x, int ldx, const unsigned short* w,
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(512);
-  constexpr size_t lds = (size_t)NST * (BM + BN) * 64;
+  constexpr size_t lds_main = (size_t)NST * (BM + BN) * 64, lds_epi = (size_t)BM * BN * 2;   // rings / per-wave transposes
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
 #define IFX_LAUNCH_GB(E)                                                                                             \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
@@ -728,9 +735,11 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
     return launch_gemm_glds(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot,
                             rows_per_group, s);
   EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
-  if (tile == 1) return launch_small<128, 128, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
-  if (tile == 4) return launch_small<128, 64, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 1) return launch_small<128, 128, IFX_SMALL_NST>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 4) return launch_small<128, 64, IFX_SMALL_NST64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 3) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 5) return launch_big<256, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // two workgroups per CU
+  if (tile == 6) return launch_big<128, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // eight waves, three per CU
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 

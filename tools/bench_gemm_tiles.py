@@ -16,12 +16,14 @@ def timeit(fn, iters=10, inner=10):
     ts.sort(); return ts[len(ts) // 2]
 x = rnd(M, d); res = rnd(M, d); mod = rnd(3, 6, d)
 shapes = [("o/q-cross N=1536 K=1536", x, rnd(d, d) * 0.03, rnd(d), dict(epilogue=_hip.IFX_EPI_RESIDUAL, residual=res)),
-          ("qkv N=4608 K=1536", x, rnd(3 * d, d) * 0.03, rnd(3 * d), dict())]
+          ("qkv N=4608 K=1536", x, rnd(3 * d, d) * 0.03, rnd(3 * d), dict()),
+          ("ffn0 N=8960 K=1536 gelu", x, rnd(f, d) * 0.03, rnd(f), dict(epilogue=_hip.IFX_EPI_GELU_TANH)),
+          ("ffn2 N=1536 K=8960 res", rnd(M, f), rnd(d, f) * 0.01, rnd(d), dict(epilogue=_hip.IFX_EPI_RESIDUAL, residual=res))]
 for name, a, w, b, kw in shapes:
     out = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=dev)
     row = []
-    for v in (0, 2, 3, 4, 5, 6):
+    for v in (0, 3, 7, 8):
         ops.set_option("gemm_variant", v)
         row.append(f"v{v}: {timeit(lambda: ops.linear(a, w, b, out=out, **kw))*1e3:6.1f}")
     ops.set_option("gemm_variant", 0)
-    print(name, " ".join(row), " (v2 256x128x64, v3 128x128, v4 64x64, v5 256x256x32, v6 128x64)")
+    print(name, " ".join(row), " (v2 256x128x64, v3 128x128, v4 64x64, v5 256x256x32, v6 128x64, v7 256x128x32 two per CU, v8 128x128x32 8 waves three per CU)")
