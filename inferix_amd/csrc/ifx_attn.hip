@@ -391,7 +391,7 @@ size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
 int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt);
 // wave groups of the multi-wave kernel for a launch: 3 (384-row tiles) when variant 3 is forced or chosen, else 2
 // 0 (auto) and 5: software-pipelined schedule; 2: phase-locked ping-pong; 3: three groups; 4: free-running
-static int attn_groups(int variant) { return variant == 3 ? 3 : (variant == 4 ? 4 : (variant == 2 ? 2 : 5)); }
+static int attn_groups(int variant) { return variant == 3 ? 3 : (variant == 4 ? 4 : (variant == 2 ? 2 : (variant == 6 ? 6 : 5))); }
 
 }  // namespace ifx
 
@@ -460,7 +460,7 @@ extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv
                                        int64_t* workspace_bytes) {
   int splits = 1;
   if (q_rows > 0 && heads > 0 && kv_len > kv_start)
-    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_variant() == 3 ? 384 : 256);
+    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_variant() == 3 ? 384 : (attn_variant() == 6 ? 128 : 256));
   if (workspace_bytes) *workspace_bytes = (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits);
   return splits;
 }

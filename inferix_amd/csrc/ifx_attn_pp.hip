@@ -148,12 +148,16 @@ __device__ __forceinline__ void pp_wait_tiles(int tiles) {
 // workgroup barrier per tile and no phase assignment — the two waves of a SIMD drift apart by themselves, the older one takes
 // the matrix pipe first and its softmax then overlaps with the younger wave's MFMAs (tools/probe_roles.hip).
 template <bool PAGED, bool SPLIT, int NG, int FR = 0>
-__global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
+__global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(AttnArgsPP A) {
   using namespace pp;
   constexpr int QT = 128 * NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // DMA prefetch distance and LDS rings of this schedule (FR = 2 reads K one tile ahead and V one tile behind)
-  constexpr int PD = FR == 2 ? 3 : pp::PD, RK = FR == 2 ? 3 : pp::RK, RV = FR == 2 ? 5 : pp::RV, V_OFF = RK * 16384;
+  // FR = 3 (attn_variant 6): the software-pipelined loop in FOUR-wave workgroups of 128 queries, TWO of them per CU (80 KiB of
+  // LDS each: K ring 2, V ring 3).  The two waves of a SIMD then belong to different workgroups: no barrier couples them, so
+  // the older wave no longer waits ~600 cycles per tile for the younger one; the price is that each workgroup streams K/V itself.
+  constexpr bool SWP = FR >= 2, DUAL = FR == 3;
+  constexpr int PD = FR == 2 ? 3 : pp::PD, RK = DUAL ? 2 : (FR == 2 ? 3 : pp::RK), RV = DUAL ? 3 : (FR == 2 ? 5 : pp::RV), V_OFF = RK * 16384;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = (NG == 2 && PP_GROUP) ? (wave & 1) : (wave >> 2);
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   const pp_v4i vrs = pp_make_rsrc(A.v + kvh * HD, nrec);
   const unsigned lds00 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem;
   const int last_key = kv_e - 1;
-  auto issue_w = [&](int t, int wv) {               // the four pieces that belong to wave `wv` (rows 4 wv .. 4 wv + 3 of each half)
+  auto issue_w = [&](int t, int wv, int what = 3) {  // the pieces that belong to wave `wv` (rows 4 wv .. 4 wv + 3 of each half); what: 1 K, 2 V
     const unsigned lds0 = lds00 + wv * 1024;
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(ln));                    // recomputed, not kept live (see stepM)
@@ -221,16 +225,16 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       const int soff = (kv_s + t * KT) * row_bytes;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        pp_dma16(krs, kb + r * 8192, k_voff, soff + r * 32 * row_bytes);
-        pp_dma16(vrs, vb + r * 8192, v_voff, soff + r * 32 * row_bytes);
+        if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff, soff + r * 32 * row_bytes);
+        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff, soff + r * 32 * row_bytes);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int key = min(kv_s + t * KT + d_row0 + 32 * r, last_key);
         const int delta = (A.ka.slot(key) - d_row0) * row_bytes;         // physical row instead of tile row
-        pp_dma16(krs, kb + r * 8192, k_voff + delta, 0);
-        pp_dma16(vrs, vb + r * 8192, v_voff + delta, 0);
+        if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff + delta, 0);
+        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff + delta, 0);
       }
     }
   };
@@ -458,14 +462,14 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
   };
 
   // ---- prologue: tiles 0 .. PD-1 in flight
-  if (FR != 2) {
+  if (!SWP) {
 #pragma unroll
     for (int i = 0; i < PD; ++i)
       if (loader && i < NT) issue(i);
   }
 
-  if (FR == 2) {
-    // ================= software-pipelined schedule (attn_variant 5) =================================================
+  if (SWP) {
+    // ================= software-pipelined schedule (attn_variant 5; 6 = two four-wave workgroups per CU) =================================================
     // One wave keeps BOTH pipes busy by itself: iteration t interleaves, instruction by instruction, the 16 MFMAs of
     // PV(t-1), the 16 MFMAs of QK(t+1) and the ~110 VALU instructions of softmax(t) — three mutually independent streams
     // (P(t-1) and S(t) were finished last iteration, S(t+1) and P(t) are for the next one).  An MFMA holds the matrix pipe
@@ -621,9 +625,16 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
     auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) {
       long long tr[6] = {0, 0, 0, 0, 0, 0};
       if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
-      // own pieces of tile t+1 landed (t+2 may stay in flight); only waves 0-3 have any (8 per tile, see below)
-      if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (DUAL) {
+        // issue order per iteration: K(t+2) then V(t+1) (4 pieces each per wave).  Here K(t+1) must have landed; the V(t) pieces
+        // issued after it may stay in flight (PV(t) is next iteration's) — except at t = 0, where K(1) was the last thing issued
+        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        // own pieces of tile t+1 landed (t+2 may stay in flight); only waves 0-3 have any (8 per tile, see below)
+        if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (PP_TRACE) tr[1] = __builtin_readcyclecounter();
       __builtin_amdgcn_s_barrier();                    // tile t+1 complete for everyone; K(t) and V(t-2) are free
@@ -632,7 +643,16 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       //  instruction stalls its wave for ~100 cycles and inside the body that stall also holds back the wave's MFMAs)
       // LDS-DMA issue stalls a wave for ~80 cycles per instruction: the OLDER wave of each SIMD issues the pieces of both
       // (8 per tile) while the younger one starts the matrix pipe at once — which also staggers the two waves' bodies
-      if (wave < 4 && t + PD < NT && !(PP_ABLATE & 1)) {
+      if (DUAL) {
+        if (t + 2 < NT) {
+          issue_w(t + 2, wave, 1);
+          issue_w(t + 2, wave + 4, 1);
+        }
+        if (t + 1 < NT) {
+          issue_w(t + 1, wave, 2);
+          issue_w(t + 1, wave + 4, 2);
+        }
+      } else if (wave < 4 && t + PD < NT && !(PP_ABLATE & 1)) {
         issue_w(t + PD, wave);
         issue_w(t + PD, wave + 4);
       }
@@ -661,13 +681,24 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
         for (int i = 0; i < 6; ++i) tp[i] = tr[i];
       }
     };
+    if (DUAL) {                                        // K(0), V(0), K(1); K(0) and V(0) must land before QK(0) / the P = 0 pass over V(0)
+      issue_w(0, wave, 3);
+      issue_w(0, wave + 4, 3);
+      if (NT > 1) {
+        issue_w(1, wave, 1);
+        issue_w(1, wave + 4, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PD; ++i)
-      if (i < NT && wave < 4) {
+      if (!DUAL && i < NT && wave < 4) {
         issue_w(i, wave);
         issue_w(i, wave + 4);
       }
-    {
+    if (!DUAL) {
       const int fl = min(NT, PD) - 1;                  // tiles that may stay in flight behind tile 0 (8 pieces each)
       if (fl <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (fl == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -688,6 +719,10 @@ __global__ __launch_bounds__(NG * 256) void attn_fwd_pp_kernel(AttnArgsPP A) {
       pb[0][1] = pb2[0][1];
       pb[1][0] = pb2[1][0];
       pb[1][1] = pb2[1][1];
+    }
+    if (DUAL) {                                        // V(NT-1) was allowed to stay in flight; everyone's pieces must be visible
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
     {   // drain: PV(NT-1)
       const unsigned char* vb = smem + V_OFF + ((NT - 1) % RV) * 16384;
@@ -932,6 +967,26 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt) {
   return best;
 }
 
+static void launch_pp_dual(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
+  constexpr int LDS_DUAL = 5 * 16384;                   // 80 KiB: two workgroups per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    attr_set = true;
+  }
+  const dim3 block(256);
+  if (split) {
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 1, 3>), grid, block, LDS_DUAL, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 1, 3>), grid, block, LDS_DUAL, stream, a);
+  } else {
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, 3>), grid, block, LDS_DUAL, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 1, 3>), grid, block, LDS_DUAL, stream, a);
+  }
+}
+
 template <int FR>
 static void launch_pp_fr(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   using namespace pp;
@@ -982,8 +1037,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
                    hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr) {
   using namespace pp;
-  const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : 0);   // attn_variant 4 / 5: free-running / software-pipelined
-  if (fr_mode) groups = 2;
+  const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : 0));   // attn_variant 4 / 5 / 6
+  if (fr_mode) groups = fr_mode == 3 ? 1 : 2;
   const int QT = 128 * groups;
   AttnArgsPP a;
   a.q = q;
@@ -1023,7 +1078,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
     set_error("ifx_attn_fwd_paged_split: split / partial launches need a workspace");
     return IFX_EINVAL;
   }
-  if (fr_mode == 2) launch_pp_fr<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
+  if (fr_mode == 3) launch_pp_dual(a, kv->page_table != nullptr, write_partials, grid, stream);
+  else if (fr_mode == 2) launch_pp_fr<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
   else if (fr_mode == 1) launch_pp_fr<1>(a, kv->page_table != nullptr, write_partials, grid, stream);
   else if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, write_partials, grid, stream);
   else launch_pp_ng<2>(a, kv->page_table != nullptr, write_partials, grid, stream);

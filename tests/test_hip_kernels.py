@@ -356,7 +356,7 @@ def test_gemm_every_tile_variant(ops, variant, M, N, K):
         ops.set_option("gemm_variant", 0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_attention_both_kernels(ops, variant):
     ops.set_option("attn_variant", variant)
     try:
