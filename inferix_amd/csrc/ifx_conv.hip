@@ -351,52 +351,69 @@ struct NormArgs {
   float scale;
 };
 
-template <int G>
+// G lanes share one pixel; every lane holds CPL 16-byte chunks of it (chunk k G + lane: each load instruction of the group is
+// contiguous).  CPL = 3 for the decoder's 96 / 192 / 384 channels (G = 4 / 8 / 16: every lane busy; with one chunk per lane a
+// quarter of the lanes idled in a VALU-bound kernel), CPL = 1 for powers of two.  NPX pixels per group are loaded up front.
+template <int G, int CPL>
 __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(NormArgs A) {
-  constexpr int NPX = 4;                    // pixels per lane group: four 16-byte loads in flight per lane
+  constexpr int NPX = CPL == 1 ? 4 : 2;     // 16-byte loads in flight per lane: 4
   constexpr int GPB = 256 / G;              // lane groups per block
   const int lane_in = threadIdx.x % G, grp = threadIdx.x / G;
-  const bool lane_on = lane_in * 8 < A.C;
   const int pix0 = blockIdx.x * (GPB * NPX) + grp;          // pixel indices fit 32 bits (checked by the launcher)
-  u16x8 xv[NPX];
+  u16x8 xv[NPX][CPL], gv[CPL];
+  bool on[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    on[k] = (k * G + lane_in) * 8 < A.C;
+    gv[k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (on[k]) gv[k] = *reinterpret_cast<const u16x8*>(A.gamma + (k * G + lane_in) * 8);
+  }
 #pragma unroll
   for (int i = 0; i < NPX; ++i) {
     const int pix = pix0 + i * GPB;
-    xv[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (lane_on && pix < A.pixels) xv[i] = *reinterpret_cast<const u16x8*>(A.x + (long long)pix * A.C + lane_in * 8);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      xv[i][k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (on[k] && pix < A.pixels) xv[i][k] = *reinterpret_cast<const u16x8*>(A.x + (long long)pix * A.C + (k * G + lane_in) * 8);
+    }
   }
-  u16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (lane_on) gv = *reinterpret_cast<const u16x8*>(A.gamma + lane_in * 8);
 #pragma unroll
   for (int i = 0; i < NPX; ++i) {
     float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float f = bf2f(xv[i][e]);
-      ss += f * f;
-    }
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(xv[i][k][e]);
+        ss += f * f;
+      }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const int pix = pix0 + i * GPB;
-    if (!lane_on || pix >= A.pixels) continue;
+    if (pix >= A.pixels) continue;
     const float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
     // x / n without the IEEE division sequence (the kernel was VALU-bound on it): reciprocal + one residual step gives
     // the correctly rounded quotient except for ties no bf16 rounding can see
     const float rn = __builtin_amdgcn_rcpf(n);
-    u16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = bf2f(xv[i][e]);
-      float q = x * rn;
-      q = __builtin_fmaf(__builtin_fmaf(-q, n, x), rn, q);
-      float v = rbf(q);
-      v = rbf(v * A.scale);
-      v = rbf(v * bf2f(gv[e]));
-      if (A.silu) v = v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-      o[e] = f2bf(v);
-    }
     const int f = pix / A.frame_pixels, pp = pix - f * A.frame_pixels;
-    *reinterpret_cast<u16x8*>(A.y + (long long)A.out_slot[f] * A.out_frame_stride + (long long)pp * A.C + lane_in * 8) = o;
+    unsigned short* yp = A.y + (long long)A.out_slot[f] * A.out_frame_stride + (long long)pp * A.C;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      if (!on[k]) continue;
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = bf2f(xv[i][k][e]);
+        float q = x * rn;
+        q = __builtin_fmaf(__builtin_fmaf(-q, n, x), rn, q);
+        float v = rbf(q);
+        v = rbf(v * A.scale);
+        v = rbf(v * bf2f(gv[k][e]));
+        if (A.silu) v = v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+        o[e] = f2bf(v);
+      }
+      *reinterpret_cast<u16x8*>(yp + (k * G + lane_in) * 8) = o;
+    }
   }
 }
 
@@ -525,19 +542,28 @@ extern "C" int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16
   a.scale = sqrtf((float)channels);
   const int chunks = channels / 8;
   hipStream_t s = (hipStream_t)stream;
-#define IFX_NORM_G(GG)                                                                                         \
+#define IFX_NORM_G(GG, CC)                                                                                     \
   {                                                                                                            \
-    const long long per_block = (256 / GG) * 4;                                                               \
+    const long long per_block = (256 / GG) * (CC == 1 ? 4 : 2);                                                \
     const long long blocks = (a.pixels + per_block - 1) / per_block;                                           \
-    hipLaunchKernelGGL((rmsnorm_cl_kernel<GG>), dim3((unsigned)blocks), dim3(256), 0, s, a);                   \
+    hipLaunchKernelGGL((rmsnorm_cl_kernel<GG, CC>), dim3((unsigned)blocks), dim3(256), 0, s, a);               \
   }
-  if (chunks <= 1) IFX_NORM_G(1)
-  else if (chunks <= 2) IFX_NORM_G(2)
-  else if (chunks <= 4) IFX_NORM_G(4)
-  else if (chunks <= 8) IFX_NORM_G(8)
-  else if (chunks <= 16) IFX_NORM_G(16)
-  else if (chunks <= 32) IFX_NORM_G(32)
-  else IFX_NORM_G(64)
+  if (chunks % 3 == 0 && (chunks / 3 & (chunks / 3 - 1)) == 0 && chunks / 3 <= 64) {      // 96 / 192 / 384 ... channels
+    const int g3 = chunks / 3;
+    if (g3 == 1) IFX_NORM_G(1, 3)
+    else if (g3 == 2) IFX_NORM_G(2, 3)
+    else if (g3 == 4) IFX_NORM_G(4, 3)
+    else if (g3 == 8) IFX_NORM_G(8, 3)
+    else if (g3 == 16) IFX_NORM_G(16, 3)
+    else if (g3 == 32) IFX_NORM_G(32, 3)
+    else IFX_NORM_G(64, 3)
+  } else if (chunks <= 1) IFX_NORM_G(1, 1)
+  else if (chunks <= 2) IFX_NORM_G(2, 1)
+  else if (chunks <= 4) IFX_NORM_G(4, 1)
+  else if (chunks <= 8) IFX_NORM_G(8, 1)
+  else if (chunks <= 16) IFX_NORM_G(16, 1)
+  else if (chunks <= 32) IFX_NORM_G(32, 1)
+  else IFX_NORM_G(64, 1)
 #undef IFX_NORM_G
   return check_launch("ifx_rmsnorm_cl");
 }
