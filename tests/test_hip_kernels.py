@@ -364,6 +364,9 @@ def test_attention_both_kernels(ops, variant):
         _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
         _attn_case(ops, 1000, 2, 700, cap=777)                 # several query tiles, ragged last key tile
         _attn_case(ops, 390, 3, 64, cap=64)                    # a single key tile
+        _attn_case(ops, 200, 2, 100, cap=128)                  # two key tiles, ragged (even tile count of the parity-unrolled loop)
+        _attn_case(ops, 200, 2, 190, cap=192)                  # three key tiles, ragged (odd tile count)
+        _attn_case(ops, 70, 2, 40, cap=64)                     # one ragged tile
         _attn_case(ops, 500, 2, 1111, cap=1200, splits=3)
     finally:
         ops.set_option("attn_variant", 0)
@@ -389,7 +392,7 @@ def test_kernels_are_run_to_run_deterministic(ops):
                 return False
         return True
     try:
-        for av in (1, 2, 3):
+        for av in (1, 2, 3, 4, 5, 6):
             ops.set_option("attn_variant", av)
             assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
         ops.set_option("attn_variant", 0)
