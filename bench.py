@@ -164,6 +164,35 @@ def vae_decode_leg():
             "conv_frac_of_bf16_peak": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
 
+def per_block_decode_leg(clip_with_callback):
+    """BASELINE config 2 end to end (PER_BLOCK): the same clip with every finished block handed to the VAE decoder the way the
+    streaming pipeline does (`decode_to_pixel(block, use_cache=True, chunk_size=1)` from the block callback).  Measured AFTER the
+    timed region; `value` keeps SURVEY §8d's definition (generator calls only)."""
+    import time
+    from inferix_amd.vae import HipWanVAEWrapper, synthetic_decoder_state_dict
+    vae = HipWanVAEWrapper(synthetic_decoder_state_dict(seed=0))
+    frames = []
+
+    def cb(block_latent, block_index):
+        frames.append(vae.decode_to_pixel(block_latent, use_cache=True, chunk_size=1))
+
+    # (decoding block b on a second HIP stream while block b + 1 is denoised was measured too: 1494.8 vs 1498.9 ms per clip — both
+    #  workloads fill the chip, the streams serialise)
+    clip_with_callback(cb)
+    torch.cuda.synchronize()
+    frames.clear()
+    t0 = time.perf_counter()
+    clip_with_callback(cb)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    n_video = sum(int(f.shape[1]) for f in frames)
+    del vae
+    torch.cuda.empty_cache()
+    return {"workload": "config 2 end to end: 7 blocks x (4 denoise + 1 context forwards + per-block VAE decode to 480x832 pixels)",
+            "ms_per_clip": round(ms, 1), "latent_frames_per_s": round(FRAMES / ms * 1e3, 3), "video_frames": n_video,
+            "video_frames_per_s": round(n_video / ms * 1e3, 1)}
+
+
 def text_encoder_leg():
     """Time-to-first-block component of a prompt switch, measured AFTER the timed region and not part of
     `value`: umT5-XXL encoder (24 layers, dim 4096, synthetic weights generated on the device) on one 512-token prompt."""
@@ -331,7 +360,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Self-Forcing 480p bf16 (Wan2.1-T2V-1.3B causal DiT, 30 layers), block_size=3, "
                                    "21 latent frames = 7 blocks x (4 denoise + 1 context) generator forwards, paged KV "
-                                   "prefix 4680..32760 keys, NO_DECODE (text encoder / VAE outside the path)",
+                                   "prefix 4680..32760 keys; `value` counts the generator calls (SURVEY 8d), the per-block VAE decode of config 2 "
+                                   "is measured beside it (`per_block_decode`, `vae_decode`), the text encoder in `text_encoder`",
                        "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
                        "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
                        "layers": model.num_layers},
@@ -353,6 +383,9 @@ def main():
         if breakdown:
             res["kernel_breakdown"] = breakdown
         if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
+            res["per_block_decode"] = per_block_decode_leg(lambda cb: pipe.inference(
+                noise=noise, text_prompts=["synthetic"], kv_cache_manager=kvm, kv_cache_requests=reqs,
+                decode_mode=DecodeMode.NO_DECODE, free_cache_before_vae=False, block_callback=cb))
             res["vae_decode"] = vae_decode_leg()
         if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
             res["text_encoder"] = text_encoder_leg()
