@@ -35,5 +35,16 @@ if "norm" in which:
     mod = rnd(3, 6, d)
     for _ in range(reps):
         ops.layernorm(x, 1e-6, mod=mod, rows_per_group=1560)
+if "conv" in which:
+    # the three dominant decoder shapes: 96->96 @480x832 (12 frames), 192->192 @240x416 (12), 384->384 @120x208 (6)
+    for c, h, w_, t in ((96, 480, 832, 12), (192, 240, 416, 12), (384, 120, 208, 6)):
+        ring = rnd(t + 2, h, w_, c)
+        wt = (rnd(27, c, c) * (27 * c) ** -0.5).contiguous()
+        b = rnd(c)
+        res = rnd(t, h, w_, c)
+        y = torch.empty(t, h, w_, c, dtype=torch.bfloat16, device=dev)
+        for _ in range(reps):
+            ops.conv3d_cl(ring, list(range(t + 2)), wt, b, kt=3, ks=3, y=y, out_slots=list(range(t)), residual=res)
+        del ring, res, y
 torch.cuda.synchronize()
 print("pmc_micro done", which, L)
