@@ -22,6 +22,9 @@
 
 #include "ifx_common.h"
 
+#ifndef IFX_T8_NST
+#define IFX_T8_NST 2
+#endif
 #ifndef IFX_SMALL_NST64
 #define IFX_SMALL_NST64 3
 #endif
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
 // (pick_tile in ifx_gemm.hip); same operand roles, swizzled DMA and LDS-transposed epilogue as above.
 //   LDS rows are 64 B (32 bf16): physical 16-byte chunk = logical chunk XOR ((row >> 2) & 3).
 template <int BM, int BN, int WAVES_M, int NST, int EPI>
-__global__ __launch_bounds__(512, (BM * BN <= 128 * 128 && NST <= 2) ? 3 : ((BM * BN <= 256 * 128 && NST <= 2) ? 2 : 1)) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
+__global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : ((BM * BN <= 256 * 128 && NST <= 2) ? 2 : 1)) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
                                                        const unsigned short* __restrict__ w,
                                                        unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                        int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
@@ -739,7 +742,7 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   if (tile == 4) return launch_small<128, 64, IFX_SMALL_NST64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 3) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 5) return launch_big<256, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // two workgroups per CU
-  if (tile == 6) return launch_big<128, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // eight waves, three per CU
+  if (tile == 6) return launch_big<128, 128, 2, IFX_T8_NST>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // eight waves, several per CU
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 
