@@ -454,6 +454,178 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
 // 32 KiB stages keep 96 KiB in flight in a 128 KiB ring.  Used when the tile count still fills the chip
 // (pick_tile in ifx_gemm.hip); same operand roles, swizzled DMA and LDS-transposed epilogue as above.
 //   LDS rows are 64 B (32 bf16): physical 16-byte chunk = logical chunk XOR ((row >> 2) & 3).
+// ---------------------------------------------------------------------------------------------------------------------
+// Warp-specialised tile: waves 0-3 (one per SIMD, the older ones) only compute, waves 4-7 only issue the LDS-DMA of the operand
+// stages.  An LDS-DMA instruction stalls its issuing wave ~65 cycles and serialises per SIMD, but does not slow the MFMAs of the
+// other wave on that SIMD (tools/probe_overlap.hip) — in the other kernels every wave spends a third to a half of each K-step
+// issuing loads with nothing queued on the matrix pipe.  BM x BN x 64 tile, consumer wave = (BM/2) x (BN/2).
+template <int BM, int BN, int NST, int EPI>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                      const unsigned short* __restrict__ w, unsigned short* __restrict__ y, int ldy,
+                                                      int M, int N, int K, int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
+  constexpr int BK = 64;
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int A_OFF = 0, B_OFF = BM * BK * 2;
+  constexpr int PA = BM / 32, PB = BN / 32, P = PA + PB;     // 1 KiB pieces per PRODUCER wave per K-tile (8 rows each)
+  constexpr int WM = BM / 2, WN = BN / 2, TJ = WM / 32, TI = WN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int t_id = xcd * per_xcd + slot_i;
+  if (slot_i >= per_xcd || t_id >= total) return;
+  constexpr int GM = 4;
+  const int tiles_n = total / tiles_m;
+  const int grp_sz = GM * tiles_n;
+  const int first_m = (t_id / grp_sz) * GM;
+  const int gm = min(GM, tiles_m - first_m);
+  const int rem = t_id % grp_sz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+  const int KT = K / BK;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  if (producer) {
+    const int pw = wave - 4;
+    const int r8 = lane >> 3, pc = lane & 7;
+    const unsigned short* src_a[PA];
+    const unsigned short* src_b[PB];
+#pragma unroll
+    for (int r = 0; r < PA; ++r) {
+      const int row = (r * 4 + pw) * 8 + r8;
+      src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int r = 0; r < PB; ++r) {
+      const int row = (r * 4 + pw) * 8 + r8;
+      src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 1) & 7)) * 8;
+    }
+    auto issue = [&](int kt) {
+      unsigned char* st = smem + (kt % NST) * STAGE;
+      const size_t ko = (size_t)kt * BK;
+#pragma unroll
+      for (int r = 0; r < PA; ++r)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * 4 + pw) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int r = 0; r < PB; ++r)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_b[r] + ko), (lds_ptr_t)(st + B_OFF + (r * 4 + pw) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < KT) issue(i);
+    for (int kt = 0; kt < KT; ++kt) {
+      const int later = min(KT - 1 - kt, NST - 2);          // stages that may stay in flight behind stage kt
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // stage kt published; the slot of stage kt-1 is drained
+      if (kt + NST - 1 < KT) issue(kt + NST - 1);
+    }
+    __builtin_amdgcn_s_barrier();                           // the consumers' epilogue barrier
+    return;
+  }
+
+  const int wm = wave & 1, wn = wave >> 1;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_row_off[TJ], b_row_off[TI], a_swz[TJ], b_swz[TI];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int row = wm * WM + j * 32 + l31;
+    a_row_off[j] = A_OFF + row * 128;
+    a_swz[j] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int row = wn * WN + i * 32 + l31;
+    b_row_off[i] = B_OFF + row * 128;
+    b_swz[i] = (row >> 1) & 7;
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own fragment reads of stage kt-1 retired
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* st = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + hi;
+      bf16x8 fa[TJ], fb[TI];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fb[i] = *reinterpret_cast<const bf16x8*>(st + b_row_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(st + a_row_off[j] + ((c ^ a_swz[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (consumer waves): per-wave LDS transpose of v = bf16(acc + bias), then row-contiguous 16-byte accesses
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int RB = WN * 2, CR = RB / 16, RP = 64 / CR;
+  unsigned char* tw = smem + wave * (WM * RB);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int mrow = j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = i * 32 + g * 8 + hi * 4;
+        const int n = n_base + wn * WN + nl;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (ea.bias && n < N) {
+          const u16x4 bv = *reinterpret_cast<const u16x4*>(ea.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(bv[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        const int chunk = (nl >> 3) ^ (mrow & (CR - 1));
+        *reinterpret_cast<u16x4*>(tw + mrow * RB + chunk * 16 + (nl & 4) * 2) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rr = lane / CR, cc = lane % CR;
+#pragma unroll
+    for (int p = 0; p < WM / RP; ++p) {
+      const int mrow = p * RP + rr;
+      const int m = m_base + wm * WM + mrow;
+      const int n = n_base + wn * WN + cc * 8;
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * RB + ((cc ^ (mrow & (CR - 1))) << 4));
+      if (m >= M || n >= N) continue;
+      u16x8 o;
+      if (EPI == IFX_EPI_BIAS) {
+        o = vv;
+      } else if (EPI == IFX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+      } else {
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
+        if (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + bf2f(vv[e]));
+        } else {
+          const u16x8 gv = *reinterpret_cast<const u16x8*>(
+              ea.mod + ((size_t)(m / ea.rows_per_group) * ea.mod_slots + ea.gate_slot) * N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+        }
+      }
+      *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+    }
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int NST, int EPI>
 __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : ((BM * BN <= 256 * 128 && NST <= 2) ? 2 : 1)) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
                                                        const unsigned short* __restrict__ w,
@@ -661,6 +833,36 @@ static int launch_big(const unsigned short* x, int ldx, const unsigned short* w,
 }
 
 template <int BM, int BN, int NST>
+static int launch_ws(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
+                     int mode, const EpiArgs2& ea, hipStream_t s) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const dim3 grid(per_xcd * 8), block(512);
+  constexpr size_t lds_main = (size_t)NST * (BM + BN) * 128, lds_epi = (size_t)BM * BN * 2;
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+#define IFX_LAUNCH_WS(E)                                                                                             \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, NST, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                           \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, NST, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
+                       per_xcd, ea);                                                                                 \
+  } while (0)
+  switch (mode) {
+    case IFX_EPI_BIAS: IFX_LAUNCH_WS(IFX_EPI_BIAS); break;
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_WS(IFX_EPI_GELU_TANH); break;
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_WS(IFX_EPI_RESIDUAL); break;
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_WS(IFX_EPI_GATE_RES); break;
+    default: return IFX_EINVAL;
+  }
+#undef IFX_LAUNCH_WS
+  return check_launch("ifx_gemm_bf16");
+}
+
+template <int BM, int BN, int NST>
 static int launch_small(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                         int N, int K, int mode, const EpiArgs2& ea, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -742,6 +944,8 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   if (tile == 4) return launch_small<128, 64, IFX_SMALL_NST64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 3) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 5) return launch_big<256, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // two workgroups per CU
+  if (tile == 7) return launch_ws<256, 128, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // warp-specialised (producer / consumer waves)
+  if (tile == 8) return launch_ws<128, 128, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // same, 64 KiB: two workgroups per CU
   if (tile == 6) return launch_big<128, 128, 2, IFX_T8_NST>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // eight waves, several per CU
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }

@@ -99,6 +99,94 @@ static void run(const unsigned char* d, size_t region, size_t row_pitch, const c
          1024 / ROWB, NOUT, NOUT * 8, bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.4e9);
 }
 
+// Shared-panel pattern of a GEMM: groups of `share` consecutive workgroups (same XCD via blockIdx & 7 kept equal) stream the
+// SAME 64 KiB panel; rot = 1 rotates each workgroup's starting offset inside the panel (stagger-K).
+template <int NOUT>
+__global__ __launch_bounds__(512) void stream_shared(const unsigned char* __restrict__ src, int share, int rot, int iters, float* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;            // idx-th workgroup of this XCD
+  const int panel = xcd * 64 + idx / share;                         // which 64 KiB panel
+  const unsigned char* base = src + (size_t)panel * 65536;
+  size_t pos = rot ? (size_t)(idx % share) * (65536 / share) : 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + ((pos + wave * 1024 + lane * 16) & 65535)),
+                                       (lds_ptr_t)(smem + ((it * NOUT + k) % 16) * 8192 + wave * 1024), 16, 0, 0);
+      pos += 8192;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT / 2) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && out) out[blockIdx.x] = smem[0];
+}
+
+// GEMM operand pattern with cheap addressing: one instruction = ROWS rows x (1024 / ROWS) bytes, rows `pitch` bytes apart; the
+// workgroup walks K (columns) of a [512 rows][pitch] panel that stays L2-resident (32 workgroups of an XCD share it).
+template <int ROWS, int NOUT>
+__global__ __launch_bounds__(512) void stream_rows(const unsigned char* __restrict__ src, int pitch, int iters, float* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RB = 1024 / ROWS, CPR = RB / 16;                    // row bytes per instruction, 16-byte chunks per row
+  const int row = wave * ROWS + lane / CPR, chunk = lane % CPR;
+  const unsigned char* p = src + (size_t)(blockIdx.x & 7) * (512 * 3072) + (size_t)row * pitch + chunk * 16;
+  int col = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+      // k-th instruction of the step: next block of 8 * ROWS rows, same K columns
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p + (size_t)((k & 7) * 8 * ROWS) * pitch + col),
+                                       (lds_ptr_t)(smem + ((it * NOUT + k) % 16) * 8192 + wave * 1024), 16, 0, 0);
+    }
+    col = (col + RB) & (pitch - 1 >= 2047 ? 2047 : 1023);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT / 2) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && out) out[blockIdx.x] = smem[0];
+}
+
+template <int ROWS>
+static void run_rows(const unsigned char* d, int pitch) {
+  constexpr int NOUT = 8;
+  const int iters = 4000;
+  hipFuncSetAttribute((const void*)stream_rows<ROWS, NOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipEvent_t s, e;
+  hipEventCreate(&s);
+  hipEventCreate(&e);
+  stream_rows<ROWS, NOUT><<<256, 512, 131072>>>(d, pitch, iters, nullptr);
+  hipDeviceSynchronize();
+  hipEventRecord(s);
+  stream_rows<ROWS, NOUT><<<256, 512, 131072>>>(d, pitch, iters, nullptr);
+  hipEventRecord(e);
+  hipEventSynchronize(e);
+  float ms;
+  hipEventElapsedTime(&ms, s, e);
+  const double bytes = 256.0 * 8 * 1024.0 * NOUT * iters;
+  printf("L2 hits, GEMM rows: %2d rows x %4d B per instruction, pitch %4d B: %7.2f TB/s = %5.1f B/clk/CU @2.4GHz\n", ROWS,
+         1024 / ROWS, pitch, bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.4e9);
+}
+
+static void run_shared(const unsigned char* d, int share, int rot) {
+  constexpr int NOUT = 12;
+  const int iters = 2000 / NOUT * 4;
+  hipFuncSetAttribute((const void*)stream_shared<NOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipEvent_t s, e;
+  hipEventCreate(&s);
+  hipEventCreate(&e);
+  stream_shared<NOUT><<<256, 512, 131072>>>(d, share, rot, iters, nullptr);
+  hipDeviceSynchronize();
+  hipEventRecord(s);
+  stream_shared<NOUT><<<256, 512, 131072>>>(d, share, rot, iters, nullptr);
+  hipEventRecord(e);
+  hipEventSynchronize(e);
+  float ms;
+  hipEventElapsedTime(&ms, s, e);
+  const double bytes = 256.0 * 8 * 1024.0 * NOUT * iters;
+  printf("L2 hits, %2d workgroups of an XCD share one 64 KiB panel%s: %7.2f TB/s = %5.1f B/clk/CU @2.4GHz\n", share,
+         rot ? ", rotated start" : ", same order   ", bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.4e9);
+}
+
 int main() {
   unsigned char* d;
   const size_t total = (size_t)256 * (64 << 20);           // 16 GiB: 64 MiB per workgroup
@@ -120,6 +208,16 @@ int main() {
     run_vgpr<1024, 8>(d, region, 1024, what);
     run_vgpr<128, 4>(d, region, 3072, what);
     run_vgpr<128, 16>(d, region, 3072, what);
+  }
+  run_rows<1>(d, 3072);
+  run_rows<4>(d, 3072);
+  run_rows<8>(d, 3072);
+  run_rows<16>(d, 3072);
+  run_rows<8>(d, 2048);
+  run_rows<16>(d, 2048);
+  for (int share : {1, 8, 32}) {
+    run_shared(d, share, 0);
+    if (share > 1) run_shared(d, share, 1);
   }
   return 0;
 }
