@@ -626,12 +626,16 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const unsigned short* __re
   }
 }
 
-template <int BM, int BN, int WAVES_M, int NST, int EPI>
+// BK = 32: operand rows of 64 B in LDS; BK = 64: rows of 128 B.  LDS-DMA moves rows of >= 128 B from L2 at 52-58 B/clk/CU and
+// 64-byte rows at HALF of that (tools/probe_dma.hip: a 64-byte request still costs a 128-byte line), so the 64-deep variant pays
+// half the DMA time per byte; it needs (BM + BN) * 128 B per stage (64 KiB for 256x256: two stages).
+template <int BM, int BN, int WAVES_M, int NST, int EPI, int BK = 32>
 __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : ((BM * BN <= 256 * 128 && NST <= 2) ? 2 : 1)) void gemm_big_kernel(const unsigned short* __restrict__ x, int ldx,
                                                        const unsigned short* __restrict__ w,
                                                        unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                        int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
-  constexpr int BK = 32;
+  constexpr int CPR = BK / 8, RPP = 64 / CPR;           // 16-byte chunks per row (4 | 8), rows per 1 KiB DMA piece (16 | 8)
+  constexpr int SW_SH = BK == 32 ? 2 : 1;                // swizzle phase: (row >> SW_SH) & (CPR - 1)
   constexpr int STAGE = (BM + BN) * BK * 2;              // 32 KiB (256x256) / 24 KiB (256x128)
   constexpr int A_OFF = 0, B_OFF = BM * BK * 2;          // x tile [BM][64 B], W tile [BN][64 B]
   constexpr int WAVES_N = 8 / WAVES_M;
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
   // SIMD free (tools/probe_overlap.hip): with IFX_GEMM_LOADERS = 4 only waves 0-3 (the older wave of each SIMD) issue the
   // pieces of both waves, the younger ones go straight to the matrix pipe after the barrier.
   constexpr int LW = IFX_GEMM_LOADERS, LM = 8 / LW;      // loader waves, wave-slots per loader
-  constexpr int PA = BM / 128 * LM, PB = BN / 128 * LM, P = PA + PB;   // DMA instructions per LOADER wave per K-tile (16 rows each)
+  constexpr int PA = BM / (8 * RPP) * LM, PB = BN / (8 * RPP) * LM, P = PA + PB;   // DMA instructions per LOADER wave per K-tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -657,21 +661,21 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
   const int m_base = tile_m * BM, n_base = tile_n * BN;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
-  // LDS-DMA: one wave-instruction = 16 rows x 64 B; lane -> row (lane >> 2), physical chunk (lane & 3)
-  const int r16 = lane >> 2, pc = lane & 3;
+  // LDS-DMA: one wave-instruction = RPP rows x (BK * 2) B; lane -> row (lane / CPR), physical chunk (lane % CPR)
+  const int r16 = lane / CPR, pc = lane % CPR;
   const unsigned short* src_a[PA];
   const unsigned short* src_b[PB];
   const bool loader = wave < LW;
   // piece index of (r, wave): r * LW + wave, covering rows [16 piece, 16 piece + 16)
 #pragma unroll
   for (int r = 0; r < PA; ++r) {
-    const int row = (r * LW + wave) * 16 + r16;
-    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 2) & 3)) * 8;
+    const int row = (r * LW + wave) * RPP + r16;
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> SW_SH) & (CPR - 1))) * 8;
   }
 #pragma unroll
   for (int r = 0; r < PB; ++r) {
-    const int row = (r * LW + wave) * 16 + r16;
-    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 2) & 3)) * 8;
+    const int row = (r * LW + wave) * RPP + r16;
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> SW_SH) & (CPR - 1))) * 8;
   }
   auto issue = [&](int kt) {
     unsigned char* st = smem + (kt % NST) * STAGE;
@@ -702,14 +706,14 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int row = wm * WM + j * 32 + l31;
-    a_off[j] = A_OFF + row * 64;
-    a_swz[j] = (row >> 2) & 3;
+    a_off[j] = A_OFF + row * (BK * 2);
+    a_swz[j] = (row >> SW_SH) & (CPR - 1);
   }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int row = wn * WN + i * 32 + l31;
-    b_off[i] = B_OFF + row * 64;
-    b_swz[i] = (row >> 2) & 3;
+    b_off[i] = B_OFF + row * (BK * 2);
+    b_swz[i] = (row >> SW_SH) & (CPR - 1);
   }
 
   for (int kt = 0; kt < KT; ++kt) {
@@ -723,22 +727,25 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
     __builtin_amdgcn_s_barrier();
     if (kt + NST - 1 < KT && loader) issue(kt + NST - 1);
     const unsigned char* st = smem + (kt % NST) * STAGE;
-    bf16x8 fa[2][TJ], fb[2][TI];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = 2 * ks + hi;
+    for (int half = 0; half < BK / 32; ++half) {           // 32 channels at a time: two k-steps of fragments in registers
+      bf16x8 fa[2][TJ], fb[2][TI];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) fb[ks][i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + ((c ^ b_swz[i]) << 4));
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 4 * half + 2 * ks + hi;
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) fa[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_off[j] + ((c ^ a_swz[j]) << 4));
+        for (int i = 0; i < TI; ++i) fb[ks][i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fa[ks][j] = *reinterpret_cast<const bf16x8*>(st + a_off[j] + ((c ^ a_swz[j]) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
   }
 
   // ---- epilogue: per-wave LDS transpose of v = bf16(acc + bias) (128 tokens x 128 B, 16 KiB per wave = the whole
@@ -802,23 +809,23 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
   }
 }
 
-template <int BM, int BN, int WAVES_M, int NST>
+template <int BM, int BN, int WAVES_M, int NST, int BK = 32>
 static int launch_big(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N,
                       int K, int mode, const EpiArgs2& ea, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(512);
-  constexpr size_t lds_main = (size_t)NST * (BM + BN) * 64, lds_epi = (size_t)BM * BN * 2;   // rings / per-wave transposes
+  constexpr size_t lds_main = (size_t)NST * (BM + BN) * BK * 2, lds_epi = (size_t)BM * BN * 2;   // rings / per-wave transposes
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
 #define IFX_LAUNCH_GB(E)                                                                                             \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WAVES_M, NST, E>,                               \
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WAVES_M, NST, E, BK>,                               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WAVES_M, NST, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K,  \
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WAVES_M, NST, E, BK>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K,  \
                        tiles_m, total, per_xcd, ea);                                                                 \
   } while (0)
   switch (mode) {
@@ -942,8 +949,9 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   EpiArgs2 ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
   if (tile == 1) return launch_small<128, 128, IFX_SMALL_NST>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 4) return launch_small<128, 64, IFX_SMALL_NST64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
-  if (tile == 3) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 3) return launch_big<256, 256, 2, 2, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // 128-byte operand rows: full-rate LDS-DMA (FFN up 171 -> 164 us)
   if (tile == 5) return launch_big<256, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // two workgroups per CU
+  if (tile == 9) return launch_big<256, 256, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // the 32-deep four-stage predecessor of tile 3
   if (tile == 7) return launch_ws<256, 128, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // warp-specialised (producer / consumer waves)
   if (tile == 8) return launch_ws<128, 128, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // same, 64 KiB: two workgroups per CU
   if (tile == 6) return launch_big<128, 128, 2, IFX_T8_NST>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // eight waves, several per CU

@@ -329,7 +329,7 @@ def test_gemm_ffn_real_shapes(ops):
     assert_bf16_parity(y, torch.nn.functional.linear(u_ref, w2, b2), what="ffn.2 8960->1536")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", [(585, 1536, 1536), (300, 640, 256), (77, 64, 64), (1170, 4608, 1536)])
 def test_gemm_every_tile_variant(ops, variant, M, N, K):
     """Each GEMM kernel (register-staged 128x128, LDS-DMA 256x128 / 128x128 / 64x64) on shard shapes with ragged
