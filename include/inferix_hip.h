@@ -256,7 +256,8 @@ int ifx_kv_scatter_shards(const ifx_bf16* gathered, int32_t world, int32_t frame
  *              history frames, then the new ones) lives at x + in_slots[f] * in_frame_stride; in_slots[f] < 0
  *              = an all-zero frame (the causal padding in front of the stream)
  *   upsample   1: the 3x3 taps read the nearest-2x upsampled frame (output 2hs x 2ws), never materialised
- *   w          [kt*ks*ks][cout][cin] bf16 (tap-major repack of the torch [cout][cin][kt][ks][ks] weight)
+ *   w          [kt*ks*ks][cin/32][cout][32] bf16: tap-major, 32-channel-chunk-major repack of the torch
+ *              [cout][cin][kt][ks][ks] weight (a DMA piece of 16 output channels x 32 input channels is contiguous)
  *   y          output frame t at y + out_slots[t] * out_frame_stride, [ho][wo][cout]
  *   residual   NULL or contiguous [t_out][ho][wo][cout]: y = bf16(bf16(conv + bias) + residual)
  *   zero_page  >= 64 bytes of zeros in device memory

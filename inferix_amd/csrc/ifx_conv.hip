@@ -13,7 +13,8 @@
 //     offset — 3.9 patch loads per output pixel-chunk instead of the 27 an implicit GEMM gathers.  The nearest-2x
 //     upsample in front of the `Resample` conv2d is folded into the fragment address (source pixel = (o + d - 1) >> 1),
 //     so the 4x larger upsampled tensor never exists.
-//   * weights [tap][Cout][Cin] stream through a ring of groups (one kernel row = 3 taps x 32 channels x BN rows), one or
+//   * weights, packed [tap][Cin/32][Cout][32] so that a 1 KiB DMA piece (16 rows x 64 B) is CONTIGUOUS (LDS-DMA moves 64-byte rows
+//     128 bytes apart at half rate, tools/probe_dma.hip), stream through a ring of groups (one kernel row = 3 taps x 32 channels x BN rows), one or
 //     two groups ahead; ONE barrier per group, and inside a group the fragments of tap i+1 are read under the MFMAs of
 //     tap i (a barrier per tap left the matrix pipe idle for the LDS latency of every tap: 845 -> see DESIGN.md).
 //   * both DMA streams share the wave's vmcnt; the wait before group g allows exactly the instructions issued after
@@ -151,19 +152,19 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
   for (int q = 0; q < WPW; ++q) {
     const int idx = wave + LW * q;
     const int wrow = (idx % G::WP) * 16 + (lane >> 2);
-    woff[q] = min(n_base + wrow, A.Cout - 1) * A.Cin + (((lane & 3) ^ ((wrow >> 2) & 3)) << 3);
+    woff[q] = min(n_base + wrow, A.Cout - 1) * 32 + (((lane & 3) ^ ((wrow >> 2) & 3)) << 3);     // [tap][cc][cout][32]: 64-byte rows, contiguous
   }
   auto issue_w = [&](int g) {                       // all weight pieces of this wave for group g
     const int s = g / GPS, gi = g - s * GPS;
     const int dt = s / CC, cc = s - dt * CC;
-    const unsigned short* wbase = A.w + (size_t)(dt * TAPS + gi * TG) * A.Cout * A.Cin + cc * 32;
+    const unsigned short* wbase = A.w + ((size_t)(dt * TAPS + gi * TG) * CC + cc) * A.Cout * 32;
     unsigned char* ring = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {
       const int idx = wave + LW * q;
       const int tg = idx / G::WP;                   // tap within the group
       const bool real = idx < TG * G::WP;
-      const unsigned short* src = wbase + (size_t)(real ? min(tg, TG - 1) : 0) * A.Cout * A.Cin + woff[q];
+      const unsigned short* src = wbase + (size_t)(real ? min(tg, TG - 1) : 0) * CC * A.Cout * 32 + woff[q];
       unsigned char* dst = real ? ring + tg * G::W_TAP + (idx % G::WP) * 1024 : smem + G::S_OFF + wave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     }

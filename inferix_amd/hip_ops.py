@@ -381,13 +381,13 @@ def _slots(v) -> "C.Array":
 def conv3d_cl(x: torch.Tensor, in_slots, w: torch.Tensor, bias: Optional[torch.Tensor], *, kt: int, ks: int,
               y: torch.Tensor, out_slots, upsample: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Causal conv on channels-last frames (ifx_conv3d_cl).  `x` `[slots, hs, ws, cin]`, logical input frame f at
-    `x[in_slots[f]]` (negative slot = zero frame; `t_out + kt - 1` entries); `w` `[kt*ks*ks, cout, cin]`; output frame t
+    `x[in_slots[f]]` (negative slot = zero frame; `t_out + kt - 1` entries); `w` `[kt*ks*ks, cin/32, cout, 32]`; output frame t
     goes to `y[out_slots[t]]` `[ho, wo, cout]`; `residual` `[t_out, ho, wo, cout]`."""
     t_out = len(out_slots)
     assert len(in_slots) == t_out + kt - 1, (len(in_slots), t_out, kt)
     _, hs, ws, cin = x.shape
-    taps, cout, cin_w = w.shape
-    assert taps == kt * ks * ks and cin_w == cin and x.is_contiguous() and y.is_contiguous() and w.is_contiguous()
+    taps, cc, cout, c32 = w.shape
+    assert taps == kt * ks * ks and c32 == 32 and cc * 32 == cin and x.is_contiguous() and y.is_contiguous() and w.is_contiguous()
     ho, wo = (hs * 2, ws * 2) if upsample else (hs, ws)
     assert tuple(y.shape[1:]) == (ho, wo, cout), (tuple(y.shape), ho, wo, cout)
     assert max(out_slots) < y.shape[0] and max(in_slots) < x.shape[0]

@@ -38,12 +38,15 @@ VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
 
 
 def _repack_conv(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
-    """torch conv weight `[cout, cin, (kt,) kh, kw]` -> tap-major `[taps, cout, cin]` bf16 (ifx_conv3d_cl layout)."""
+    """torch conv weight `[cout, cin, (kt,) kh, kw]` -> `[taps, cin/32, cout, 32]` bf16 (ifx_conv3d_cl layout: tap-major, then
+    32-channel chunks, so that the 16-row x 64-byte pieces the kernel DMAs are contiguous)."""
     cout, cin = w.shape[:2]
-    t = w.reshape(cout, cin, -1).permute(2, 0, 1)
-    if cin_pad > cin:
-        t = torch.nn.functional.pad(t, (0, cin_pad - cin))
-    return t.contiguous().to(BF16)
+    t = w.reshape(cout, cin, -1).permute(2, 0, 1)                       # [taps, cout, cin]
+    cin_p = max(cin_pad, (cin + 31) // 32 * 32)
+    if cin_p > cin:
+        t = torch.nn.functional.pad(t, (0, cin_p - cin))
+    taps = t.shape[0]
+    return t.reshape(taps, cout, cin_p // 32, 32).permute(0, 2, 1, 3).contiguous().to(BF16)
 
 
 def synthetic_decoder_state_dict(dim: int = 96, z_dim: int = 16, dim_mult: Sequence[int] = (1, 2, 4, 4),

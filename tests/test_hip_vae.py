@@ -1,5 +1,6 @@
 """GPU parity of the VAE decoder path: `ifx_conv3d_cl`, `ifx_rmsnorm_cl`, `ifx_softmax_rows` per op and
 `HipWanVAEWrapper.decode_to_pixel` end to end against the CPU oracle and the reference-generated golden pixels."""
+import ctypes as C
 import os
 
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")        # the on-device oracle of the 480p test: no exhaustive kernel search
@@ -102,11 +103,16 @@ def test_conv3d_cl_zero_history_is_causal_padding(ops):
 
 def test_conv3d_cl_argument_errors(ops):
     from inferix_amd import _hip
-    x = torch.zeros(3, 8, 8, 48, dtype=BF, device="cuda")
-    w = torch.zeros(27, 32, 48, dtype=BF, device="cuda")
+    x = torch.zeros(3, 8, 8, 64, dtype=BF, device="cuda")
+    w = torch.zeros(27, 2, 32, 32, dtype=BF, device="cuda")
     y = torch.zeros(1, 8, 8, 32, dtype=BF, device="cuda")
-    with pytest.raises(_hip.HipKernelError, match="multiple of 32"):
-        ops.conv3d_cl(x, [0, 1, 2], w, None, kt=3, ks=3, y=y, out_slots=[0])
+    with pytest.raises(_hip.HipKernelError, match="temporal kernel"):
+        d = _hip.Conv3dDesc(x.data_ptr(), 8 * 8 * 64, (C.c_int32 * 3)(0, 1, 2), 8, 8, 64, 0, w.data_ptr(), None, 2, 3, y.data_ptr(),
+                            8 * 8 * 32, (C.c_int32 * 1)(0), 32, 1, None, x.data_ptr())
+        _hip.check(_hip.load().ifx_conv3d_cl(C.byref(d), torch.cuda.current_stream().cuda_stream), "ifx_conv3d_cl")
+    x48 = torch.zeros(3, 8, 8, 48, dtype=BF, device="cuda")
+    with pytest.raises(AssertionError):
+        ops.conv3d_cl(x48, [0, 1, 2], w, None, kt=3, ks=3, y=y, out_slots=[0])
 
 
 @pytest.mark.parametrize("c,silu", [(32, True), (96, True), (128, False), (192, True), (384, True), (384, False)])

@@ -63,8 +63,8 @@ def main():
             r = orig(x, in_slots, w, bias, kt=kt, ks=ks, y=y, out_slots=out_slots, upsample=upsample, residual=residual)
             e_.record()
             ho, wo = y.shape[1], y.shape[2]
-            key = f"k{kt}x{ks}x{ks}{'u' if upsample else ''} {x.shape[3]}->{w.shape[1]} @{ho}x{wo} t{len(out_slots)}"
-            recs.append((key, s_, e_, 2.0 * len(out_slots) * ho * wo * w.shape[1] * x.shape[3] * w.shape[0]))
+            key = f"k{kt}x{ks}x{ks}{'u' if upsample else ''} {x.shape[3]}->{w.shape[2]} @{ho}x{wo} t{len(out_slots)}"
+            recs.append((key, s_, e_, 2.0 * len(out_slots) * ho * wo * w.shape[2] * x.shape[3] * w.shape[0]))
             return r
 
         import inferix_amd.vae as vmod
