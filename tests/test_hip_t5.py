@@ -144,3 +144,31 @@ def test_pipeline_takes_the_hip_text_encoder(tiny, tmp_path):
     torch.manual_seed(3)
     _, lat2 = pipe2._run_inference(["a prompt"], 3, 1, decode_mode=DecodeMode.NO_DECODE, return_latents=True)
     assert rel_l2(lat.float().cpu(), lat2.float().cpu()) < 2e-2
+
+
+def test_full_size_umt5_properties():
+    """umT5-XXL geometry (24 layers, dim 4096, 64 heads, ffn 10240; weights generated on the device): the CPU oracle is out of
+    reach here, so size-independent properties — finite, padding rows zeroed, what sits in the PADDED positions of `ids` cannot
+    change the valid rows (key-padding mask), a prompt does not depend on its batch neighbours, run-to-run bit determinism."""
+    from inferix_amd.t5 import HipWanTextEncoder, synthetic_t5_state_dict
+    enc = HipWanTextEncoder(synthetic_t5_state_dict(device="cuda", seed=5), None)
+    g = torch.Generator().manual_seed(2)
+    L, lens = 512, [77, 300]
+    ids = torch.randint(1, 256384, (2, L), generator=g)
+    mask = torch.zeros(2, L, dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    a = enc.encode_ids(ids, mask)["prompt_embeds"]
+    assert a.shape == (2, L, 4096) and a.dtype == BF and torch.isfinite(a.float()).all()
+    assert all(float(a[b, n:].abs().max()) == 0.0 for b, n in enumerate(lens))
+    assert float(a[0, :77].float().std()) > 0.1
+    ids2 = ids.clone()
+    ids2[0, 77:] = torch.randint(1, 256384, (L - 77,), generator=g)          # garbage behind the mask
+    b2 = enc.encode_ids(ids2, mask)["prompt_embeds"]
+    assert torch.equal(a[0, :77], b2[0, :77]) and torch.equal(a[1], b2[1])
+    one = enc.encode_ids(ids[1:], mask[1:])["prompt_embeds"]
+    assert torch.equal(one[0], a[1])
+    assert torch.equal(a, enc.encode_ids(ids, mask)["prompt_embeds"])
+    del enc
+    torch.cuda.empty_cache()
