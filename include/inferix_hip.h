@@ -43,7 +43,9 @@ const char* ifx_arch(void);            /* "gfx950" */
 /* Kernel-selection override for benchmarking and tests (default 0 = choose by shape):
  *   "gemm_variant": 1 register-staged 128x128; LDS-DMA tiles 2 = 256x128x64, 3 = 128x128x64 (two workgroups per CU),
  *                   4 = 64x64, 5 = 256x256x64, 6 = 128x64, 7 = 256x128x32 (two per CU), 8 = 128x128x32 (eight waves),
- *                   9 / 10 = warp-specialised 256x128 / 128x128, 11 = 256x256x32 four stages
+ *                   9 / 10 = warp-specialised 256x128 / 128x128, 11 = 256x256x32 four stages,
+ *                   12 / 13 / 14 = 64x64 (four K-groups), 64x64 (two), 128x128 (two): split-K between the wave groups of one
+ *                   workgroup, what 0 = auto picks for launches of at most one workgroup per CU; K / 64 must divide by the groups
  *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
  *                   4 free-running schedule, 5 software-pipelined schedule (what 0 = auto picks for large launches),
  *                   6 software-pipelined in four-wave workgroups, two per CU

@@ -183,12 +183,21 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
 // LDS-DMA tile choice: score = (measured relative throughput of the tile at full occupancy) x (how well the launch's
 // workgroups fill whole rounds of the chip).  256 CUs; the 64-wide tiles run two workgroups per CU.
 //   tile 3 = 256x256x32, 0 = 256x128x64, 1 = 128x128, 4 = 128x64, 2 = 64x64   (bench: tools/bench_kernels.py gemm M)
-static int pick_tile(int M, int N) {
+//   tile 10 = 64x64 with four K-groups, 11 = 64x64 with two K-groups, 12 = 128x128 with two K-groups (split-K inside the workgroup)
+static int pick_tile(int M, int N, int K) {
   struct Cand { int tile, bm, bn, slots; float base; };
   // 128x128 runs double-buffered with TWO workgroups per CU (64 KiB of LDS each): the co-resident workgroup hides the operand
   // latency better than the deep rings of the big tiles do — QKV 92 -> 83 us, O 38 -> 35, FFN down 150 -> 137 (tools/bench_gemm_tiles.py)
   static const Cand cands[] = {{3, 256, 256, 256, 1.00f}, {0, 256, 128, 256, 0.85f}, {1, 128, 128, 512, 0.95f},
-                               {4, 128, 64, 512, 0.78f},  {2, 64, 64, 512, 0.50f}};
+                               {4, 128, 64, 512, 0.68f},  {2, 64, 64, 512, 0.50f}};
+  // Few output tiles (one rank's M = 4680 / P rows of a sequence-parallel shard): the parallelism has to come from K.  Tiles 10-12
+  // split K between wave groups of ONE workgroup (no workspace, fixed summation order).  Measured, tools/bench_gemm_tiles.py 585 / 2340:
+  //   585x1536x1536 12.3 -> 9.8 us (tile 10), 585x1536x8960 43.2 -> 33.8 (tile 11), 2340x1536x8960 88.9 -> 79.7 (tile 12)
+  const int kt = K / 64;
+  const int wgs64 = ((M + 63) / 64) * ((N + 63) / 64), wgs128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (wgs64 <= 256 && kt >= 64 && kt % 2 == 0) return 11;
+  if (wgs64 <= 256 && kt >= 16 && kt % 4 == 0) return 10;
+  if (wgs128 > 128 && wgs128 <= 256 && kt >= 64 && kt % 2 == 0) return 12;
   int best = 2;
   float best_score = -1.f;
   for (const Cand& c : cands) {
@@ -203,7 +212,8 @@ static int pick_tile(int M, int N) {
 
 // kernel selection: 0 = auto (LDS-DMA kernels, tile by shape), 1 = force the register-staged 128x128 kernel,
 // 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32, 6 = force LDS-DMA 128x64,
-// 7 / 8 = the two-per-CU 256x128x32 and eight-wave 128x128x32 experiments (slower than 3, kept selectable)
+// 7 / 8 = the two-per-CU 256x128x32 and eight-wave 128x128x32 experiments (slower than 3, kept selectable),
+// 12 / 13 / 14 = the split-K-inside-the-workgroup tiles 10 / 11 / 12 (small launches)
 }  // namespace ifx
 
 using namespace ifx;
@@ -232,7 +242,7 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
   const int variant = gemm_variant();
   const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0);
   if (wide_ok && variant != 1) {
-    const int tile = variant >= 2 ? variant - 2 : pick_tile(M, N);
+    const int tile = variant >= 2 ? variant - 2 : pick_tile(M, N, K);
     return launch_gemm_lds_dma(tile, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod,
                                ea.mod_slots, ea.gate_slot, ea.rows_per_group, (hipStream_t)stream);
   }

@@ -278,8 +278,13 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short*
 // {128x128, 64x64}, 4 waves (2x2), same LDS-DMA staging / swizzle / transposed MFMA tile / LDS-transposed
 // epilogue as above, a 4-stage ring with THREE K-tiles in flight and one barrier per K-tile; the 64x64 shape
 // uses 64 KiB of LDS so two workgroups share a CU and hide each other's waits.
-template <int BM, int BN, int NST, int EPI>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* __restrict__ x, int ldx,
+// KG > 1: split-K INSIDE the workgroup — KG groups of four waves each take a contiguous 1/KG of the K tiles of the SAME output tile
+// through their own operand ring and are summed through LDS (fixed order: deterministic) before the epilogue.  For launches with at
+// most one workgroup per CU (one rank's M = 4680 / P rows of a sequence-parallel shard) the K loop of a single four-wave workgroup
+// serialises DMA issue -> fragment reads -> MFMA on each SIMD (~770 clk per 64-deep step, the matrix pipe busy for ~130 of them);
+// KG = 4 puts four waves on every SIMD without needing more output tiles.
+template <int BM, int BN, int NST, int EPI, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_small_kernel(const unsigned short* __restrict__ x, int ldx,
                                                          const unsigned short* __restrict__ w,
                                                          unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                          int tiles_m, int total, int per_xcd, EpiArgs2 ea) {
@@ -291,7 +296,9 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
   constexpr int WM = BM / 2, WN = BN / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG > 1 ? wave_all >> 2 : 0, wave = wave_all & 3;
+  unsigned char* const ring = smem + kg * (NST * STAGE);
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
   const int t_id = xcd * per_xcd + slot_i;
   if (slot_i >= per_xcd || t_id >= total) return;
@@ -318,9 +325,11 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
     const int row = (r * 4 + wave) * 8 + r8;
     src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 1) & 7)) * 8;
   }
+  const int KT = (K / BK) / KG;                               // K tiles of this group (the host checks divisibility)
+  const int kt0 = kg * KT;
   auto issue = [&](int kt) {
-    unsigned char* st = smem + (kt % NST) * STAGE;
-    const size_t ko = (size_t)kt * BK;
+    unsigned char* st = ring + (kt % NST) * STAGE;
+    const size_t ko = (size_t)(kt0 + kt) * BK;
 #pragma unroll
     for (int r = 0; r < PA; ++r)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_a[r] + ko), (lds_ptr_t)(st + A_OFF + (r * 4 + wave) * 1024), 16, 0, 0);
@@ -337,7 +346,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = K / BK;
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i)
     if (i < KT) issue(i);
@@ -360,13 +368,21 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
   for (int kt = 0; kt < KT; ++kt) {
     // own pieces of tile kt landed; up to two later tiles stay in flight
     const int later = min(KT - 1 - kt, NST - 2);
-    if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert((NST - 2) * P <= 63 && NST <= 8, "vmcnt is a 6-bit counter");
+#define IFX_WAIT_LATER(n)                                                                  \
+  else if (NST - 2 >= (n) && later == (n)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((n) * P) & 63) : "memory")
+    if (later == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IFX_WAIT_LATER(1);
+    IFX_WAIT_LATER(2);
+    IFX_WAIT_LATER(3);
+    IFX_WAIT_LATER(4);
+    IFX_WAIT_LATER(5);
+    IFX_WAIT_LATER(6);
+#undef IFX_WAIT_LATER
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own fragment reads of tile kt-1 retired
     __builtin_amdgcn_s_barrier();          // tile kt complete for everyone; the slot of tile kt-1 drained by everyone
     if (kt + NST - 1 < KT) issue(kt + NST - 1);
-    const unsigned char* st = smem + (kt % NST) * STAGE;
+    const unsigned char* st = ring + (kt % NST) * STAGE;
     bf16x8 fa[4][TJ], fb[4][TI];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -388,6 +404,38 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const unsigned short* _
   // ---- epilogue: per-wave LDS transpose of v = bf16(acc + bias), then row-contiguous 16-byte accesses
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (KG > 1) {
+    // partial sums of groups 1..KG-1 -> LDS (behind the transposes of the epilogue), [group][wave][i][j][quad][lane] x 16 B
+    float* part = reinterpret_cast<float*>(smem + BM * BN * 2);
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int slot = ((((kg - 1) * 4 + wave) * TI + i) * TJ + j) * 4 + q;
+            *reinterpret_cast<f32x4*>(part + (size_t)slot * 256 + lane * 4) =
+                f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int slot = ((((g - 1) * 4 + wave) * TI + i) * TJ + j) * 4 + q;
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(part + (size_t)slot * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += pv[e];
+          }
+  }
   constexpr int RB = WN * 2, CR = RB / 16, RP = 64 / CR;     // row bytes, 16-B chunks per row, rows per instruction
   unsigned char* tw = smem + wave * (WM * RB);
 #pragma unroll
@@ -869,22 +917,28 @@ static int launch_ws(const unsigned short* x, int ldx, const unsigned short* w, 
   return check_launch("ifx_gemm_bf16");
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int KG = 1>
 static int launch_small(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                         int N, int K, int mode, const EpiArgs2& ea, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
-  const dim3 grid(per_xcd * 8), block(256);
-  constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
+  const dim3 grid(per_xcd * 8), block(256 * KG);
+  constexpr size_t lds_ring = (size_t)KG * NST * (BM + BN) * 128, lds_sum = (size_t)BM * BN * 2 + (size_t)(KG - 1) * BM * BN * 4;
+  constexpr size_t lds = KG > 1 && lds_sum > lds_ring ? lds_sum : lds_ring;
+  static_assert(lds <= 160 * 1024, "LDS");
+  if (KG > 1 && (K / 64) % KG != 0) {
+    set_error("ifx_gemm_bf16: K/64 = %d is not a multiple of the %d K-groups of this tile", K / 64, KG);
+    return IFX_EINVAL;
+  }
 #define IFX_LAUNCH_GS(E)                                                                                             \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_small_kernel<BM, BN, NST, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)gemm_small_kernel<BM, BN, NST, E, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                           \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_small_kernel<BM, BN, NST, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
+    hipLaunchKernelGGL((gemm_small_kernel<BM, BN, NST, E, KG>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, \
                        per_xcd, ea);                                                                                 \
   } while (0)
   switch (mode) {
@@ -955,6 +1009,11 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   if (tile == 7) return launch_ws<256, 128, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // warp-specialised (producer / consumer waves)
   if (tile == 8) return launch_ws<128, 128, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);       // same, 64 KiB: two workgroups per CU
   if (tile == 6) return launch_big<128, 128, 2, IFX_T8_NST>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);   // eight waves, several per CU
+  // split-K inside the workgroup for launches of at most one workgroup per CU (a sequence-parallel rank's M = 4680 / P rows);
+  // deeper rings of the single-group tiles do NOT help there (64x64 x 8 stages: 12.0 vs 11.4 us on 585x1536x1536)
+  if (tile == 10) return launch_small<64, 64, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);    // 16 waves, four K-groups, 128 KiB
+  if (tile == 11) return launch_small<64, 64, 4, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);    // 8 waves, two K-groups, 128 KiB
+  if (tile == 12) return launch_small<128, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);  // 8 waves, two K-groups, 128 KiB
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 

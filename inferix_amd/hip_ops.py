@@ -65,8 +65,12 @@ class _timed:
             _timer.records.append((self.name, self.s, self.e, self.flops, self.nbytes))
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream        # the HIP stream torch would launch on, without building a Stream object
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_cur_device())
 
 
 def _dev(t: torch.Tensor, name: str, dtype=BF16) -> int:
@@ -181,7 +185,7 @@ def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[tor
 
 
 def set_option(key: str, value: int) -> None:
-    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..4, 'attn_variant' 0..2; 0 = choose by shape."""
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..14, 'attn_variant' 0..6 (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
 
 

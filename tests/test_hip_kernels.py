@@ -329,8 +329,12 @@ def test_gemm_ffn_real_shapes(ops):
     assert_bf16_parity(y, torch.nn.functional.linear(u_ref, w2, b2), what="ffn.2 8960->1536")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
-@pytest.mark.parametrize("M,N,K", [(585, 1536, 1536), (300, 640, 256), (77, 64, 64), (1170, 4608, 1536)])
+_GEMM_CASES = [(v, M, N, K) for v in range(1, 12) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 64), (1170, 4608, 1536)]]
+# 12-14 split K between the wave groups of a workgroup: K/64 has to divide by the groups (4, 2, 2)
+_GEMM_CASES += [(v, M, N, K) for v in (12, 13, 14) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 512), (585, 1536, 8960)]]
+
+
+@pytest.mark.parametrize("variant,M,N,K", _GEMM_CASES)
 def test_gemm_every_tile_variant(ops, variant, M, N, K):
     """Each GEMM kernel (register-staged 128x128, LDS-DMA 256x128 / 128x128 / 64x64) on shard shapes with ragged
     M and N edges, all four epilogues; the auto choice is covered by the other tests."""
@@ -354,6 +358,25 @@ def test_gemm_every_tile_variant(ops, variant, M, N, K):
         assert_bf16_parity(got, res + (y * gate).to(BF), max_ulp=2, floor=1.0, what=f"variant {variant} gate+residual")
     finally:
         ops.set_option("gemm_variant", 0)
+
+
+def test_gemm_split_k_tiles_refuse_indivisible_k(ops):
+    """A forced split-K tile on a K it cannot split evenly is an error, not a silently different kernel; the auto choice
+    (variant 0) only picks those tiles when K divides."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(3)
+    x, w, b = rnd(g, 77, 192), rnd(g, 64, 192), rnd(g, 64)
+    ops.set_option("gemm_variant", 12)
+    try:
+        with pytest.raises(_hip.HipKernelError, match="K-groups"):
+            ops.linear(gpu(x), gpu(w), gpu(b))
+    finally:
+        ops.set_option("gemm_variant", 0)
+    assert_bf16_parity(ops.linear(gpu(x), gpu(w), gpu(b)), torch.nn.functional.linear(x, w, b), what="auto tile, K = 192")
+    # small launches whose K splits: the auto choice takes the split-K tiles (head linear / text embedding / shard shapes)
+    for M, N, K in [(585, 1536, 1536), (585, 1536, 8960), (4680, 64, 1536), (512, 1536, 4096), (2340, 1536, 8960)]:
+        x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+        assert_bf16_parity(ops.linear(gpu(x), gpu(w), gpu(b)), torch.nn.functional.linear(x, w, b), what=f"auto {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
@@ -397,7 +420,7 @@ def test_kernels_are_run_to_run_deterministic(ops):
             assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
         ops.set_option("attn_variant", 0)
         assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=4)), "split-KV attention"
-        for gv in (1, 2, 3, 4, 5, 6):
+        for gv in (1, 2, 3, 4, 5, 6, 12, 13, 14):
             ops.set_option("gemm_variant", gv)
             assert stable(lambda: ops.linear(x, w, b, epilogue=_hip.IFX_EPI_GELU_TANH), reps=15), f"gemm variant {gv}"
     finally:
