@@ -388,10 +388,21 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
 int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsigned short* out, float* lse, int q_rows,
                       int heads, hipStream_t stream);
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
-int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt);
-// wave groups of the multi-wave kernel for a launch: 3 (384-row tiles) when variant 3 is forced or chosen, else 2
-// 0 (auto) and 5: software-pipelined schedule; 2: phase-locked ping-pong; 3: three groups; 4: free-running
-static int attn_groups(int variant) { return variant == 3 ? 3 : (variant == 4 ? 4 : (variant == 2 ? 2 : (variant == 6 ? 6 : 5))); }
+int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots);
+// schedule of the multi-wave kernel for a launch (the `groups` code of launch_attn_pp): 2 phase-locked ping-pong, 3 three groups
+// (384-row tiles), 4 free-running, 5 software-pipelined, 6 software-pipelined in four-wave workgroups (128-row tiles, two per CU).
+// Auto (variant 0): 5, except for launches whose rows fill 128-row tiles markedly better than 256-row tiles — one rank's 585 rows
+// of an eight-way sequence-parallel shard: 5 x 128 (91 %) against 3 x 256 (76 %); one rank's clip 348 -> 332 ms
+static int attn_groups(int variant, int q_rows) {
+  if (variant == 3 || variant == 4 || variant == 2 || variant == 6) return variant;
+  if (variant == 0 && q_rows > 0) {
+    const float u256 = (float)q_rows / (256.f * ((q_rows + 255) / 256)), u128 = (float)q_rows / (128.f * ((q_rows + 127) / 128));
+    if (u128 > 1.1f * u256) return 6;
+  }
+  return 5;
+}
+static int attn_qt(int groups) { return groups == 3 ? 384 : (groups == 6 ? 128 : 256); }
+static int attn_slots(int groups) { return groups == 6 ? 512 : 256; }
 
 }  // namespace ifx
 
@@ -413,11 +424,11 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
     IFX_REQUIRE(workspace && workspace_bytes >= (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits),
                 "ifx_attn_fwd_paged_split: workspace of %lld B too small for %d splits (need %lld B)",
                 (long long)workspace_bytes, splits, (long long)attn_pp_workspace_bytes(q_rows, heads, splits));
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant),
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant, q_rows),
                           (hipStream_t)stream);
   }
   if (variant >= 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant),
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant, q_rows),
                           (hipStream_t)stream);
   AttnArgs a;
   a.q = q;
@@ -460,7 +471,8 @@ extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv
                                        int64_t* workspace_bytes) {
   int splits = 1;
   if (q_rows > 0 && heads > 0 && kv_len > kv_start)
-    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_variant() == 3 ? 384 : (attn_variant() == 6 ? 128 : 256));
+    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_qt(attn_groups(attn_variant(), q_rows)),
+                                     attn_slots(attn_groups(attn_variant(), q_rows)));
   if (workspace_bytes) *workspace_bytes = (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits);
   return splits;
 }
@@ -489,7 +501,7 @@ extern "C" int ifx_attn_fwd_partial(const ifx_bf16* q, const ifx_kv_view* kv, in
               "ifx_attn_fwd_partial: workspace of %lld B too small for %d slots", (long long)workspace_bytes, slot_cap);
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_partial: page_size must be > 0");
   return launch_attn_pp(q, nullptr, nullptr, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace,
-                        attn_groups(attn_variant()), (hipStream_t)stream, slot_base, slot_cap, slots_used);
+                        attn_groups(attn_variant(), q_rows), (hipStream_t)stream, slot_base, slot_cap, slots_used);
 }
 
 extern "C" int ifx_attn_merge_partials(const void* workspace, int32_t slot_cap, int32_t slots_used, ifx_bf16* out,

@@ -952,16 +952,16 @@ size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits) {
 }
 
 // number of key chunks that fills the chip (one workgroup per CU, 256 CUs) for a query tile of `qt` rows
-int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt) {
+int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots) {
   using namespace pp;
   const int tiles = ((q_rows + qt - 1) / qt) * heads;
   const int nt = (nkeys + KT - 1) / KT;
-  if (tiles >= 208 || nt < 16) return 1;               // >= ~80 % of the CUs already busy / nothing to split
+  if (tiles * 16 >= slots * 13 || nt < 16) return 1;   // >= ~80 % of the workgroup slots already busy / nothing to split
   int best = 1;
-  float best_eff = (float)tiles / (256.f * ((tiles + 255) / 256));
+  float best_eff = (float)tiles / ((float)slots * ((tiles + slots - 1) / slots));
   for (int s = 2; s <= 32 && s * 8 <= nt; ++s) {        // chunks of >= 8 tiles (512 keys)
-    const int wg = tiles * s, rounds = (wg + 255) / 256;
-    const float eff = (float)wg / (256.f * rounds) * (1.f - 0.01f * s);   // small per-chunk prologue/merge penalty
+    const int wg = tiles * s, rounds = (wg + slots - 1) / slots;
+    const float eff = (float)wg / ((float)slots * rounds) * (1.f - 0.01f * s);   // small per-chunk prologue/merge penalty
     if (eff > best_eff + 1e-3f) best_eff = eff, best = s;
   }
   return best;

@@ -192,12 +192,13 @@ static int pick_tile(int M, int N, int K) {
                                {4, 128, 64, 512, 0.68f},  {2, 64, 64, 512, 0.50f}};
   // Few output tiles (one rank's M = 4680 / P rows of a sequence-parallel shard): the parallelism has to come from K.  Tiles 10-12
   // split K between wave groups of ONE workgroup (no workspace, fixed summation order).  Measured, tools/bench_gemm_tiles.py 585 / 2340:
-  //   585x1536x1536 12.3 -> 9.8 us (tile 10), 585x1536x8960 43.2 -> 33.8 (tile 11), 2340x1536x8960 88.9 -> 79.7 (tile 12)
+  //   585x1536x1536 12.3 -> 9.8 us (tile 10), 585x1536x8960 43.2 -> 33.8 (tile 11)
   const int kt = K / 64;
-  const int wgs64 = ((M + 63) / 64) * ((N + 63) / 64), wgs128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const int wgs64 = ((M + 63) / 64) * ((N + 63) / 64);
   if (wgs64 <= 256 && kt >= 64 && kt % 2 == 0) return 11;
   if (wgs64 <= 256 && kt >= 16 && kt % 4 == 0) return 10;
-  if (wgs128 > 128 && wgs128 <= 256 && kt >= 64 && kt % 2 == 0) return 12;
+  // (tile 12 on 128 < wgs128 <= 256 launches is worth 10 % on 2340x1536x8960, but the same rule would change the summation order
+  //  between one and two prompts of the text encoder — a prompt must not depend on its batch neighbours — so it stays opt-in)
   int best = 2;
   float best_score = -1.f;
   for (const Cand& c : cands) {
