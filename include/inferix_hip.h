@@ -45,7 +45,8 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   4 = 64x64, 5 = 256x256x64, 6 = 128x64, 7 = 256x128x32 (two per CU), 8 = 128x128x32 (eight waves),
  *                   9 / 10 = warp-specialised 256x128 / 128x128, 11 = 256x256x32 four stages,
  *                   12 / 13 / 14 = 64x64 (four K-groups), 64x64 (two), 128x128 (two): split-K between the wave groups of one
- *                   workgroup, what 0 = auto picks for launches of at most one workgroup per CU; K / 64 must divide by the groups
+ *                   workgroup, what 0 = auto picks for launches of at most one workgroup per CU; K / 64 must divide by the groups;
+ *                   15 = 128x64 two stages (three per CU), 16 / 17 = 64x128 two / three stages
  *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
  *                   4 free-running schedule, 5 software-pipelined schedule (what 0 = auto picks for large launches),
  *                   6 software-pipelined in four-wave workgroups, two per CU

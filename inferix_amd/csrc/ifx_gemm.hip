@@ -184,6 +184,7 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
 // workgroups fill whole rounds of the chip).  256 CUs; the 64-wide tiles run two workgroups per CU.
 //   tile 3 = 256x256x32, 0 = 256x128x64, 1 = 128x128, 4 = 128x64, 2 = 64x64   (bench: tools/bench_kernels.py gemm M)
 //   tile 10 = 64x64 with four K-groups, 11 = 64x64 with two K-groups, 12 = 128x128 with two K-groups (split-K inside the workgroup)
+//   tile 13 = 128x64 with two stages (three workgroups per CU), 14 / 15 = 64x128 with two / three stages
 static int pick_tile(int M, int N, int K) {
   struct Cand { int tile, bm, bn, slots; float base; };
   // 128x128 runs double-buffered with TWO workgroups per CU (64 KiB of LDS each): the co-resident workgroup hides the operand
@@ -197,6 +198,10 @@ static int pick_tile(int M, int N, int K) {
   const int wgs64 = ((M + 63) / 64) * ((N + 63) / 64);
   if (wgs64 <= 256 && kt >= 64 && kt % 2 == 0) return 11;
   if (wgs64 <= 256 && kt >= 16 && kt % 4 == 0) return 10;
+  // one round of 128x64 workgroups at THREE per CU (two stages, 48 KiB) instead of 1.4 rounds at two per CU:
+  //   585x8960x1536 31.8 -> 29.2 us, 585x4608x1536 19.2 -> 17.7, 1170x4608x1536 28.6 -> 27.2
+  const int wgs12864 = ((M + 127) / 128) * ((N + 63) / 64);
+  if (wgs12864 > 256 && wgs12864 <= 768) return 13;
   // (tile 12 on 128 < wgs128 <= 256 launches is worth 10 % on 2340x1536x8960, but the same rule would change the summation order
   //  between one and two prompts of the text encoder — a prompt must not depend on its batch neighbours — so it stays opt-in)
   int best = 2;
@@ -214,7 +219,7 @@ static int pick_tile(int M, int N, int K) {
 // kernel selection: 0 = auto (LDS-DMA kernels, tile by shape), 1 = force the register-staged 128x128 kernel,
 // 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32, 6 = force LDS-DMA 128x64,
 // 7 / 8 = the two-per-CU 256x128x32 and eight-wave 128x128x32 experiments (slower than 3, kept selectable),
-// 12 / 13 / 14 = the split-K-inside-the-workgroup tiles 10 / 11 / 12 (small launches)
+// 12 / 13 / 14 = the split-K-inside-the-workgroup tiles 10 / 11 / 12 (small launches), 15 = 128x64 three per CU, 16 / 17 = 64x128
 }  // namespace ifx
 
 using namespace ifx;

@@ -1014,6 +1014,9 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   if (tile == 10) return launch_small<64, 64, 2, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);    // 16 waves, four K-groups, 128 KiB
   if (tile == 11) return launch_small<64, 64, 4, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);    // 8 waves, two K-groups, 128 KiB
   if (tile == 12) return launch_small<128, 128, 2, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);  // 8 waves, two K-groups, 128 KiB
+  if (tile == 13) return launch_small<128, 64, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);      // 48 KiB: three per CU
+  if (tile == 14) return launch_small<64, 128, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);      // 48 KiB: three per CU
+  if (tile == 15) return launch_small<64, 128, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);      // 72 KiB: two per CU
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 

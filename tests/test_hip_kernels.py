@@ -331,6 +331,7 @@ def test_gemm_ffn_real_shapes(ops):
 
 _GEMM_CASES = [(v, M, N, K) for v in range(1, 12) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 64), (1170, 4608, 1536)]]
 # 12-14 split K between the wave groups of a workgroup: K/64 has to divide by the groups (4, 2, 2)
+_GEMM_CASES += [(v, M, N, K) for v in (15, 16, 17) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 64)]]
 _GEMM_CASES += [(v, M, N, K) for v in (12, 13, 14) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 512), (585, 1536, 8960)]]
 
 
