@@ -48,21 +48,39 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     _timer = t
 
 
-class _timed:
-    def __init__(self, name, flops=0.0, nbytes=0.0):
-        self.on = _timer is not None and _timer.wants(name)
+class _Timing:
+    def __init__(self, name, flops, nbytes):
         self.name, self.flops, self.nbytes = name, flops, nbytes
 
     def __enter__(self):
-        if self.on:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
-            self.s.record()
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.e = torch.cuda.Event(enable_timing=True)
+        self.s.record()
 
     def __exit__(self, *a):
-        if self.on:
-            self.e.record()
-            _timer.records.append((self.name, self.s, self.e, self.flops, self.nbytes))
+        self.e.record()
+        _timer.records.append((self.name, self.s, self.e, self.flops, self.nbytes))
+
+
+class _NotTimed:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOT_TIMED = _NotTimed()
+
+
+def _timed(name, flops=0.0, nbytes=0.0):
+    """Context around one launch: a shared no-op unless a KernelTimer asked for `name` (the wrappers sit on the host's critical
+    path when a sequence-parallel rank issues ~17 k launches of 5-50 us per clip)."""
+    if _timer is None or name not in _timer.names:
+        return _NOT_TIMED
+    return _Timing(name, flops, nbytes)
 
 
 _raw_stream = torch._C._cuda_getCurrentRawStream        # the HIP stream torch would launch on, without building a Stream object
@@ -102,12 +120,19 @@ class KvCacheView:
     page_size: int = 1
 
     def struct(self) -> _hip.KvView:
+        # checked and marshalled once per (k, v, page table): a layer's view is reused by every forward
+        key = (self.k.data_ptr(), self.v.data_ptr(), None if self.page_table is None else self.page_table.data_ptr(), self.page_size)
+        memo = self.__dict__.get("_memo")
+        if memo is not None and memo[0] == key:
+            return memo[1]
         assert self.k.shape == self.v.shape and self.k.dim() == 3 and self.k.is_contiguous() and self.v.is_contiguous()
         pt = 0
         if self.page_table is not None:
             pt = _dev(self.page_table, "page_table", torch.int32)
-        return _hip.KvView(_dev(self.k, "kv.k"), _dev(self.v, "kv.v"), pt, int(self.page_size),
-                           self.k.shape[0], self.k.shape[1], self.k.shape[2])
+        st = _hip.KvView(_dev(self.k, "kv.k"), _dev(self.v, "kv.v"), pt, int(self.page_size),
+                         self.k.shape[0], self.k.shape[1], self.k.shape[2])
+        self.__dict__["_memo"] = (key, st)
+        return st
 
     @staticmethod
     def from_manager_tensor(t: torch.Tensor, page_table=None, page_size=1) -> "KvCacheView":

@@ -70,6 +70,7 @@ class KVCaches:
     tensors: Dict[str, torch.Tensor]
     specs: Dict[str, KVCacheTensorSpec]
     page_tables: Dict[str, "PageTable"] = field(default_factory=dict)
+    views: Dict[str, object] = field(default_factory=dict)     # per layer: zero-copy K / V views built by the HIP model
 
 
 @dataclass
@@ -116,6 +117,7 @@ class KVCacheManager:
         del c.tensors[layer_name]
         del c.specs[layer_name]
         c.page_tables.pop(layer_name, None)
+        c.views.pop(layer_name, None)
 
     # ---- lookup -----------------------------------------------------------
     def layers(self, req: KVCacheRequest) -> Union[KeysView[str], Sequence[str]]:

@@ -214,14 +214,27 @@ class HipCausalWanModel(torch.nn.Module):
 
     def _kv_view(self, mgr: KVCacheManager, req: KVCacheRequest, name: str) -> ops.KvCacheView:
         t = mgr.get_raw(req, name)
+        pt = mgr.page_table(req, name) if hasattr(mgr, "page_table") else None
+        # the zero-copy K / V views of a layer are kept with the request's cache entry (they die with `free` / `free_layer`) and are
+        # rebuilt when the storage or its page table changed
+        caches = getattr(mgr, "request_to_kv_caches", {}).get(getattr(req, "request_id", None))
+        store = getattr(caches, "views", None)
+        key = (t.data_ptr(), None if pt is None else (pt.device.data_ptr(), pt.page_size))
+        if store is not None:
+            hit = store.get(name)
+            if hit is not None and hit[0] == key:
+                return hit[1]
         if not t.is_cuda:
             raise _hip.HipKernelError(
                 f"KV cache '{name}' lives on {t.device}: the HIP path reads pages in place from HBM "
                 "(create the model with enable_kv_offload=False)")
-        pt = mgr.page_table(req, name) if hasattr(mgr, "page_table") else None
         if pt is not None:
-            return ops.KvCacheView.from_manager_tensor(t, pt.device, pt.page_size)
-        return ops.KvCacheView.from_manager_tensor(t)
+            v = ops.KvCacheView.from_manager_tensor(t, pt.device, pt.page_size)
+        else:
+            v = ops.KvCacheView.from_manager_tensor(t)
+        if store is not None:
+            store[name] = (key, v)
+        return v
 
     def _evict(self, mgr, req, name: str, view: ops.KvCacheView, step: KVIndexStep) -> None:
         """Sink + rolling eviction (causal_model.py:287-292): page-table rotation when the spans are page
