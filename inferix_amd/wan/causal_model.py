@@ -382,8 +382,9 @@ class HipCausalWanModel(torch.nn.Module):
         xact = ops.linear(patches.contiguous(), self.g["patch_w"], self.g["patch_b"], out=self._buf("x", B * N, d))
         t = t.to(dev)
         emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]
-        e = F.linear(F.silu(F.linear(emb, self.g["time0_w"], self.g["time0_b"])), self.g["time2_w"], self.g["time2_b"])
-        e0 = F.linear(F.silu(e), self.g["tproj_w"], self.g["tproj_b"]).unflatten(1, (6, d))   # [B*Ft, 6, d]
+        # time_embedding / time_projection (a handful of rows): the same MFMA GEMM as the block linears, SiLU is elementwise glue
+        e = ops.linear(F.silu(ops.linear(emb.contiguous(), self.g["time0_w"], self.g["time0_b"])), self.g["time2_w"], self.g["time2_b"])
+        e0 = ops.linear(F.silu(e), self.g["tproj_w"], self.g["tproj_b"]).unflatten(1, (6, d))   # [B*Ft, 6, d]
         Ft = t.shape[1]                                                          # frames carrying a timestep (F or 1)
         rows_per_group = (F_ // Ft) * fs_l
         E = (self.mod_all + e0.unsqueeze(0)).contiguous()                        # [L, B*Ft, 6, d] bf16
