@@ -71,7 +71,7 @@ constexpr int HD = 128;
 #endif
 constexpr int PD = PP_PD;
 constexpr int RK = PD + 1, RV = PD + 2;
-constexpr int K_OFF = 0, V_OFF = RK * 16384;
+constexpr int K_OFF = 0;
 constexpr int LDS_BYTES = (RK + RV) * 16384;   // 114688
 constexpr int LDS_SWP = 8 * 16384;              // software-pipelined schedule (FR = 2): 3 K tiles + 5 V tiles
 constexpr int LDS_ALLOC = PP_TRACE ? LDS_SWP + 24576 : (LDS_BYTES > LDS_SWP ? LDS_BYTES : LDS_SWP);   // trace: 24 KiB of stamps behind the rings
@@ -377,7 +377,9 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   auto exp_block = [&](int b) {
     // exponent arguments two at a time (v_pk_fma_f32); row sums in two plain chains
     float a0 = 0.f, a1 = 0.f;
+#if !PP_PACKED
     const float mc = v_mcv[0];
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #if PP_PACKED

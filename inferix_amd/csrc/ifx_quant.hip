@@ -285,17 +285,21 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((address_space(3))) void* q8_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* q8_gbl_ptr_t;
 
-template <bool FP8, int BM, int BN, int WAVES_M, int EPI>
+// BKB = bytes of K per operand row of a stage: 64 (four stages) or 128 (two / three stages).  LDS-DMA moves rows of >= 128 B from L2 at
+// twice the rate of 64-byte rows (tools/probe_dma.hip), the same finding that moved the bf16 256x256 tile to 64-deep stages.
+template <bool FP8, int BM, int BN, int WAVES_M, int EPI, int BKB = 64, int NST = 4>
 __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* __restrict__ x, int ldx,
                                                           const unsigned char* __restrict__ w,
                                                           unsigned short* __restrict__ y, int ldy, int M, int N, int K,
                                                           int tiles_m, int total, int per_xcd, EpiArgsQ ea) {
-  constexpr int BKB = 64, NST = 4;
+  constexpr int CPR = BKB / 16, RPP = 64 / CPR;           // 16-byte chunks per row (4 | 8), rows per 1 KiB DMA piece (16 | 8)
+  constexpr int SW_SH = BKB == 64 ? 2 : 1;                 // swizzle phase: (row >> SW_SH) & (CPR - 1)
   constexpr int STAGE = (BM + BN) * BKB;
   constexpr int A_OFF = 0, B_OFF = BM * BKB;
   constexpr int WAVES_N = 8 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TJ = WM / 32, TI = WN / 32;
-  constexpr int PA = BM / 128, PB = BN / 128, P = PA + PB;
+  constexpr int PA = BM / (8 * RPP), PB = BN / (8 * RPP), P = PA + PB;
+  static_assert((NST - 2) * P <= 63 && NST >= 2 && NST <= 4, "stages");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,18 +316,18 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
   const int m_base = tile_m * BM, n_base = tile_n * BN;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
-  const int r16 = lane >> 2, pc = lane & 3;
+  const int r16 = lane / CPR, pc = lane % CPR;
   const unsigned char* src_a[PA];
   const unsigned char* src_b[PB];
 #pragma unroll
   for (int r = 0; r < PA; ++r) {
-    const int row = (r * 8 + wave) * 16 + r16;
-    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> 2) & 3)) * 16;
+    const int row = (r * 8 + wave) * RPP + r16;
+    src_a[r] = x + (size_t)min(m_base + row, M - 1) * ldx + (pc ^ ((row >> SW_SH) & (CPR - 1))) * 16;
   }
 #pragma unroll
   for (int r = 0; r < PB; ++r) {
-    const int row = (r * 8 + wave) * 16 + r16;
-    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> 2) & 3)) * 16;
+    const int row = (r * 8 + wave) * RPP + r16;
+    src_b[r] = w + (size_t)min(n_base + row, N - 1) * K + (pc ^ ((row >> SW_SH) & (CPR - 1))) * 16;
   }
   auto issue = [&](int kt) {
     unsigned char* st = smem + (kt % NST) * STAGE;
@@ -358,14 +362,14 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int row = wm * WM + j * 32 + l31;
-    a_off[j] = A_OFF + row * 64;
-    a_swz[j] = (row >> 2) & 3;
+    a_off[j] = A_OFF + row * BKB;
+    a_swz[j] = (row >> SW_SH) & (CPR - 1);
   }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int row = wn * WN + i * 32 + l31;
-    b_off[i] = B_OFF + row * 64;
-    b_swz[i] = (row >> 2) & 3;
+    b_off[i] = B_OFF + row * BKB;
+    b_swz[i] = (row >> SW_SH) & (CPR - 1);
   }
 
   for (int kt = 0; kt < KT; ++kt) {
@@ -377,10 +381,12 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
     __builtin_amdgcn_s_barrier();
     if (kt + NST - 1 < KT) issue(kt + NST - 1);
     const unsigned char* st = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int kh = 0; kh < BKB / 64; ++kh) {                // 64 bytes of K per MFMA step
     i32x4 fa[2][TJ], fb[2][TI];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int c = 2 * ks + hi;
+      const int c = 4 * kh + 2 * ks + hi;
 #pragma unroll
       for (int i = 0; i < TI; ++i) fb[ks][i] = *reinterpret_cast<const i32x4*>(st + b_off[i] + ((c ^ b_swz[i]) << 4));
 #pragma unroll
@@ -409,6 +415,7 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
             iacc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][i], fa[ks][j], iacc[i][j], 0, 0, 0);
         }
       }
+    }
   }
 
   // ---- epilogue: v = bf16(acc * sa[m] * sw[n] + bias[n]) transposed through LDS per wave, then 16-byte row accesses
@@ -481,23 +488,24 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
   }
 }
 
-template <bool FP8, int BM, int BN, int WAVES_M>
+template <bool FP8, int BM, int BN, int WAVES_M, int BKB = 64, int NST = 4>
 static int launch_q8_dma(const unsigned char* x, int ldx, const unsigned char* w, unsigned short* y, int ldy, int M, int N,
                          int K, int mode, const EpiArgsQ& ea, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(512);
-  constexpr size_t ring = (size_t)4 * (BM + BN) * 64, epi = (size_t)BM * BN * 2;
+  constexpr size_t ring = (size_t)NST * (BM + BN) * BKB, epi = (size_t)BM * BN * 2;
+  static_assert(ring <= 160 * 1024, "LDS");
   constexpr size_t lds = ring > epi ? ring : epi;
 #define IFX_LAUNCH_Q8D(E)                                                                                            \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_q8_dma_kernel<FP8, BM, BN, WAVES_M, E>,                            \
+      (void)hipFuncSetAttribute((const void*)gemm_q8_dma_kernel<FP8, BM, BN, WAVES_M, E, BKB, NST>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_q8_dma_kernel<FP8, BM, BN, WAVES_M, E>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, \
+    hipLaunchKernelGGL((gemm_q8_dma_kernel<FP8, BM, BN, WAVES_M, E, BKB, NST>), grid, block, lds, s, x, ldx, w, y, ldy, M, N, K, \
                        tiles_m, total, per_xcd, ea);                                                                 \
   } while (0)
   switch (mode) {
@@ -574,6 +582,15 @@ extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, co
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     const int t = wgs(256, 256) >= 512 ? 2 : (wgs(256, 128) >= 224 ? 1 : 0);
+    // 128-byte operand rows (two / three stages) unless gemm_variant 2 asks for the 64-byte four-stage ring they replaced
+    const bool rows128 = gemm_variant() != 2;
+    // (a 128x128 eight-wave tile at two workgroups per CU for the 1536- and 4608-wide outputs measured the same as 256x128)
+    if (t == 2 && rows128)
+      return format == IFX_Q_FP8_E4M3 ? launch_q8_dma<true, 256, 256, 2, 128, 2>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s)
+                                      : launch_q8_dma<false, 256, 256, 2, 128, 2>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s);
+    if (t == 1 && rows128)
+      return format == IFX_Q_FP8_E4M3 ? launch_q8_dma<true, 256, 128, 4, 128, 3>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s)
+                                      : launch_q8_dma<false, 256, 128, 4, 128, 3>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s);
     if (t == 2)
       return format == IFX_Q_FP8_E4M3 ? launch_q8_dma<true, 256, 256, 2>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s)
                                       : launch_q8_dma<false, 256, 256, 2>(xp, ldx, wp, y, ldy, M, N, K, mode, ea, s);
