@@ -231,6 +231,13 @@ int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int32_t ldq, fl
 int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
                 const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t format,
                 const ifx_epilogue* epi, void* stream);
+/* ifx_layernorm_quant: ifx_layernorm followed by ifx_quant_per_token of its bf16 result, in one pass over the row — what the
+ * quantised qkv / cross-attention q / ffn.0 linears of a block see (the reference's DAX wrapper quantises the input of every
+ * nn.Linear, i.e. the norm's bf16 output: run_self_forcing_quantized.py:47-64, causal_model.py:419-428,470-476).  Same bytes and
+ * scales as the two calls, bit for bit; the bf16 row is not written.  Arguments as ifx_layernorm + (q, ldq, scale, format). */
+int ifx_layernorm_quant(const ifx_bf16* x, void* q, int32_t ldq, float* scale, int32_t rows, int32_t dim, float eps,
+                        int32_t mode, const ifx_bf16* gamma, const ifx_bf16* beta, const ifx_bf16* mod, int32_t mod_slots,
+                        int32_t shift_slot, int32_t scale_slot, int32_t rows_per_group, int32_t format, void* stream);
 
 /* ------------------------------------------------------------------------
  * KV cache maintenance.  ifx_kv_roll: the reference's eviction shift

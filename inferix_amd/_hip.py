@@ -87,6 +87,7 @@ SIGNATURES = {
     "ifx_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
     "ifx_kv_roll": (C.c_int, [C.POINTER(KvView), _i32, _i32, _i32, _vp, _vp]),
     "ifx_quant_per_token": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "ifx_layernorm_quant": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ifx_gemm_q8": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
 }
 

@@ -53,12 +53,15 @@ struct Row {
 };
 
 // ---------------------------------------------------------------------------
-template <int NCH>
+// QUANT: 0 = bf16 row out; 1 / 2 = the per-token e4m3 / int8 quantiser of the 8-bit linears (ifx_quant_per_token) applied to the
+// bf16-rounded row while it is still in registers: amax -> scale -> bytes, op for op the standalone quantiser, so the 8-bit GEMM
+// sees the same bytes and scales and the bf16 row never goes to HBM (7.7 us per 4680 x 1536 launch, three per layer).
+template <int NCH, int QUANT = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int rows, int dim, float eps,
     int mode, const unsigned short* __restrict__ gamma, const unsigned short* __restrict__ beta,
     const unsigned short* __restrict__ mod, int mod_slots, int shift_slot, int scale_slot,
-    int rows_per_group) {
+    int rows_per_group, unsigned char* __restrict__ q = nullptr, int ldq = 0, float* __restrict__ qscale = nullptr) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -106,6 +109,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   const float var = wave_sum(ss) * inv_n;
   const float rstd = 1.0f / sqrtf(var + eps);
 
+  u16x8 qrow[QUANT != 0 ? NCH : 1];
+  if (QUANT != 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) qrow[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
@@ -129,7 +137,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = f2bf((row.v[c][i] - mean) * rstd);
     }
-    *reinterpret_cast<u16x8*>(y + (size_t)r * dim + col) = o;
+    if (QUANT == 0) *reinterpret_cast<u16x8*>(y + (size_t)r * dim + col) = o;
+    else qrow[c] = o;
+  }
+  if (QUANT != 0) {
+    constexpr float QMAX = QUANT == 1 ? 448.0f : 127.0f;
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(bf2f(qrow[c][i])));
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / QMAX : 1.0f;
+    if (lane == 0) qscale[r] = sc;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col >= dim) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(bf2f(qrow[c][i]) / sc, -QMAX), QMAX);
+      u32x2 pk;
+      if (QUANT == 1) {
+        unsigned w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+        pk = u32x2{w0, w1};
+      } else {
+        unsigned w[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i >> 2] |= ((unsigned)(int)rintf(v[i]) & 0xffu) << (8 * (i & 3));
+        pk = u32x2{w[0], w[1]};
+      }
+      *reinterpret_cast<u32x2*>(q + (size_t)r * ldq + col) = pk;
+    }
   }
 }
 
@@ -363,10 +406,38 @@ extern "C" int ifx_layernorm(const ifx_bf16* x, ifx_bf16* y, int32_t rows, int32
                 "ifx_layernorm: modulate mode needs mod/slots/rows_per_group");
   if (rows == 0) return IFX_OK;
   return dispatch_nch(dim, [&](auto nch) {
-    hipLaunchKernelGGL((layernorm_kernel<decltype(nch)::value>), dim3((rows + 3) / 4), dim3(256), 0,
+    hipLaunchKernelGGL((layernorm_kernel<decltype(nch)::value, 0>), dim3((rows + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, x, y, rows, dim, eps, mode, gamma, beta, mod, mod_slots, shift_slot,
-                       scale_slot, rows_per_group > 0 ? rows_per_group : 1);
+                       scale_slot, rows_per_group > 0 ? rows_per_group : 1, (unsigned char*)nullptr, 0, (float*)nullptr);
     return check_launch("ifx_layernorm");
+  });
+}
+
+extern "C" int ifx_layernorm_quant(const ifx_bf16* x, void* q, int32_t ldq, float* scale, int32_t rows, int32_t dim, float eps,
+                                   int32_t mode, const ifx_bf16* gamma, const ifx_bf16* beta, const ifx_bf16* mod,
+                                   int32_t mod_slots, int32_t shift_slot, int32_t scale_slot, int32_t rows_per_group,
+                                   int32_t format, void* stream) {
+  IFX_REQUIRE(x && q && scale && rows >= 0 && dim > 0 && dim % 8 == 0 && ldq >= dim && ldq % 8 == 0,
+              "ifx_layernorm_quant: bad x/q/scale/rows/dim(%d)/ldq(%d)", dim, ldq);
+  IFX_REQUIRE(mode >= IFX_LN_PLAIN && mode <= IFX_LN_MODULATE, "ifx_layernorm_quant: bad mode %d", mode);
+  IFX_REQUIRE(format == IFX_Q_FP8_E4M3 || format == IFX_Q_INT8, "ifx_layernorm_quant: unknown format %d", format);
+  if (mode == IFX_LN_AFFINE) IFX_REQUIRE(gamma && beta, "ifx_layernorm_quant: affine mode needs gamma/beta");
+  if (mode == IFX_LN_MODULATE)
+    IFX_REQUIRE(mod && rows_per_group > 0 && mod_slots > 0 && shift_slot >= 0 && shift_slot < mod_slots &&
+                    scale_slot >= 0 && scale_slot < mod_slots,
+                "ifx_layernorm_quant: modulate mode needs mod/slots/rows_per_group");
+  if (rows == 0) return IFX_OK;
+  return dispatch_nch(dim, [&](auto nch) {
+    constexpr int NC = decltype(nch)::value;
+    const dim3 grid((rows + 3) / 4), block(256);
+    const int rpg = rows_per_group > 0 ? rows_per_group : 1;
+    if (format == IFX_Q_FP8_E4M3)
+      hipLaunchKernelGGL((layernorm_kernel<NC, 1>), grid, block, 0, (hipStream_t)stream, x, (unsigned short*)nullptr, rows, dim, eps,
+                         mode, gamma, beta, mod, mod_slots, shift_slot, scale_slot, rpg, (unsigned char*)q, ldq, scale);
+    else
+      hipLaunchKernelGGL((layernorm_kernel<NC, 2>), grid, block, 0, (hipStream_t)stream, x, (unsigned short*)nullptr, rows, dim, eps,
+                         mode, gamma, beta, mod, mod_slots, shift_slot, scale_slot, rpg, (unsigned char*)q, ldq, scale);
+    return check_launch("ifx_layernorm_quant");
   });
 }
 

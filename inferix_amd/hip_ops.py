@@ -181,6 +181,33 @@ def layernorm(x: torch.Tensor, eps: float, *, gamma=None, beta=None, mod=None, s
     return out
 
 
+def layernorm_quant(x: torch.Tensor, eps: float, fmt: int, *, gamma=None, beta=None, mod=None, shift_slot=0, scale_slot=1,
+                    rows_per_group: Optional[int] = None, q: Optional[torch.Tensor] = None,
+                    scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`quant_per_token(layernorm(x, ...), fmt)` in one pass (ifx_layernorm_quant): bytes `[rows, dim]` uint8 + scale `[rows]` fp32,
+    bit-identical to the two calls."""
+    lib = _hip.load()
+    rows, dim, ld = _rows2d(x, "x")
+    assert ld == dim, "x rows must be dense"
+    q = torch.empty(rows, dim, dtype=torch.uint8, device=x.device) if q is None else q
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
+    if mod is not None:
+        mode = _hip.IFX_LN_MODULATE
+        assert mod.dim() == 3 and mod.shape[-1] == dim and mod.is_contiguous() and rows_per_group
+        assert rows <= mod.shape[0] * rows_per_group
+        args = (None, None, _dev(mod, "mod"), mod.shape[1], shift_slot, scale_slot, rows_per_group)
+    elif gamma is not None:
+        mode = _hip.IFX_LN_AFFINE
+        args = (_dev(gamma, "gamma"), _dev(beta, "beta"), None, 0, 0, 0, 1)
+    else:
+        mode = _hip.IFX_LN_PLAIN
+        args = (None, None, None, 0, 0, 0, 1)
+    with _timed("layernorm", 0.0, 3.0 * rows * dim):
+        _hip.check(lib.ifx_layernorm_quant(_dev(x, "x"), _dev(q, "q", torch.uint8), q.stride(0), _dev(scale, "scale", torch.float32),
+                                           rows, dim, eps, mode, *args, int(fmt), _stream()), "ifx_layernorm_quant")
+    return q, scale
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _hip.load()
     rows, dim, ldx = _rows2d(x, "x")

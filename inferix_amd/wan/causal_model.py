@@ -250,21 +250,34 @@ class HipCausalWanModel(torch.nn.Module):
             self._roll_scratch = torch.empty(need, dtype=BF16, device=self.device_)
         ops.kv_roll(view, step.sink_tokens, step.evicted, step.rolled, self._roll_scratch)
 
+    def _q8_scratch(self, rows: int, cols: int, device):
+        xq = self._scratch.get(("xq", rows, cols))
+        if xq is None:
+            xq = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+            self._scratch[("xq", rows, cols)] = xq
+            self._scratch[("xs", rows)] = torch.empty(rows, dtype=torch.float32, device=device)
+        return xq, self._scratch[("xs", rows)]
+
     def _lin(self, w: Dict[str, torch.Tensor], key: str, x: torch.Tensor, **kw) -> torch.Tensor:
         """Linear `key` of a block: bf16 MFMA GEMM, or (after inferix_amd.quant.quantize_dynamic) per-token
         activation quantisation + fp8 / int8 MFMA GEMM with the same epilogue."""
         if key + "_q" in w:
             fmt = w[key + "_fmt"]
-            rows = x.shape[0]
-            xq = self._scratch.get(("xq", rows, x.shape[1]))
-            if xq is None:
-                xq = torch.empty(rows, x.shape[1], dtype=torch.uint8, device=x.device)
-                self._scratch[("xq", rows, x.shape[1])] = xq
-                self._scratch[("xs", rows)] = torch.empty(rows, dtype=torch.float32, device=x.device)
-            xs = self._scratch[("xs", rows)]
+            xq, xs = self._q8_scratch(x.shape[0], x.shape[1], x.device)
             ops.quant_per_token(x, fmt, q=xq, scale=xs)
             return ops.linear_q8(xq, xs, w[key + "_q"], w[key + "_s"], w[key + "_b"], fmt, **kw)
         return ops.linear(x, w[key + "_w"], w[key + "_b"], **kw)
+
+    def _norm_lin(self, w: Dict[str, torch.Tensor], key: str, x: torch.Tensor, h: torch.Tensor, norm_kw: dict, **kw) -> torch.Tensor:
+        """`linear_key(layernorm(x, ...))`.  A quantised linear takes its bytes and scales straight from the norm kernel
+        (ifx_layernorm_quant: same bytes as quantising the norm's bf16 output, which then never goes to HBM)."""
+        if key + "_q" in w:
+            fmt = w[key + "_fmt"]
+            xq, xs = self._q8_scratch(x.shape[0], x.shape[1], x.device)
+            ops.layernorm_quant(x, self.eps, fmt, q=xq, scale=xs, **norm_kw)
+            return ops.linear_q8(xq, xs, w[key + "_q"], w[key + "_s"], w[key + "_b"], fmt, **kw)
+        ops.layernorm(x, self.eps, out=h, **norm_kw)
+        return ops.linear(h, w[key + "_w"], w[key + "_b"], **kw)
 
     def _run_block(self, l: int, xact: torch.Tensor, El: torch.Tensor, st: dict, meta: dict, cmeta: dict,
                    kv_cache_manager, kv_cache_requests) -> None:
@@ -281,8 +294,7 @@ class HipCausalWanModel(torch.nn.Module):
         ab = self._buf("a", B * N, d)
         ub = self._buf("u", B * N, self.ffn_dim)
         # ---------------- self attention ----------------
-        ops.layernorm(xact, self.eps, mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
-        self._lin(w, "qkv", h, out=qkv)
+        self._norm_lin(w, "qkv", xact, h, dict(mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group), out=qkv)
         explicit = st.get("explicit_slots")          # CausVid: (kv_start, kv_end) given by the caller
         if explicit is None:
             g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
@@ -318,8 +330,7 @@ class HipCausalWanModel(torch.nn.Module):
         self._lin(w, "o", ab, epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
                   rows_per_group=rows_per_group, out=xact)
         # ---------------- cross attention ----------------
-        ops.layernorm(xact, self.eps, gamma=w["n3_w"], beta=w["n3_b"], out=h)
-        self._lin(w, "cq", h, out=qb)
+        self._norm_lin(w, "cq", xact, h, dict(gamma=w["n3_w"], beta=w["n3_b"]), out=qb)
         ops.rmsnorm(qb, w["cnq"], self.eps, out=qb)
         for b, req in enumerate(kv_cache_requests):
             cview = self._kv_view(kv_cache_manager, req, blk.kv_cache_manager.cross_name)
@@ -333,8 +344,8 @@ class HipCausalWanModel(torch.nn.Module):
         cmeta["is_init"] = True
         self._lin(w, "co", ab, epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
         # ---------------- feed forward ----------------
-        ops.layernorm(xact, self.eps, mod=El, shift_slot=3, scale_slot=4, rows_per_group=rows_per_group, out=h)
-        self._lin(w, "f0", h, epilogue=_hip.IFX_EPI_GELU_TANH, out=ub)
+        self._norm_lin(w, "f0", xact, h, dict(mod=El, shift_slot=3, scale_slot=4, rows_per_group=rows_per_group),
+                       epilogue=_hip.IFX_EPI_GELU_TANH, out=ub)
         self._lin(w, "f2", ub, epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=5,
                   rows_per_group=rows_per_group, out=xact)
 

@@ -32,6 +32,29 @@ def test_quant_per_token_bit_exact(fmt, rows, K):
     assert torch.equal(q.cpu(), Q.quantized_bytes(x, fmt)), "quantised bytes must be bit-exact"
 
 
+@pytest.mark.parametrize("fmt", [Q.FP8, Q.INT8])
+@pytest.mark.parametrize("rows,dim", [(4680, 1536), (585, 1536), (77, 256), (5, 3072)])
+def test_layernorm_quant_is_the_two_calls(fmt, rows, dim):
+    """ifx_layernorm_quant (the fused producer of the quantised qkv / cross-q / ffn.0 inputs) against ifx_layernorm followed by
+    ifx_quant_per_token — which the tests above pin to the oracle — in all three norm modes: bytes and scales bit for bit."""
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(rows + dim + fmt)
+    x = rnd(g, rows, dim, scale=2.0).cuda()
+    x[1 % rows] = 0                                  # constant row: normalises to the shift / beta alone
+    x[2 % rows, 3] = 200.0
+    frames = 3
+    rpg = (rows + frames - 1) // frames
+    mod = rnd(g, frames, 6, dim, scale=0.5).cuda()
+    gamma, beta = rnd(g, dim).cuda(), rnd(g, dim, scale=0.1).cuda()
+    for kw in (dict(mod=mod, shift_slot=3, scale_slot=4, rows_per_group=rpg), dict(gamma=gamma, beta=beta), dict()):
+        q_ref, s_ref = ops.quant_per_token(ops.layernorm(x, 1e-6, **kw), fmt)
+        q, s = ops.layernorm_quant(x, 1e-6, fmt, **kw)
+        assert torch.equal(s, s_ref), f"scales differ ({sorted(kw)})"
+        assert torch.equal(q, q_ref), f"bytes differ ({sorted(kw)})"
+    with pytest.raises(Exception):
+        ops.layernorm_quant(x, 1e-6, 7)              # unknown format
+
+
 def test_quantize_weight_matches_oracle():
     from inferix_amd import _hip
     from inferix_amd.quant import QConfig, quantize_weight
