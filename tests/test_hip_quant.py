@@ -19,13 +19,18 @@ def rnd(g, *shape, scale=1.0):
 
 
 @pytest.mark.parametrize("fmt", [Q.FP8, Q.INT8])
-@pytest.mark.parametrize("rows,K", [(72, 256), (4680, 1536), (513, 8960), (5, 128)])
+@pytest.mark.parametrize("rows,K", [(72, 256), (4680, 1536), (513, 8960), (5, 128), (4680, 8960)])
 def test_quant_per_token_bit_exact(fmt, rows, K):
     from inferix_amd import hip_ops as ops
     g = torch.Generator().manual_seed(rows + K + fmt)
     x = rnd(g, rows, K, scale=3.0)
     x[1 % rows] = 0                                  # all-zero row -> scale 1, zeros
     x[2 % rows, 3] = 300.0                           # outlier row
+    if rows > 8:
+        x[3] = x[3] * 1e-30                          # tiny scale: the kernel's hoisted-reciprocal division must fall back
+        x[4] = x[4] * 1e30                           # huge scale
+        x[5, : K // 2] = (torch.arange(K // 2) % 255 - 127).to(BF)   # integers: exact quotients and .5 ties after the scale
+        x[5, 0] = 254.0
     q, s = ops.quant_per_token(x.cuda(), fmt)
     _, s_ref = Q.quantize_rows(x, fmt)
     assert torch.equal(s.cpu(), s_ref), "per-token scales must be bit-exact (fp32 abs-max / QMAX)"
