@@ -1,0 +1,32 @@
+"""The driver's contract with bench.py: ONE JSON line on stdout with the agreed keys (a short two-layer debug run; the
+numbers of such a run are marked INVALID by bench.py itself and are not looked at here)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--layers", "2",
+                        "--no-decode-leg"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 1 and r["warmup"] == 0 and r["higher_is_better"] is True
+    assert r["metric"] == "latent_frames_per_sec" and r["unit"] == "frames/s" and r["value"] > 0 and r["vs_baseline"] is None
+    assert r["dtype"] == "bf16" and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert r["config"]["INVALID"]                                  # two layers: bench.py says so itself
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and rf["launches"] > 0
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["unit"]
