@@ -22,6 +22,9 @@
 
 #include "ifx_common.h"
 
+#ifndef IFX_GEMM_GM
+#define IFX_GEMM_GM 4       // row tiles per rasterisation group (tile ids sweep GM rows x all column tiles before the next GM rows)
+#endif
 #ifndef IFX_T8_NST
 #define IFX_T8_NST 2
 #endif
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short*
   // grouped raster: consecutive ids walk GM token-tiles, then the next channel-tile -> the ~32 workgroups
   // resident on one XCD form a GM x (32/GM) block of tiles sharing GM x-panels and 32/GM W-panels in its L2
   // (v1's id = m-fastest order made every XCD touch every panel: 0.9-1.2 GB of memory-side fetches per GEMM).
-  constexpr int GM = 4;
+  constexpr int GM = IFX_GEMM_GM;
   const int tiles_n = total / tiles_m;
   const int grp_sz = GM * tiles_n;
   const int first_m = (t_id / grp_sz) * GM;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_small_kernel(const unsigned sho
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
   const int t_id = xcd * per_xcd + slot_i;
   if (slot_i >= per_xcd || t_id >= total) return;
-  constexpr int GM = 4;
+  constexpr int GM = IFX_GEMM_GM;
   const int tiles_n = total / tiles_m;
   const int grp_sz = GM * tiles_n;
   const int first_m = (t_id / grp_sz) * GM;
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const unsigned short* __re
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
   const int t_id = xcd * per_xcd + slot_i;
   if (slot_i >= per_xcd || t_id >= total) return;
-  constexpr int GM = 4;
+  constexpr int GM = IFX_GEMM_GM;
   const int tiles_n = total / tiles_m;
   const int grp_sz = GM * tiles_n;
   const int first_m = (t_id / grp_sz) * GM;
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
   const int t_id = xcd * per_xcd + slot_i;
   if (slot_i >= per_xcd || t_id >= total) return;
-  constexpr int GM = 4;
+  constexpr int GM = IFX_GEMM_GM;
   const int tiles_n = total / tiles_m;
   const int grp_sz = GM * tiles_n;
   const int first_m = (t_id / grp_sz) * GM;
