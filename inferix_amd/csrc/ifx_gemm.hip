@@ -202,8 +202,14 @@ static int pick_tile(int M, int N, int K) {
   //   585x8960x1536 31.8 -> 29.2 us, 585x4608x1536 19.2 -> 17.7, 1170x4608x1536 28.6 -> 27.2
   const int wgs12864 = ((M + 127) / 128) * ((N + 63) / 64);
   if (wgs12864 > 256 && wgs12864 <= 768) return 13;
-  // (tile 12 on 128 < wgs128 <= 256 launches is worth 10 % on 2340x1536x8960, but the same rule would change the summation order
-  //  between one and two prompts of the text encoder — a prompt must not depend on its batch neighbours — so it stays opt-in)
+  // (tile 12 on 128 < wgs128 <= 256 launches is worth 10 % on 2340x1536x8960; it stays opt-in because it would flip the umT5
+  //  encoder's M = 512 x batch launches between summation orders.)
+  // NOTE on batch invariance: the split-K tiles above add the K-halves / K-quarters in a fixed order, which is NOT the order of the
+  // single-pass tiles, and the choice depends on M.  A launch's bits are therefore a function of (M, N, K) — deterministic run to run,
+  // but a row's low bits may differ between two launch sizes that land on either side of the wgs64 <= 256 rule (e.g. the Wan
+  // text_embedding linear, N = 1536, K = 4096: split at one 512-token prompt, single-pass at two).  The umT5 encoder's shapes
+  // (N >= 4096) never take a split tile, which is what tests/test_hip_t5.py's batch-invariance test relies on; callers that need
+  // invariance elsewhere pin the tile with ifx_set_option("gemm_variant", ...).
   int best = 2;
   float best_score = -1.f;
   for (const Cand& c : cands) {

@@ -106,7 +106,16 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int, int]:
     if t.dim() == 1:
         return 1, t.shape[0], t.shape[0]
     if t.dim() > 2:
-        t = t.flatten(0, -2) if t.is_contiguous() else t.reshape(-1, t.shape[-1])
+        if t.is_contiguous():
+            t = t.flatten(0, -2)
+        else:
+            # the caller passes the ORIGINAL tensor's data pointer: a reshape that had to copy would pair that pointer with the
+            # copy's pitch, so only true views (uniformly strided rows) are accepted
+            try:
+                t = t.view(-1, t.shape[-1])
+            except RuntimeError as e:
+                raise ValueError(f"{name}: tensor of shape {tuple(t.shape)} / strides {t.stride()} is not a matrix of "
+                                 "uniformly strided rows; make it contiguous first") from e
     return t.shape[0], t.shape[1], t.stride(0)
 
 
@@ -365,6 +374,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
         epi.residual, epi.ld_res = _dev(residual, "residual"), ldr
     if mod is not None:
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
+        assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
     with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         _hip.check(lib.ifx_gemm_bf16(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
@@ -403,6 +413,7 @@ def linear_q8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale
         epi.residual, epi.ld_res = _dev(residual, "residual"), ldr
     if mod is not None:
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
+        assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
     with _timed("gemm_q8", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * N):
         _hip.check(lib.ifx_gemm_q8(_dev(xq, "xq", torch.uint8), xq.stride(0), _dev(x_scale, "x_scale", torch.float32),

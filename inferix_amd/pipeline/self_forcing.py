@@ -38,9 +38,12 @@ def _load_config(path_or_dict, default=None) -> SimpleNamespace:
         import yaml
         with open(p) as f:
             return yaml.safe_load(f) or {}
-    cfg = read(default)
-    cfg.update(read(path_or_dict))           # the specific config wins, as OmegaConf.merge(default, config)
-    return SimpleNamespace(**cfg)
+    def merge(a, b):                         # OmegaConf.merge(default, config): nested mappings merge key by key
+        out = dict(a)
+        for k, v in b.items():
+            out[k] = merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+        return out
+    return SimpleNamespace(**merge(read(default), read(path_or_dict)))
 
 
 class SelfForcingPipeline:

@@ -44,6 +44,8 @@ class SequenceParallelExchange:
         if page_table is None and key in self._slot_cache:
             return self._slot_cache[key]
         P = self.world
+        if fs % P != 0:
+            raise ValueError(f"a frame's {fs} tokens do not divide over {P} sequence-parallel ranks")
         hw_local = fs // P
         r = torch.arange(P).view(P, 1, 1)
         f = torch.arange(frames).view(1, frames, 1)

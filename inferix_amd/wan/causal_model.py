@@ -381,6 +381,8 @@ class HipCausalWanModel(torch.nn.Module):
         F_, fs = grid[0], grid[1] * grid[2]
         cp_ws = self.parallel_config.world_size
         cp_rank = self.parallel_config.rank
+        if fs % cp_ws != 0:
+            raise ValueError(f"sequence parallelism splits every frame's {fs} tokens over {cp_ws} ranks: not divisible")
         hw_local = fs // cp_ws
         fs_l = hw_local                               # tokens per frame on this rank
         N = F_ * fs_l                                 # tokens per sample on this rank

@@ -136,7 +136,18 @@ def kv_manager_fixture():
         k, v = mgr.adjust_key_and_value_for_inference(kv, ip, meta)
         out.update({f"kv{i}_in": kv, f"kv{i}_k": k, f"kv{i}_v": v,
                     f"kv{i}_args": torch.tensor([c["n"], c["slice_point"], int(c["update"]), int(c["fwd_extra"]), int(c["distill"])])})
-    out["kv_cache_final"] = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0")
+    # the reference allocates the cache with torch.empty (kvcache_manager.py:232-243): slots no call stored to hold whatever the
+    # allocator returned.  Only the stored extent is part of the contract, so the never-written tail is zeroed in the fixture
+    # (otherwise a regeneration differs from the committed file and from the oracle's zero-initialised cache).
+    final = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0").clone()
+    written = 0
+    for c in calls:
+        if c["update"]:
+            stored = c["n"] - clip if c["distill"] else c["n"]
+            written = max(written, c["slice_point"] * clip + stored)
+    final[:, written:] = 0
+    out["kv_cache_final"] = final
+    out["kv_cache_written"] = torch.tensor(written)
     out["kv_calls"] = torch.tensor(len(calls))
     return out
 
