@@ -109,6 +109,15 @@ int ifx_attn_fwd_paged_split(const ifx_bf16* q, ifx_bf16* out, float* lse, const
                              int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
                              int32_t num_splits, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ifx_attn_fwd_paged with explicit row strides of q and out (elements, >= heads * 128): the query rows may be a column block of
+ * a wider matrix and the result may be written straight into a column block of the next GEMM's input — MAGI concatenates the
+ * self-attention and cross-attention outputs in front of linear_proj (inferix/models/magi/dit/dit_module.py:1281-1295); with the
+ * two attention launches writing columns [0, Q) and [Q, 2Q) of one [rows, 2Q] buffer the concatenation never exists as a copy.
+ * num_splits / workspace as ifx_attn_fwd_paged_split (1 / NULL = no split). */
+int ifx_attn_fwd_paged_ld(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t ldo, float* lse, const ifx_kv_view* kv,
+                          int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale, int32_t num_splits,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The same split-KV algebra in separate launches that share one workspace: under sequence parallelism the cached
  * prefix is attended while the collective that delivers the new block's keys is still in flight, then the new keys,
  * then ONE merge.  ifx_attn_fwd_partial writes the fp32 partials of up to `num_splits` key chunks of
@@ -196,8 +205,9 @@ int ifx_layernorm(const ifx_bf16* x, ifx_bf16* y, int32_t rows, int32_t dim, flo
  *   IFX_EPI_RESIDUAL  : y = bf16(res + bf16(acc + b))                         (cross-attn o)
  *   IFX_EPI_GATE_RES  : y = bf16(res + bf16(bf16(acc + b) * gate[r / rows_per_group]))
  *                       gate = rows of `mod` [groups, mod_slots, N] at gate_slot   (:444,455-456)
+ *   IFX_EPI_GELU_ERF  : y = bf16(gelu_erf(bf16(acc + b)))   exact GELU, MAGI CustomMLP fc1 (magi/dit/dit_module.py:545-557)
  * ---------------------------------------------------------------------- */
-enum { IFX_EPI_BIAS = 0, IFX_EPI_GELU_TANH = 1, IFX_EPI_RESIDUAL = 2, IFX_EPI_GATE_RES = 3 };
+enum { IFX_EPI_BIAS = 0, IFX_EPI_GELU_TANH = 1, IFX_EPI_RESIDUAL = 2, IFX_EPI_GATE_RES = 3, IFX_EPI_GELU_ERF = 4 };
 typedef struct {
   int32_t epilogue;
   const ifx_bf16* residual;  /* [M, N], row stride ld_res */
@@ -238,6 +248,23 @@ int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* w
 int ifx_layernorm_quant(const ifx_bf16* x, void* q, int32_t ldq, float* scale, int32_t rows, int32_t dim, float eps,
                         int32_t mode, const ifx_bf16* gamma, const ifx_bf16* beta, const ifx_bf16* mod, int32_t mod_slots,
                         int32_t shift_slot, int32_t scale_slot, int32_t rows_per_group, int32_t format, void* stream);
+
+/* Static-scale and per-tensor quantisers (the other qconfig families north_star names, and MAGI's own FP8 linears).
+ *   ifx_quant_static     : q[m,k] = cast(clamp(x[m,k] / divisor[k or 0], +-QMAX)).  With via_bf16 = 1 the clamped quotient is
+ *                          rounded to bf16 before the e4m3 cast — exactly `div_clamp_to`, the one quantisation routine in the
+ *                          reference tree (inferix/models/magi/dit/dit_module.py:367-387), used by PerTensorQuantizedFp8Linear
+ *                          (divisor = input_scale [in_features], :448-462) and PerChannelQuantizedFp8Linear (divisor =
+ *                          smooth_scale [1, in_features], :480-490).  divisor_len = K (per input channel) or 1.  row_scale:
+ *                          optional [rows] fp32, filled with divisor[0] when divisor_len == 1 (feeds ifx_gemm_q8's x_scale).
+ *                          The matmul itself is flashinfer's bmm_fp8 upstream (un-vendored): ifx_gemm_q8 with x_scale[m] =
+ *                          input_scale and w_scale[n] = weight_scale computes bf16(acc * (input_scale * weight_scale)).
+ *   ifx_quant_per_tensor : dynamic per-TENSOR scale s = max|x| / QMAX (1.0 for an all-zero tensor), q = cast(clamp(x / s)),
+ *                          row_scale[m] = s for every row.  Two kernels on the stream (abs-max reduction into the 4-byte
+ *                          amax_workspace, which the call zeroes with hipMemsetAsync, then the quantiser); no host sync. */
+int ifx_quant_static(const ifx_bf16* x, int32_t ldx, void* q, int32_t ldq, const float* divisor, int32_t divisor_len,
+                     float* row_scale, int32_t rows, int32_t K, int32_t format, int32_t via_bf16, void* stream);
+int ifx_quant_per_tensor(const ifx_bf16* x, int32_t ldx, void* q, int32_t ldq, float* row_scale, void* amax_workspace,
+                         int32_t rows, int32_t K, int32_t format, void* stream);
 
 /* ------------------------------------------------------------------------
  * KV cache maintenance.  ifx_kv_roll: the reference's eviction shift
@@ -322,6 +349,60 @@ int ifx_t5_attention(const ifx_bf16* q, int32_t ldq, const ifx_bf16* k, int32_t 
 /* h[rows][ffn] = fc1 * GELU(gate) with the tanh GELU of t5.py:50-52 evaluated op by op in bf16 (T5FeedForward.forward,
  * t5.py:138-139); gate_fc1 = [rows][2*ffn], columns [0, ffn) = gate pre-activation, [ffn, 2 ffn) = fc1 (one fused GEMM). */
 int ifx_t5_gated_gelu(const ifx_bf16* gate_fc1, ifx_bf16* h, int32_t rows, int32_t ffn, void* stream);
+
+/* ----------------------------------------------------------------------
+ * MAGI transformer layer (BASELINE config 5), the row kernels between its GEMMs and attention calls.
+ *
+ * ifx_magi_head_prep: everything FullyParallelAttention.get_q / get_k / get_v / get_xqkv do to the projection outputs
+ * (inferix/models/magi/dit/dit_module.py:902-970), one pass over the fused projection row:
+ *   layout 0: in = [rows, q_heads q | q_heads qx | kv_heads k | kv_heads v] x 128 (ONE GEMM over the concatenated
+ *             linear_qkv.{q,qx,k,v} weights)
+ *               q  : fp32 LayerNorm(128; qn_w (+1), qn_b) -> non-interleaved rotary (flash-attn apply_rotary_emb: with the head
+ *                    split x1 | x2, out = x1*cos - x2*sin | x1*sin + x2*cos, fp32) -> bf16 -> q_out[r, h*128]
+ *               k  : the same with kn_w / kn_b -> k_out[dest(r), h]
+ *               v  : copy -> v_out[dest(r), h]
+ *               qx : bf16 LayerNorm(xn_w (+1 in bf16), xn_b), one rounding -> qx_out[r, h*128]      (q_layernorm_xattn)
+ *   layout 1: in = [rows, kv_heads x (k | v)] x 128 (linear_kv_xattn output viewed [y, hn, 2*hd], :959-968)
+ *               k  : bf16 LayerNorm(xn_w, xn_b) (k_layernorm_xattn) -> k_out[dest(r), h];  v : copy -> v_out[dest(r), h]
+ *   rope      [rows, 128] fp32 = (sin[64] | cos[64]) per token, the reference's rotary_pos_emb rows (:1097)
+ *   k / v destination: element offset dest(r) * ld_kv + h * kv_head_stride with
+ *               dest(r) = r < split ? row0 + r : row1 + (r - split)
+ *             i.e. the rows MagiKVCacheManager's rule stores go to their final cache slots and the rest to the scratch tail
+ *             (inferix/kvcache_manager/model/magi_kv_cache_manager.py:76-187); or (row0 = 0, split = rows) a staging buffer
+ *             of the Ulysses all-to-all.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const ifx_bf16* in;
+  int32_t ld_in, rows, layout, q_heads, kv_heads, head_dim;
+  const float* rope;
+  const float *qn_w, *qn_b, *kn_w, *kn_b;     /* fp32 [128] */
+  const ifx_bf16 *xn_w, *xn_b;                /* bf16 [128] */
+  float eps;
+  int32_t layernorm_1p;                       /* apply_layernorm_1p: norm weight + 1 */
+  ifx_bf16* q_out;
+  int32_t ld_q;
+  ifx_bf16* qx_out;
+  int32_t ld_qx;
+  ifx_bf16* k_out;
+  ifx_bf16* v_out;
+  int32_t ld_kv, kv_head_stride;
+  int32_t row0, split, row1;
+} ifx_magi_head_prep_desc;
+int ifx_magi_head_prep(const ifx_magi_head_prep_desc* desc, void* stream);
+
+/* bias_modulate_add (dit_module.py:295-313): the Triton `range_mod_kernel_fwd` (:204-292) + post-norm + residual in one pass:
+ *   y[r] = bf16( LayerNorm_fp32( float(x[r]) * float(gate[condition_map[r]]) ; norm_w (+1), norm_b ) + float(residual[r]) )
+ *   gate: rows of the softcapped AdaModulateLayer output, row stride ld_gate (pass gate + hidden for the MLP half);
+ *   norm_w / norm_b fp32 [dim] (self_attn_post_norm / mlp_post_norm are fp32 modules, dit_model.py:620-637). */
+int ifx_magi_gate_norm_residual(const ifx_bf16* x, int32_t ldx, const ifx_bf16* residual, int32_t ld_res,
+                                const int32_t* condition_map, const ifx_bf16* gate, int32_t ld_gate, const float* norm_w,
+                                const float* norm_b, int32_t layernorm_1p, ifx_bf16* y, int32_t ldy, int32_t rows, int32_t dim,
+                                float eps, void* stream);
+
+/* Elementwise bf16 -> bf16 with fp32 math and one rounding: IFX_ACT_SILU (AdaModulateLayer.act, :196-198),
+ * IFX_ACT_TANH (softcap with cap 1, :363-364,:1300-1303). */
+enum { IFX_ACT_SILU = 0, IFX_ACT_TANH = 1 };
+int ifx_act_rows(const ifx_bf16* x, ifx_bf16* y, int64_t n, int32_t mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IFX_HIP_LIB", os.path.join(_HERE, "libinferix_hip.so"))   # override: kernel studies only
 
 IFX_LN_PLAIN, IFX_LN_AFFINE, IFX_LN_MODULATE = 0, 1, 2
-IFX_EPI_BIAS, IFX_EPI_GELU_TANH, IFX_EPI_RESIDUAL, IFX_EPI_GATE_RES = 0, 1, 2, 3
+IFX_EPI_BIAS, IFX_EPI_GELU_TANH, IFX_EPI_RESIDUAL, IFX_EPI_GATE_RES, IFX_EPI_GELU_ERF = 0, 1, 2, 3, 4
+IFX_ACT_SILU, IFX_ACT_TANH = 0, 1
 IFX_Q_FP8_E4M3, IFX_Q_INT8 = 0, 1
 
 
@@ -59,6 +60,17 @@ class Epilogue(C.Structure):
                 ("rows_per_group", C.c_int32)]
 
 
+class MagiHeadPrepDesc(C.Structure):
+    """ifx_magi_head_prep_desc"""
+    _fields_ = [("inp", C.c_void_p), ("ld_in", C.c_int32), ("rows", C.c_int32), ("layout", C.c_int32),
+                ("q_heads", C.c_int32), ("kv_heads", C.c_int32), ("head_dim", C.c_int32), ("rope", C.c_void_p),
+                ("qn_w", C.c_void_p), ("qn_b", C.c_void_p), ("kn_w", C.c_void_p), ("kn_b", C.c_void_p),
+                ("xn_w", C.c_void_p), ("xn_b", C.c_void_p), ("eps", C.c_float), ("layernorm_1p", C.c_int32),
+                ("q_out", C.c_void_p), ("ld_q", C.c_int32), ("qx_out", C.c_void_p), ("ld_qx", C.c_int32),
+                ("k_out", C.c_void_p), ("v_out", C.c_void_p), ("ld_kv", C.c_int32), ("kv_head_stride", C.c_int32),
+                ("row0", C.c_int32), ("split", C.c_int32), ("row1", C.c_int32)]
+
+
 # name -> (restype, argtypes); the complete export list of include/inferix_hip.h
 _vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
 SIGNATURES = {
@@ -89,6 +101,14 @@ SIGNATURES = {
     "ifx_quant_per_token": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "ifx_layernorm_quant": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ifx_gemm_q8": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
+    "ifx_attn_fwd_paged_ld": (C.c_int, [_vp, _i32, _vp, _i32, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
+                                        C.c_int64, _vp]),
+    "ifx_quant_static": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ifx_quant_per_tensor": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "ifx_magi_head_prep": (C.c_int, [C.POINTER(MagiHeadPrepDesc), _vp]),
+    "ifx_magi_gate_norm_residual": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32,
+                                              _vp]),
+    "ifx_act_rows": (C.c_int, [_vp, _vp, C.c_int64, _i32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

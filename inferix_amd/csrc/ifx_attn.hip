@@ -46,6 +46,7 @@ struct AttnArgs {
   const unsigned short* v;
   KvAddr ka;
   int q_rows, heads, kv_start, kv_len, q_tiles, per_xcd, total;   // keys [kv_start, kv_len)
+  int ldq, ldo;             // elements between consecutive rows of q / out
   int kv_heads, q_per_kv;   // grouped-query attention: query head h reads kv head h / q_per_kv
   float scale, scale_log2;
 };
@@ -101,7 +102,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const int wi = xcd * A.per_xcd + slot_i;
   if (slot_i >= A.per_xcd || wi >= A.total) return;
   const int head = wi / A.q_tiles, qt = wi - head * A.q_tiles;
-  const int row_stride = A.heads * HD;   // elements between consecutive tokens (q, out)
   const int kv_stride = A.kv_heads * HD;  // ... of the cache rows
   const int kvh = head / A.q_per_kv;
 
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const int qrow_c = min(qrow, A.q_rows - 1);
   bf16x8 qf[8];
   {
-    const unsigned short* qp = A.q + (size_t)qrow_c * row_stride + head * HD + hi * 8;
+    const unsigned short* qp = A.q + (size_t)qrow_c * A.ldq + head * HD + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   if (qrow < A.q_rows) {
-    unsigned short* op = A.out + (size_t)qrow * row_stride + head * HD + 4 * hi;
+    unsigned short* op = A.out + (size_t)qrow * A.ldo + head * HD + 4 * hi;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -384,9 +384,9 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
 
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
-                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr);
+                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0);
 int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsigned short* out, float* lse, int q_rows,
-                      int heads, hipStream_t stream);
+                      int heads, hipStream_t stream, int ldo = 0);
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
 int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots);
 // schedule of the multi-wave kernel for a launch (the `groups` code of launch_attn_pp): 2 phase-locked ping-pong, 3 three groups
@@ -410,8 +410,12 @@ using namespace ifx;
 
 static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv, int32_t q_rows,
                          int32_t heads, int32_t kv_start, int32_t kv_len, float scale, int32_t splits, void* workspace,
-                         int64_t workspace_bytes, void* stream) {
+                         int64_t workspace_bytes, void* stream, int32_t ldq = 0, int32_t ldo = 0) {
   IFX_REQUIRE(q && out && kv && kv->k && kv->v, "ifx_attn_fwd_paged: null argument");
+  if (ldq <= 0) ldq = heads * HD;
+  if (ldo <= 0) ldo = heads * HD;
+  IFX_REQUIRE(ldq >= heads * HD && ldo >= heads * HD && ldq % 8 == 0 && ldo % 8 == 0,
+              "ifx_attn_fwd_paged: row strides (%d, %d) must be >= heads * 128 and multiples of 8", ldq, ldo);
   IFX_REQUIRE(kv->head_dim == HD, "ifx_attn_fwd_paged: head_dim %d not built (128 only)", kv->head_dim);
   IFX_REQUIRE(heads > 0 && kv->kv_heads > 0 && heads % kv->kv_heads == 0,
               "ifx_attn_fwd_paged: heads %d is not a multiple of kv_heads %d", heads, kv->kv_heads);
@@ -425,11 +429,11 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
                 "ifx_attn_fwd_paged_split: workspace of %lld B too small for %d splits (need %lld B)",
                 (long long)workspace_bytes, splits, (long long)attn_pp_workspace_bytes(q_rows, heads, splits));
     return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant, q_rows),
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, 0, 0, nullptr, ldq, ldo);
   }
   if (variant >= 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
     return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant, q_rows),
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, 0, 0, nullptr, ldq, ldo);
   AttnArgs a;
   a.q = q;
   a.out = out;
@@ -439,6 +443,8 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
   a.ka = KvAddr{kv->page_table, kv->page_size};
   a.q_rows = q_rows;
   a.heads = heads;
+  a.ldq = ldq;
+  a.ldo = ldo;
   a.kv_start = kv_start;
   a.kv_len = kv_len;
   a.kv_heads = kv->kv_heads;
@@ -465,6 +471,15 @@ extern "C" int ifx_attn_fwd_paged(const ifx_bf16* q, ifx_bf16* out, float* lse, 
                                   int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
                                   void* stream) {
   return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, 0, stream);
+}
+
+extern "C" int ifx_attn_fwd_paged_ld(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t ldo, float* lse, const ifx_kv_view* kv,
+                                     int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale,
+                                     int32_t num_splits, void* workspace, int64_t workspace_bytes, void* stream) {
+  IFX_REQUIRE(num_splits >= 1 && num_splits <= 64, "ifx_attn_fwd_paged_ld: num_splits %d outside [1, 64]", num_splits);
+  IFX_REQUIRE(ldq > 0 && ldo > 0, "ifx_attn_fwd_paged_ld: row strides must be given");
+  return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, workspace_bytes, stream,
+                       ldq, ldo);
 }
 
 extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len,

@@ -85,6 +85,7 @@ struct AttnArgsPP {
   const unsigned short* v;
   KvAddr ka;
   int q_rows, heads, kv_start, kv_len, num_slots, q_tiles, per_xcd, total;
+  int ldq, ldo;             // elements between consecutive rows of q / out (heads * 128 unless the caller strides them)
   float scale, scale_log2;
   // split-KV (SPLIT kernels only): `splits` key chunks of `chunk_tiles` 64-key tiles each; chunk sp of (head, q tile)
   // writes a normalised fp32 partial O to part_o[sp][row][head][128] and its LSE to part_lse[sp][head][row]
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   const int qrow_c = min(qrow, A.q_rows - 1);
   bf16x8 qf[8];
   {
-    const unsigned short* qp = A.q + (size_t)qrow_c * row_stride + head * HD + hi * 8;
+    const unsigned short* qp = A.q + (size_t)qrow_c * A.ldq + head * HD + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     return;
   }
   if (qrow < A.q_rows) {
-    unsigned short* op = A.out + (size_t)qrow * row_stride + head * HD + 4 * hi;
+    unsigned short* op = A.out + (size_t)qrow * A.ldo + head * HD + 4 * hi;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -926,7 +927,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
 __global__ __launch_bounds__(256) void attn_split_merge_kernel(const float* __restrict__ part_o,
                                                                const float* __restrict__ part_lse,
                                                                unsigned short* __restrict__ out, float* __restrict__ lse,
-                                                               int q_rows, int heads, int splits) {
+                                                               int q_rows, int heads, int splits, int ldo) {
   const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);      // (row, head) pair, 32 lanes x 4 channels
   if (pair >= q_rows * heads) return;
   const int row = pair / heads, head = pair - row * heads, c = (threadIdx.x & 31) * 4;
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(256) void attn_split_merge_kernel(const float* __re
   u16x4 w4;
 #pragma unroll
   for (int e = 0; e < 4; ++e) w4[e] = f2bf(acc[e] * inv);
-  *reinterpret_cast<u16x4*>(out + ((size_t)row * heads + head) * 128 + c) = w4;
+  *reinterpret_cast<u16x4*>(out + (size_t)row * ldo + head * 128 + c) = w4;
   if (lse != nullptr && c == 0) lse[(size_t)head * q_rows + row] = mx + __logf(den);
 }
 
@@ -1037,7 +1038,7 @@ static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid,
 //                [slot_base, slot_base + splits), no merge; *slots_used reports how many chunks were written.
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
-                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr) {
+                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0) {
   using namespace pp;
   const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : 0));   // attn_variant 4 / 5 / 6
   if (fr_mode) groups = fr_mode == 3 ? 1 : 2;
@@ -1051,6 +1052,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.ka = KvAddr{kv->page_table, kv->page_size};
   a.q_rows = q_rows;
   a.heads = heads;
+  a.ldq = ldq > 0 ? ldq : heads * 128;
+  a.ldo = ldo > 0 ? ldo : heads * 128;
   a.kv_start = kv_start;
   a.kv_len = kv_len;
   a.num_slots = kv->num_slots;
@@ -1089,18 +1092,18 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   if (!partial && a.splits > 1) {
     const int pairs = q_rows * heads;
     hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, a.part_o, a.part_lse, out,
-                       lse, q_rows, heads, a.splits);
+                       lse, q_rows, heads, a.splits, a.ldo);
   }
   return check_launch("ifx_attn_fwd_paged(pp)");
 }
 
 int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsigned short* out, float* lse, int q_rows,
-                      int heads, hipStream_t stream) {
+                      int heads, hipStream_t stream, int ldo = 0) {
   const float* part_o = workspace;
   const float* part_lse = workspace + (size_t)slot_cap * q_rows * heads * 128;
   const int pairs = q_rows * heads;
   hipLaunchKernelGGL(attn_split_merge_kernel, dim3((pairs + 7) / 8), dim3(256), 0, stream, part_o, part_lse, out, lse,
-                     q_rows, heads, slots_used);
+                     q_rows, heads, slots_used, ldo > 0 ? ldo : heads * 128);
   return check_launch("ifx_attn_merge_partials");
 }
 

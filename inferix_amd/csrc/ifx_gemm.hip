@@ -36,6 +36,10 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x / (1.0f + __expf(-2.0f * u));
 }
+// exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
+// inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
+// otherwise unused `gate_slot` field carries 1 for IFX_EPI_GELU_ERF.
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
       } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_tanh_f(rbf(v[e])));
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(rbf(v[e])) : gelu_tanh_f(rbf(v[e]))));
       } else {
         const u16x4 rv = *reinterpret_cast<const u16x4*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -238,8 +242,12 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
   IFX_REQUIRE(x && w && y && M >= 0 && N > 0 && K > 0, "ifx_gemm_bf16: null/empty operand");
   IFX_REQUIRE(K % BK == 0, "ifx_gemm_bf16: K (%d) must be a multiple of %d", K, BK);   // 64; also covers the 32-deep tiles
   IFX_REQUIRE(N % 4 == 0 && ldx % 8 == 0 && ldy % 4 == 0, "ifx_gemm_bf16: N %% 4, ldx %% 8, ldy %% 4 required");
-  const int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
+  int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
   EpiArgs ea{bias, nullptr, 0, nullptr, 1, 0, 1};
+  if (mode == IFX_EPI_GELU_ERF) {       // the GELU instantiation with the exact-erf activation selected at run time
+    mode = IFX_EPI_GELU_TANH;
+    ea.gate_slot = 1;
+  }
   if (mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES) {
     IFX_REQUIRE(epi->residual && epi->ld_res % 4 == 0, "ifx_gemm_bf16: residual epilogue needs residual/ld_res");
     ea.residual = epi->residual;

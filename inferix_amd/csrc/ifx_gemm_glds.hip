@@ -60,6 +60,10 @@ __device__ __forceinline__ float gelu_tanh_f2(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x / (1.0f + __expf(-2.0f * u));
 }
+// exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
+// inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
+// otherwise unused `gate_slot` field carries 1 for IFX_EPI_GELU_ERF.
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short*
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_small_kernel(const unsigned sho
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const unsigned short* __re
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {

@@ -116,6 +116,10 @@ __device__ __forceinline__ float gelu_tanh_q(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x / (1.0f + __expf(-2.0f * u));
 }
+// exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
+// inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
+// otherwise unused `gate_slot` field carries 1 for IFX_EPI_GELU_ERF.
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 template <bool FP8, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_q8_kernel(const unsigned char* __restrict__ x, int ldx,
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_kernel(const unsigned char* __
           for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
         } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_tanh_q(rbf(v[e])));
+          for (int e = 0; e < 4; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(rbf(v[e])) : gelu_tanh_q(rbf(v[e]))));
         } else {
           const u16x4 rv = *reinterpret_cast<const u16x4*>(ea.residual + (size_t)m * ea.ld_res + n);
           if (EPI == IFX_EPI_RESIDUAL) {
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_q(bf2f(vv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_q(bf2f(vv[e]))));
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -557,8 +561,12 @@ extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, co
   IFX_REQUIRE(K % 128 == 0, "ifx_gemm_q8: K (%d) must be a multiple of 128", K);
   IFX_REQUIRE(N % 4 == 0 && ldx % 16 == 0 && ldy % 4 == 0, "ifx_gemm_q8: N %% 4, ldx %% 16, ldy %% 4 required");
   IFX_REQUIRE(format == IFX_Q_FP8_E4M3 || format == IFX_Q_INT8, "ifx_gemm_q8: unknown format %d", format);
-  const int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
+  int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
   EpiArgsQ ea{x_scale, w_scale, bias, nullptr, 0, nullptr, 1, 0, 1};
+  if (mode == IFX_EPI_GELU_ERF) {       // the GELU instantiation with the exact-erf activation selected at run time
+    mode = IFX_EPI_GELU_TANH;
+    ea.gate_slot = 1;
+  }
   if (mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES) {
     IFX_REQUIRE(epi->residual && epi->ld_res % 4 == 0, "ifx_gemm_q8: residual epilogue needs residual/ld_res");
     ea.residual = epi->residual;

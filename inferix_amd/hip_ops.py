@@ -521,3 +521,120 @@ def t5_gated_gelu(gate_fc1: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     _hip.check(_hip.load().ifx_t5_gated_gelu(_dev(gate_fc1, "gate_fc1"), _dev(out, "h"), rows, ffn, _stream()),
                "ifx_t5_gated_gelu")
     return out
+
+
+# ---- strided attention, MAGI layer ops, static / per-tensor quantisers -------------------------------------------------
+def attention_ld(q: torch.Tensor, kv: KvCacheView, kv_len: int, out: torch.Tensor, heads: int, kv_start: int = 0,
+                 scale: float = 0.0, tag: str = "attn") -> torch.Tensor:
+    """`attention` for query / output rows that are column blocks of wider matrices (ifx_attn_fwd_paged_ld): `q` and `out` are
+    2-D `[rows, >= heads*128]` views whose row strides are passed on; the result lands in `out[:, :heads*128]`."""
+    lib = _hip.load()
+    rows = q.shape[0]
+    assert q.dim() == 2 and out.dim() == 2 and out.shape[0] == rows and q.stride(1) == 1 and out.stride(1) == 1
+    assert q.shape[1] >= heads * 128 and out.shape[1] >= heads * 128
+    ks = kv.struct()
+    nk = kv_len - kv_start
+    key = (rows, heads, nk)
+    plan = _SPLIT_PLAN.get(key)
+    if plan is None:
+        need = C.c_int64(0)
+        plan = (int(lib.ifx_attn_split_plan(rows, heads, int(kv_start), int(kv_len), C.byref(need))), int(need.value))
+        _SPLIT_PLAN[key] = plan
+    splits, ws_bytes = plan
+    ws = _attn_workspace(q.device, ws_bytes) if splits > 1 else None
+    d = heads * 128
+    with _timed(tag, 4.0 * rows * nk * d, 2.0 * (2 * rows * d + 2 * nk * kv.k.shape[1] * 128)):
+        _hip.check(lib.ifx_attn_fwd_paged_ld(_dev(q, "q"), q.stride(0), _dev(out, "out"), out.stride(0), None, C.byref(ks), rows,
+                                             heads, int(kv_start), int(kv_len), float(scale), int(splits),
+                                             ws.data_ptr() if ws is not None else None,
+                                             ws.numel() * 4 if ws is not None else 0, _stream()), "ifx_attn_fwd_paged_ld")
+    return out
+
+
+F32 = torch.float32
+
+
+def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: int, eps: float, layernorm_1p: bool,
+                   k_out: torch.Tensor, v_out: torch.Tensor, kv_head_stride: int, ld_kv: int, row0: int = 0,
+                   split: Optional[int] = None, row1: int = 0, rope: Optional[torch.Tensor] = None, qn=None, kn=None, xn=None,
+                   q_out: Optional[torch.Tensor] = None, qx_out: Optional[torch.Tensor] = None) -> None:
+    """ifx_magi_head_prep: per-head LayerNorm (+ rotary) of the fused projection row and the k / v scatter (include/inferix_hip.h).
+    `qn` / `kn` = (weight, bias) fp32 `[128]`; `xn` = (weight, bias) bf16 `[128]`; `k_out` / `v_out` are base tensors of the
+    destination (cache planes or a staging buffer), addressed dest(r) * ld_kv + head * kv_head_stride."""
+    rows = mixed.shape[0]
+    assert mixed.dim() == 2 and mixed.stride(1) == 1
+    d = _hip.MagiHeadPrepDesc()
+    d.inp, d.ld_in, d.rows, d.layout = _dev(mixed, "mixed"), mixed.stride(0), rows, layout
+    d.q_heads, d.kv_heads, d.head_dim = q_heads, kv_heads, 128
+    d.eps, d.layernorm_1p = float(eps), 1 if layernorm_1p else 0
+    if layout == 0:
+        assert rope is not None and rope.is_contiguous() and tuple(rope.shape) == (rows, 128)
+        d.rope = _dev(rope, "rope", F32)
+        d.qn_w, d.qn_b = _dev(qn[0], "q_layernorm.weight", F32), _dev(qn[1], "q_layernorm.bias", F32)
+        d.kn_w, d.kn_b = _dev(kn[0], "k_layernorm.weight", F32), _dev(kn[1], "k_layernorm.bias", F32)
+        d.q_out, d.ld_q = _dev(q_out, "q_out"), q_out.stride(0)
+        d.qx_out, d.ld_qx = _dev(qx_out, "qx_out"), qx_out.stride(0)
+        assert q_out.shape[0] >= rows and qx_out.shape[0] >= rows
+    d.xn_w, d.xn_b = _dev(xn[0], "layernorm_xattn.weight"), _dev(xn[1], "layernorm_xattn.bias")
+    d.k_out, d.v_out, d.ld_kv, d.kv_head_stride = _dev(k_out, "k_out"), _dev(v_out, "v_out"), int(ld_kv), int(kv_head_stride)
+    d.row0, d.split, d.row1 = int(row0), int(rows if split is None else split), int(row1)
+    n_heads = (2 * q_heads + 2 * kv_heads) if layout == 0 else 2 * kv_heads
+    with _timed("magi_head_prep", 0.0, 4.0 * rows * n_heads * 128):
+        _hip.check(_hip.load().ifx_magi_head_prep(C.byref(d), _stream()), "ifx_magi_head_prep")
+
+
+def magi_gate_norm_residual(x: torch.Tensor, residual: torch.Tensor, condition_map: torch.Tensor, gate: torch.Tensor,
+                            norm_w: torch.Tensor, norm_b: torch.Tensor, eps: float, layernorm_1p: bool,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bias_modulate_add in one pass (ifx_magi_gate_norm_residual).  `gate` `[groups, dim]` view (row-strided is fine)."""
+    rows, dim, ldx = _rows2d(x, "x")
+    _, _, ldr = _rows2d(residual, "residual")
+    out = torch.empty(rows, dim, dtype=BF16, device=x.device) if out is None else out
+    _, _, ldy = _rows2d(out, "out")
+    assert gate.dim() == 2 and gate.shape[1] == dim and gate.stride(1) == 1
+    assert condition_map.dtype == torch.int32 and condition_map.is_cuda and condition_map.numel() == rows and condition_map.is_contiguous()
+    with _timed("magi_gate_norm", 0.0, 6.0 * rows * dim):
+        _hip.check(_hip.load().ifx_magi_gate_norm_residual(
+            _dev(x, "x"), ldx, _dev(residual, "residual"), ldr, condition_map.data_ptr(), _dev(gate, "gate"), gate.stride(0),
+            _dev(norm_w, "norm_w", F32), _dev(norm_b, "norm_b", F32), 1 if layernorm_1p else 0, _dev(out, "out"), ldy, rows, dim,
+            float(eps), _stream()), "ifx_magi_gate_norm_residual")
+    return out
+
+
+def act_rows(x: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SiLU (mode IFX_ACT_SILU) / tanh (IFX_ACT_TANH) of a contiguous bf16 tensor (ifx_act_rows)."""
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _hip.check(_hip.load().ifx_act_rows(_dev(x, "x"), _dev(out, "out"), x.numel(), int(mode), _stream()), "ifx_act_rows")
+    return out
+
+
+def quant_static(x: torch.Tensor, divisor: torch.Tensor, fmt: int, via_bf16: bool, q: Optional[torch.Tensor] = None,
+                 row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q = cast(clamp(x / divisor)) with a per-input-channel (`[K]`) or single (`[1]`) fp32 divisor (ifx_quant_static);
+    `via_bf16` = the bf16 intermediate of the reference's div_clamp_to."""
+    rows, K, ldx = _rows2d(x, "x")
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
+    divisor = divisor.reshape(-1)
+    _hip.check(_hip.load().ifx_quant_static(_dev(x, "x"), ldx, _dev(q, "q", torch.uint8), q.stride(0), _dev(divisor, "divisor", F32),
+                                            divisor.numel(), _dev(row_scale, "row_scale", F32) if row_scale is not None else None,
+                                            rows, K, int(fmt), 1 if via_bf16 else 0, _stream()), "ifx_quant_static")
+    return q
+
+
+_AMAX_WS: dict = {}
+
+
+def quant_per_tensor(x: torch.Tensor, fmt: int, q: Optional[torch.Tensor] = None,
+                     scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dynamic per-tensor quantisation (ifx_quant_per_tensor): bytes `[rows, K]` + the tensor's scale repeated per row `[rows]`."""
+    rows, K, ldx = _rows2d(x, "x")
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
+    scale = torch.empty(rows, dtype=F32, device=x.device) if scale is None else scale
+    key = (x.device.index, _stream())
+    ws = _AMAX_WS.get(key)
+    if ws is None:
+        ws = _AMAX_WS[key] = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _hip.check(_hip.load().ifx_quant_per_tensor(_dev(x, "x"), ldx, _dev(q, "q", torch.uint8), q.stride(0), _dev(scale, "scale", F32),
+                                                ws.data_ptr(), rows, K, int(fmt), _stream()), "ifx_quant_per_tensor")
+    return q, scale

@@ -94,28 +94,28 @@ class MagiKVCacheManager:
             self._maps[key] = m
         return m
 
-    def adjust_key_and_value_for_inference(self, key_and_value: torch.Tensor, inference_params: Optional[InferenceParams],
-                                           meta_args: ModelMetaArgs) -> MagiKvHandle:
-        """`key_and_value` `[n, hn, 2*hd]` (K | V on the last dim, after the all-to-all).  Stores what the reference's
-        rule stores and returns the handle attention reads: logical keys = prefix `[0, slice_point*clip*B)` + the n new."""
-        n, hn, hd2 = key_and_value.shape
-        hd = hd2 // 2
+    def prepare_append(self, n: int, hn: int, hd: int, dtype: torch.dtype, device, inference_params: Optional[InferenceParams],
+                       meta_args: ModelMetaArgs) -> Tuple[MagiKvHandle, Tuple[int, int, int]]:
+        """Where the `n` new key / value rows of this forward go, decided BEFORE they are computed, so that the kernel that
+        produces them (ifx_magi_head_prep) writes them in place: returns the handle attention reads and `(row0, split, row1)` —
+        row r lands in plane row `row0 + r` if `r < split` (the rows the reference's rule stores: final cache slots) and in
+        `row1 + r - split` otherwise (the scratch tail behind the cache).  Without cache involvement the planes are fresh."""
         use_cache = inference_params is not None and (meta_args.extract_prefix_video_feature or
                                                       meta_args.fwd_extra_1st_chunk or meta_args.slice_point > 0)
         if not use_cache:
-            k, v = key_and_value[..., :hd].contiguous(), key_and_value[..., hd:].contiguous()
-            return MagiKvHandle(ops.KvCacheView(k, v), n, hn)
+            k = torch.empty(n, hn, hd, dtype=dtype, device=device)
+            v = torch.empty(n, hn, hd, dtype=dtype, device=device)
+            return MagiKvHandle(ops.KvCacheView(k, v), n, hn), (0, n, 0)
         ip = inference_params
         B = ip.max_batch_size
         if not self.is_cached(ip):
-            self.allocate_key_value_memory(ip, ip.max_sequence_length, B, key_and_value.dtype,
-                                           scratch_rows=max(self._scratch_rows, n))
+            self.allocate_key_value_memory(ip, ip.max_sequence_length, B, dtype, scratch_rows=max(self._scratch_rows, n))
         raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, self.layer_name)     # (2, tokens, 1, hn, hd)
         capacity = ip.max_sequence_length
         if raw.shape[1] - capacity < n:                  # scratch tail too small for this forward: grow it (rare)
             keep = raw[:, :capacity].clone()
             self.clear_cache(ip)
-            self.allocate_key_value_memory(ip, capacity, B, key_and_value.dtype, scratch_rows=n)
+            self.allocate_key_value_memory(ip, capacity, B, dtype, scratch_rows=n)
             raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, self.layer_name)
             raw[:, :capacity].copy_(keep)
         start = meta_args.slice_point * meta_args.clip_token_nums * B
@@ -124,14 +124,25 @@ class MagiKVCacheManager:
             stored = n - meta_args.clip_token_nums * B if meta_args.distill_nearly_clean_chunk else n
             assert start + stored <= capacity, "KV cache overflow"
         kc, vc = raw[0, :, 0], raw[1, :, 0]
-        if stored:
-            kc[start:start + stored].copy_(key_and_value[:stored, :, :hd])
-            vc[start:start + stored].copy_(key_and_value[:stored, :, hd:])
-        if n - stored:
-            kc[capacity:capacity + n - stored].copy_(key_and_value[stored:, :, :hd])
-            vc[capacity:capacity + n - stored].copy_(key_and_value[stored:, :, hd:])
         table = self._token_map(raw.device, start, stored, n - stored, capacity)
-        return MagiKvHandle(ops.KvCacheView(kc, vc, table, 1), start + n, hn)
+        return MagiKvHandle(ops.KvCacheView(kc, vc, table, 1), start + n, hn), (start, stored, capacity)
+
+    def adjust_key_and_value_for_inference(self, key_and_value: torch.Tensor, inference_params: Optional[InferenceParams],
+                                           meta_args: ModelMetaArgs) -> MagiKvHandle:
+        """`key_and_value` `[n, hn, 2*hd]` (K | V on the last dim, after the all-to-all).  Stores what the reference's
+        rule stores and returns the handle attention reads: logical keys = prefix `[0, slice_point*clip*B)` + the n new."""
+        n, hn, hd2 = key_and_value.shape
+        hd = hd2 // 2
+        handle, (row0, split, row1) = self.prepare_append(n, hn, hd, key_and_value.dtype, key_and_value.device,
+                                                          inference_params, meta_args)
+        kc, vc = handle.view.k, handle.view.v
+        if split:
+            kc[row0:row0 + split].copy_(key_and_value[:split, :, :hd])
+            vc[row0:row0 + split].copy_(key_and_value[:split, :, hd:])
+        if n - split:
+            kc[row1:row1 + n - split].copy_(key_and_value[split:, :, :hd])
+            vc[row1:row1 + n - split].copy_(key_and_value[split:, :, hd:])
+        return handle
 
 
 def core_attention(query: torch.Tensor, key, value, bs: int, meta_args: ModelMetaArgs,

@@ -1,0 +1,246 @@
+"""MAGI transformer layer on MI355X — the denoise-step compute of BASELINE config 5 behind the reference's module names.
+
+Mirrors `inferix/models/magi/dit/dit_module.py`:
+  `TransformerLayer` (:1201-1319)            -> `HipMagiTransformerLayer`   (forward: same seven arguments)
+  `FullyParallelAttention` (:833-1195)       -> `HipFullyParallelAttention` (`cp_strategy` "none" and "cp_ulysses")
+  `TransformerBlock` (:1322-1390)            -> `HipMagiTransformerBlock`   (the layer stack + fp32 final LayerNorm)
+State-dict keys are the reference's (`self_attention.linear_qkv.q.weight`, ...), loaded with `load_state_dict`.
+
+Per layer, 17 kernel launches for one denoising range (every one an `ifx_*` entry of libinferix_hip.so, no torch compute):
+  ifx_layernorm (affine)            linear_qkv.layer_norm                                               :415-416
+  ifx_gemm_bf16                     q | qx | k | v in ONE GEMM over the concatenated weights             :418-431
+  ifx_magi_head_prep                per-head LayerNorm (fp32 q/k, bf16 qx) + rotary + K/V written in place to the cache  :902-970
+  ifx_attn_fwd_paged_ld x ranges    range attention, grouped-query heads, prefix read in place, output -> columns [0, Q) of
+                                    the projection input                                                :972-1015
+  ifx_gemm_bf16 + ifx_magi_head_prep   linear_kv_xattn + k_layernorm_xattn on the caption tokens         :959-970
+  ifx_attn_fwd_paged_ld x segments  varlen cross-attention -> columns [Q, 2Q)                            :1047-1085
+  ifx_gemm_bf16                     linear_proj; the "(n hn hd) -> (hn n hd)" interleave of :1287 is folded into a column
+                                    permutation of the weight at load time, so the concatenation is never built
+  ifx_act_rows, ifx_gemm_bf16, ifx_act_rows   SiLU -> AdaModulateLayer.proj -> softcap(tanh)  (tiny: one row per range) :196-198,:1300-1303
+  ifx_magi_gate_norm_residual       range_mod gate x post-norm (fp32) + residual                        :295-313
+  ifx_layernorm, ifx_gemm_bf16 (+ exact-GELU epilogue), ifx_gemm_bf16        CustomMLP                    :545-557
+  ifx_magi_gate_norm_residual       the MLP half of the gate
+
+Batch 1 only (as `core_attention`'s cached path upstream: 3-cfg folds ranges into the batch before it gets here).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import _hip
+from .. import hip_ops as ops
+from . import context_parallel as cpl
+from .attention import MagiKVCacheManager
+from .types import InferenceParams, ModelMetaArgs
+
+BF16 = torch.bfloat16
+FP32_PARAMS = ("self_attention.q_layernorm.", "self_attention.k_layernorm.", "self_attn_post_norm.", "mlp_post_norm.",
+               "final_layernorm.")
+
+
+def _cfg(model_config, name, default=None):
+    return getattr(model_config, name, default)
+
+
+class HipFullyParallelAttention:
+    """The attention half of a layer; owns the per-layer `MagiKVCacheManager` like the reference's module."""
+
+    def __init__(self, model_config, engine_config, layer_number: int, device):
+        self.model_config, self.engine_config, self.layer_number = model_config, engine_config, layer_number
+        self.device = torch.device(device)
+        self.hd = model_config.kv_channels
+        if self.hd != 128:
+            raise NotImplementedError("the HIP attention kernels are built for head_dim 128 (MAGI-4.5B / 24B)")
+        self.hq = model_config.num_attention_heads
+        self.hk = model_config.num_query_groups
+        cp = cpl.get_cp_world_size() if getattr(engine_config, "cp_strategy", "none") != "none" else 1
+        # dit_module.py:796-800: kv heads per rank (replicated when there are fewer kv heads than ranks)
+        self.hk_local = 1 if (cp > self.hk and cp % self.hk == 0) else self.hk // cp
+        self.hq_local = self.hq // cp
+        self.kv_cache_manager = MagiKVCacheManager(layer_number=layer_number, num_query_groups_per_partition=self.hk_local,
+                                                   hidden_size_per_attention_head=self.hd, engine_config=engine_config)
+        self.adapt_linear_quant = bool(getattr(engine_config, "fp8_quant", False)) and layer_number != 0 and \
+            layer_number != model_config.num_layers - 1
+        if self.adapt_linear_quant:
+            raise NotImplementedError("fp8_quant checkpoints (static-scale FP8 linears) load through inferix_amd.quant."
+                                      "StaticFp8Linear; wiring them into this layer is not built yet")
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def load(self, W: Dict[str, torch.Tensor], prefix: str) -> None:
+        dev, Q = self.device, self.hq * self.hd
+        g = lambda k: W[prefix + k].to(dev)
+        self.w["qkv"] = torch.cat([g("linear_qkv.q.weight"), g("linear_qkv.qx.weight"), g("linear_qkv.k.weight"),
+                                   g("linear_qkv.v.weight")], dim=0).to(BF16).contiguous()
+        self.w["ln_w"], self.w["ln_b"] = g("linear_qkv.layer_norm.weight").to(BF16), g("linear_qkv.layer_norm.bias").to(BF16)
+        self.w["kvx"] = g("linear_kv_xattn.weight").to(BF16).contiguous()
+        # attn_linear_proj (:1287): the module multiplies linear_proj.weight with rearrange(cat([core, xattn]),
+        # "(n hn hd) -> (hn n hd)", n=2, hn=8).  Column j = n*Q + g*c + r of the un-rearranged concatenation (c = Q/8) is
+        # column g*2c + n*c + r of the rearranged one: permute the weight's columns once instead of the activations every call.
+        c = Q // 8
+        j = torch.arange(2 * Q)
+        n, rem = j // Q, j % Q
+        src = (rem // c) * (2 * c) + n * c + rem % c
+        self.w["proj"] = g("linear_proj.weight").to(BF16)[:, src.to(dev)].contiguous()
+        for nm in ("q_layernorm", "k_layernorm"):
+            self.w[nm] = (g(nm + ".weight").float().contiguous(), g(nm + ".bias").float().contiguous())
+        for nm in ("q_layernorm_xattn", "k_layernorm_xattn"):
+            self.w[nm] = (g(nm + ".weight").to(BF16).contiguous(), g(nm + ".bias").to(BF16).contiguous())
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def forward(self, hidden_states: torch.Tensor, key_value_states: torch.Tensor, inference_params: Optional[InferenceParams],
+                rotary_pos_emb: torch.Tensor, meta_args: ModelMetaArgs, attn_cat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> `[sq, 2Q]` bf16 = (core_attn_out | xattn_out) per token, the input of `linear_proj` (weights pre-permuted)."""
+        mc, w = self.model_config, self.w
+        s_len, bsz, h = hidden_states.shape
+        if bsz != 1:
+            raise NotImplementedError("MAGI runs the cached path with batch 1 (3-cfg converts ranges to batch upstream)")
+        eps, one_p = mc.layernorm_epsilon, bool(mc.apply_layernorm_1p)
+        Q = self.hq * self.hd
+        x2 = hidden_states.view(s_len, h)
+        hln = ops.layernorm(x2, eps, gamma=w["ln_w"], beta=w["ln_b"])
+        mixed = ops.linear(hln, w["qkv"], None)                                          # [s, q | qx | k | v]
+        if attn_cat is None:
+            attn_cat = torch.empty(s_len, 2 * Q, dtype=BF16, device=x2.device)
+        q_buf = torch.empty(s_len, Q, dtype=BF16, device=x2.device)
+        qx_buf = torch.empty(s_len, Q, dtype=BF16, device=x2.device)
+        rope = rotary_pos_emb if rotary_pos_emb.dtype == torch.float32 else rotary_pos_emb.float()
+        strategy = getattr(self.engine_config, "cp_strategy", "none")
+        cp = cpl.get_cp_world_size() if strategy != "none" else 1
+        if strategy == "cp_shuffle_overlap":
+            raise NotImplementedError("cp_shuffle_overlap targets PCIe consumer GPUs upstream; MI355X uses cp_ulysses over xGMI")
+        cq = meta_args.core_attn_params.np_q_range
+        ck = meta_args.core_attn_params.np_k_range
+        if cp == 1:
+            handle, (row0, split, row1) = self.kv_cache_manager.prepare_append(s_len, self.hk, self.hd, BF16, x2.device,
+                                                                               inference_params, meta_args)
+            ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
+                               k_out=handle.view.k, v_out=handle.view.v, kv_head_stride=self.hd, ld_kv=self.hk * self.hd,
+                               row0=row0, split=split, row1=row1, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
+                               xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
+            for i in range(meta_args.denoising_range_num):
+                qs, qe, ks, ke = int(cq[i, 0]), int(cq[i, 1]), int(ck[i, 0]), int(ck[i, 1])
+                if ke > handle.kv_len:
+                    raise ValueError(f"k_range[{i}] = [{ks}, {ke}) exceeds the {handle.kv_len} available keys")
+                ops.attention_ld(q_buf[qs:qe], handle.view, ke, attn_cat[qs:qe], self.hq, kv_start=ks, tag="attn_magi")
+        else:
+            self._ulysses(mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p)
+        # ---- cross-attention on the caption tokens (:954-970, :1047-1085); the local tokens attend the whole caption
+        xp = meta_args.cross_attn_params
+        kvx = ops.linear(key_value_states, w["kvx"], None)                                # [y, hk x (k | v)]
+        yt = kvx.shape[0]
+        kx = torch.empty(yt, self.hk, self.hd, dtype=BF16, device=x2.device)
+        vx = torch.empty(yt, self.hk, self.hd, dtype=BF16, device=x2.device)
+        ops.magi_head_prep(kvx, layout=1, q_heads=0, kv_heads=self.hk, eps=eps, layernorm_1p=one_p, k_out=kx, v_out=vx,
+                           kv_head_stride=self.hd, ld_kv=self.hk * self.hd, xn=w["k_layernorm_xattn"])
+        xview = ops.KvCacheView(kx, vx)
+        for (qs, qe), (ks, ke) in _cross_segments(xp):
+            ops.attention_ld(qx_buf[qs:qe], xview, ke, attn_cat[qs:qe, Q:], self.hq, kv_start=ks, tag="attn_magi_x")
+        return attn_cat
+
+    def _ulysses(self, mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p):
+        """cp_ulysses (:1126-1158): local tokens x all heads -> all tokens x this rank's heads, attention, and back.  K and V of
+        the local tokens are produced straight into the (K | V)-fused staging layout `all_to_all_input_split` sends."""
+        w = self.w
+        s_len = mixed.shape[0]
+        sizes = [int(v) for v in meta_args.cp_split_sizes]
+        kv_stage = torch.empty(s_len, self.hk, 2 * self.hd, dtype=BF16, device=mixed.device)
+        ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
+                           k_out=kv_stage, v_out=kv_stage.view(-1)[self.hd:], kv_head_stride=2 * self.hd,
+                           ld_kv=self.hk * 2 * self.hd, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
+                           xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
+        cq = meta_args.core_attn_params.np_q_range
+        ck = meta_args.core_attn_params.np_k_range
+
+        def core(qc, key, value):
+            out = torch.empty_like(qc)
+            hq_c = qc.shape[1]
+            for i in range(meta_args.denoising_range_num):
+                qs, qe, ks, ke = int(cq[i, 0]), int(cq[i, 1]), int(ck[i, 0]), int(ck[i, 1])
+                ops.attention(qc[qs:qe], key.view, ke, out=out[qs:qe], kv_start=ks, tag="attn_magi")
+            return out
+        Q = self.hq * self.hd
+        core_out, _ = cpl.UlyssesScheduler.get_attn_and_xattn_with_fused_kv_comm(
+            lambda: q_buf.view(s_len, self.hq, self.hd), lambda: kv_stage,
+            lambda kv: (self.kv_cache_manager.adjust_key_and_value_for_inference(kv, inference_params, meta_args),) * 2,
+            core, lambda: None, getattr(self.engine_config, "ulysses_overlap_degree", 1), 1, cp, sizes)
+        attn_cat[:, :Q].copy_(core_out.view(s_len, Q))
+
+
+def _cross_segments(xp):
+    """(query range, key range) pairs of the packed cross-attention: the per-rank `q_ranges` / `kv_ranges` when context
+    parallelism has clipped them (context_parallel.py:135-216), otherwise consecutive `cu_seqlens` segments."""
+    if xp.q_ranges is not None:
+        return list(zip(xp.q_ranges.tolist(), xp.kv_ranges.tolist()))
+    cq, ck = xp.cu_seqlens_q.tolist(), xp.cu_seqlens_kv.tolist()
+    return [((cq[i], cq[i + 1]), (ck[i], ck[i + 1])) for i in range(len(cq) - 1)]
+
+
+class HipMagiTransformerLayer:
+    def __init__(self, model_config, engine_config, layer_number: int = 1, device="cuda"):
+        self.model_config, self.engine_config, self.layer_number = model_config, engine_config, layer_number
+        self.device = torch.device(device)
+        if _cfg(model_config, "gated_linear_unit", False):
+            raise NotImplementedError("gated_linear_unit (flashinfer silu_and_mul) is not used by MAGI-4.5B and not built")
+        self.self_attention = HipFullyParallelAttention(model_config, engine_config, layer_number, device)
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def load_state_dict(self, W: Dict[str, torch.Tensor], prefix: str = "") -> None:
+        dev = self.device
+        g = lambda k: W[prefix + k].to(dev)
+        self.self_attention.load(W, prefix + "self_attention.")
+        self.w["ada_w"], self.w["ada_b"] = g("ada_modulate_layer.proj.0.weight").to(BF16).contiguous(), g("ada_modulate_layer.proj.0.bias").to(BF16)
+        for nm in ("self_attn_post_norm", "mlp_post_norm"):
+            self.w[nm] = (g(nm + ".weight").float().contiguous(), g(nm + ".bias").float().contiguous())
+        self.w["mlp_ln"] = (g("mlp.layer_norm.weight").to(BF16), g("mlp.layer_norm.bias").to(BF16))
+        self.w["fc1"], self.w["fc2"] = g("mlp.linear_fc1.weight").to(BF16).contiguous(), g("mlp.linear_fc2.weight").to(BF16).contiguous()
+
+    def gate(self, condition: torch.Tensor) -> torch.Tensor:
+        """softcap(AdaModulateLayer(condition)) `[b * ranges, 2h]` (:196-198, :1300-1303)."""
+        c2 = condition.reshape(-1, condition.shape[-1]).contiguous()
+        g = ops.linear(ops.act_rows(c2, _hip.IFX_ACT_SILU), self.w["ada_w"], self.w["ada_b"])
+        return ops.act_rows(g, _hip.IFX_ACT_TANH)
+
+    def forward(self, hidden_states: torch.Tensor, condition: torch.Tensor, condition_map: torch.Tensor,
+                y_xattn_flat: torch.Tensor, rotary_pos_emb: torch.Tensor, inference_params: Optional[InferenceParams],
+                meta_args: ModelMetaArgs) -> torch.Tensor:
+        mc, w = self.model_config, self.w
+        s_len, bsz, h = hidden_states.shape
+        eps, one_p = mc.layernorm_epsilon, bool(mc.apply_layernorm_1p)
+        x2 = hidden_states.reshape(s_len * bsz, h)
+        cmap = condition_map.reshape(-1)
+        if cmap.dtype != torch.int32:
+            cmap = cmap.to(torch.int32)
+        attn_cat = self.self_attention.forward(hidden_states, y_xattn_flat, inference_params, rotary_pos_emb, meta_args)
+        proj = ops.linear(attn_cat, self.self_attention.w["proj"], None)
+        gate = self.gate(condition)
+        hs = ops.magi_gate_norm_residual(proj, x2, cmap, gate[:, :h], *w["self_attn_post_norm"], eps, one_p)
+        m = ops.layernorm(hs, eps, gamma=w["mlp_ln"][0], beta=w["mlp_ln"][1])
+        m = ops.linear(m, w["fc1"], None, epilogue=_hip.IFX_EPI_GELU_ERF)
+        m = ops.linear(m, w["fc2"], None)
+        out = ops.magi_gate_norm_residual(m, hs, cmap, gate[:, h:], *w["mlp_post_norm"], eps, one_p)
+        return out.view(s_len, bsz, h)
+
+    __call__ = forward
+
+
+class HipMagiTransformerBlock:
+    """`TransformerBlock` (:1322-1390): the layer stack of one pipeline stage.  The final LayerNorm runs on `.float()` hidden
+    states upstream (fp32 module, dit_model.py:635-636) and feeds the fp32 `final_linear`; it is applied by the caller."""
+
+    def __init__(self, model_config, engine_config, device="cuda", num_layers: Optional[int] = None):
+        n = model_config.num_layers if num_layers is None else num_layers
+        self.layers: List[HipMagiTransformerLayer] = [HipMagiTransformerLayer(model_config, engine_config, i, device) for i in range(n)]
+
+    def load_state_dict(self, W: Dict[str, torch.Tensor], prefix: str = "layers.") -> None:
+        for i, layer in enumerate(self.layers):
+            layer.load_state_dict(W, f"{prefix}{i}.")
+
+    def forward(self, hidden_states, condition, condition_map, y_xattn_flat, rotary_pos_emb, inference_params, meta_args):
+        for layer in self.layers:
+            hidden_states = layer(hidden_states, condition, condition_map, y_xattn_flat, rotary_pos_emb, inference_params, meta_args)
+        return hidden_states
+
+    __call__ = forward

@@ -24,6 +24,8 @@ from . import _hip
 class QConfig:
     fmt: int
     name: str
+    act: str = "per_token"          # dynamic activation scale: one per token row | "per_tensor": one for the whole tensor
+    weight: str = "per_channel"     # weight scale: one per output channel | "per_tensor"
 
     @property
     def qmax(self) -> float:
@@ -38,11 +40,61 @@ def get_dynamic_int8_per_token_act_per_channel_weight_qconfig() -> QConfig:
     return QConfig(_hip.IFX_Q_INT8, "dynamic_int8_per_token_act_per_channel_weight")
 
 
+def get_dynamic_fp8_per_tensor_act_per_tensor_weight_qconfig() -> QConfig:
+    return QConfig(_hip.IFX_Q_FP8_E4M3, "dynamic_fp8_e4m3_per_tensor_act_per_tensor_weight", "per_tensor", "per_tensor")
+
+
+def get_dynamic_int8_per_tensor_act_per_tensor_weight_qconfig() -> QConfig:
+    return QConfig(_hip.IFX_Q_INT8, "dynamic_int8_per_tensor_act_per_tensor_weight", "per_tensor", "per_tensor")
+
+
+def get_dynamic_fp8_per_tensor_act_per_channel_weight_qconfig() -> QConfig:
+    return QConfig(_hip.IFX_Q_FP8_E4M3, "dynamic_fp8_e4m3_per_tensor_act_per_channel_weight", "per_tensor", "per_channel")
+
+
+def get_dynamic_int8_per_tensor_act_per_channel_weight_qconfig() -> QConfig:
+    return QConfig(_hip.IFX_Q_INT8, "dynamic_int8_per_tensor_act_per_channel_weight", "per_tensor", "per_channel")
+
+
+def quantize_activation(x: torch.Tensor, qc: QConfig) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Activation bytes + the per-row scale vector `ifx_gemm_q8` takes (a per-tensor scale is that scalar repeated)."""
+    from . import hip_ops as ops
+    return ops.quant_per_tensor(x, qc.fmt) if qc.act == "per_tensor" else ops.quant_per_token(x, qc.fmt)
+
+
+class StaticFp8Linear:
+    """MAGI's static-scale FP8 linears on `ifx_quant_static` + `ifx_gemm_q8` (fp8 MFMA):
+      PerTensorQuantizedFp8Linear  (inferix/models/magi/dit/dit_module.py:434-462): divisor = input_scale `[in_features]`
+      PerChannelQuantizedFp8Linear (:465-490):                                        divisor = smooth_scale `[1, in_features]`
+    y = bf16( (div_clamp_to(x, divisor) @ W_fp8^T) * input_scale * weight_scale ).  `weight` holds e4m3 bytes `[out, in]`
+    (the checkpoint's `(1, out, in)` float8 tensor viewed as uint8)."""
+
+    def __init__(self, weight: torch.Tensor, weight_scale: torch.Tensor, input_scale: torch.Tensor, divisor: torch.Tensor):
+        w = weight.view(torch.uint8) if weight.dtype != torch.uint8 else weight
+        self.weight = w.reshape(-1, w.shape[-1]).contiguous()
+        self.out_features, self.in_features = self.weight.shape
+        dev = self.weight.device
+        self.w_scale = weight_scale.reshape(-1)[:1].float().to(dev).expand(self.out_features).contiguous()
+        self.in_scale = input_scale.reshape(-1)[:1].float().to(dev).contiguous()
+        self.divisor = divisor.reshape(-1).float().to(dev).contiguous()
+        assert self.divisor.numel() in (1, self.in_features)
+
+    def __call__(self, x: torch.Tensor, **epilogue) -> torch.Tensor:
+        from . import hip_ops as ops
+        x2 = x.reshape(-1, self.in_features)
+        q = ops.quant_static(x2, self.divisor, _hip.IFX_Q_FP8_E4M3, via_bf16=True)
+        sx = self.in_scale.expand(x2.shape[0]).contiguous()
+        y = ops.linear_q8(q, sx, self.weight, self.w_scale, None, _hip.IFX_Q_FP8_E4M3, **epilogue)
+        return y.view(*x.shape[:-1], self.out_features)
+
+
 def quantize_weight(w: torch.Tensor, qc: QConfig) -> Tuple[torch.Tensor, torch.Tensor]:
     """[N, K] bf16 -> (bytes [N, K] uint8, scale [N] fp32): per OUTPUT channel abs-max / QMAX.  The rows of an
     nn.Linear weight are its output channels, so this is the activation quantiser (`ifx_quant_per_token`) run once
     on the weight matrix: one rule, one kernel, bit-identical to the oracle on both operands."""
     from . import hip_ops as ops
+    if qc.weight == "per_tensor":
+        return ops.quant_per_tensor(w.contiguous(), qc.fmt)          # the tensor's scale repeated per output channel
     return ops.quant_per_token(w.contiguous(), qc.fmt)
 
 
@@ -84,6 +136,7 @@ def quantize_dynamic(module, qconfig_dict: Dict[str, Optional[QConfig]]):
                 continue
             blk.w[key + "_q"], blk.w[key + "_s"] = quantize_weight(w, qc)
             blk.w[key + "_fmt"] = qc.fmt
+            blk.w[key + "_act"] = qc.act
             n += 1
     model.quantized_linears = n
     return module

@@ -264,7 +264,10 @@ class HipCausalWanModel(torch.nn.Module):
         if key + "_q" in w:
             fmt = w[key + "_fmt"]
             xq, xs = self._q8_scratch(x.shape[0], x.shape[1], x.device)
-            ops.quant_per_token(x, fmt, q=xq, scale=xs)
+            if w.get(key + "_act") == "per_tensor":
+                ops.quant_per_tensor(x, fmt, q=xq, scale=xs)
+            else:
+                ops.quant_per_token(x, fmt, q=xq, scale=xs)
             return ops.linear_q8(xq, xs, w[key + "_q"], w[key + "_s"], w[key + "_b"], fmt, **kw)
         return ops.linear(x, w[key + "_w"], w[key + "_b"], **kw)
 
@@ -274,7 +277,11 @@ class HipCausalWanModel(torch.nn.Module):
         if key + "_q" in w:
             fmt = w[key + "_fmt"]
             xq, xs = self._q8_scratch(x.shape[0], x.shape[1], x.device)
-            ops.layernorm_quant(x, self.eps, fmt, q=xq, scale=xs, **norm_kw)
+            if w.get(key + "_act") == "per_tensor":          # a tensor-wide scale needs the whole norm output first
+                ops.layernorm(x, self.eps, out=h, **norm_kw)
+                ops.quant_per_tensor(h, fmt, q=xq, scale=xs)
+            else:
+                ops.layernorm_quant(x, self.eps, fmt, q=xq, scale=xs, **norm_kw)
             return ops.linear_q8(xq, xs, w[key + "_q"], w[key + "_s"], w[key + "_b"], fmt, **kw)
         ops.layernorm(x, self.eps, out=h, **norm_kw)
         return ops.linear(h, w[key + "_w"], w[key + "_b"], **kw)

@@ -1,0 +1,291 @@
+"""GPU parity tests of the MAGI transformer layer (BASELINE config 5) on the HIP path against the reference-generated
+goldens tests/golden/magi_block_{tiny,real}.npz (the reference's own TransformerLayer run on CPU by
+oracle/gen_golden_magi_block.py) and against oracle/magi_block_oracle.py, plus the kernels underneath it."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import magi_block_oracle as MB
+from fixture_io import golden
+from util import assert_bf16_parity, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _configs(cfg: MB.MagiLayerConfig, n_layers: int, cp_strategy="none"):
+    mc = SimpleNamespace(num_layers=max(n_layers, 3), hidden_size=cfg.hidden_size, ffn_hidden_size=cfg.ffn_hidden_size,
+                         num_attention_heads=cfg.num_attention_heads, num_query_groups=cfg.num_query_groups,
+                         kv_channels=cfg.kv_channels, layernorm_epsilon=cfg.layernorm_epsilon,
+                         apply_layernorm_1p=cfg.apply_layernorm_1p, gated_linear_unit=cfg.gated_linear_unit,
+                         params_dtype=BF)
+    ec = SimpleNamespace(cp_size=1, cp_strategy=cp_strategy, fp8_quant=False, kv_offload=False, ulysses_overlap_degree=1)
+    return mc, ec
+
+
+def _meta(m: MB.LayerMeta):
+    from inferix_amd.magi.types import ModelMetaArgs, PackedCoreAttnParams, PackedCrossAttnParams
+    qr, kr = torch.tensor(m.q_ranges, dtype=torch.int32), torch.tensor(m.k_ranges, dtype=torch.int32)
+    core = PackedCoreAttnParams(q_range=qr, k_range=kr, np_q_range=qr.numpy(), np_k_range=kr.numpy(),
+                                max_seqlen_q=m.clip_token_nums, max_seqlen_k=int(kr[:, 1].max()))
+    cross = PackedCrossAttnParams(cu_seqlens_q=torch.tensor(m.cu_seqlens_q, dtype=torch.int32),
+                                  cu_seqlens_kv=torch.tensor(m.cu_seqlens_kv, dtype=torch.int32),
+                                  max_seqlen_q=m.clip_token_nums, max_seqlen_kv=int(np.diff(m.cu_seqlens_kv).max()))
+    return ModelMetaArgs(H=1, W=1, cp_pad_size=0, cp_split_sizes=None, slice_point=m.slice_point,
+                         denoising_range_num=len(m.q_ranges), range_num=len(m.q_ranges) + m.slice_point,
+                         extract_prefix_video_feature=False, fwd_extra_1st_chunk=m.use_cache and m.slice_point == 0,
+                         distill_nearly_clean_chunk=m.distill_nearly_clean_chunk, clip_token_nums=m.clip_token_nums,
+                         enable_cuda_graph=False, core_attn_params=core, cross_attn_params=cross)
+
+
+@pytest.mark.parametrize("name", ["magi_block_tiny", "magi_block_real"])
+def test_layer_stack_vs_reference_golden(name):
+    """Every forward of the fixture through HipMagiTransformerLayer: outputs against the reference's, with the distance of
+    BOTH from the float64 evaluation of the same layer printed (the bf16 floor: the reference's own rounding noise), and the
+    stored cache rows against the reference's cache."""
+    from inferix_amd.magi.dit import HipMagiTransformerLayer
+    from inferix_amd.magi.types import InferenceParams
+    fx = golden(name + ".npz")
+    cfg, n_layers, clip, n_calls, wseed, max_tokens = MB.fixture_geometry(fx)
+    mc, ec = _configs(cfg, n_layers)
+    Ws = [MB.init_layer_weights(cfg, wseed + li) for li in range(n_layers)]
+    layers = []
+    for li in range(n_layers):
+        layer = HipMagiTransformerLayer(mc, ec, li, "cuda")
+        layer.load_state_dict(Ws[li])
+        layers.append(layer)
+    ip = InferenceParams(1, max_tokens)
+    orc_caches = [MB.MagiLayerCache(max_tokens, cfg.num_query_groups, cfg.kv_channels) for _ in range(n_layers)]
+    for ci in range(n_calls):
+        inp, m = MB.fixture_call(fx, ci)
+        meta = _meta(m)
+        ip.update_kv_cache = m.update_kv_cache
+        x = inp["x"].cuda()
+        x_ref = inp["x"]
+        for li, layer in enumerate(layers):
+            # yardstick: the float64 layer on the REFERENCE's input of this layer, with the reference's cache prefix
+            exact = MB.exact_layer_forward(Ws[li], cfg, x_ref, inp["condition"], inp["condition_map"], inp["y"], inp["rope"], m,
+                                           orc_caches[li])
+            ref = fx[f"c{ci}_out_l{li}"]
+            x_in_hip = x
+            x = layer(x, inp["condition"].cuda(), inp["condition_map"].cuda(), inp["y"].cuda(), inp["rope"].cuda(), ip, meta)
+            if li == 0:                       # identical inputs on both sides: the per-layer bar
+                floor = rel_l2(ref, exact)
+                d_hip_exact, d_hip_ref = rel_l2(x.cpu(), exact), rel_l2(x.cpu(), ref)
+                print(f"{name} call {ci} layer 0: ref-vs-exact {floor:.3e}  hip-vs-exact {d_hip_exact:.3e}  hip-vs-ref {d_hip_ref:.3e}")
+                assert d_hip_exact <= 1.25 * floor + 5e-4, (ci, d_hip_exact, floor)
+                assert_bf16_parity(x, ref, max_ulp=4, max_mismatch_frac=0.6, rel=2.0 * floor + 5e-4, floor=1.0,
+                                   what=f"{name} call {ci} layer 0")
+            else:                             # chained layers: inputs already differ by the floor
+                assert rel_l2(x.cpu(), ref) < 1e-2, (ci, li)
+            # advance the oracle's cache with the reference's own stream so the yardstick prefix stays the reference's
+            MB.layer_forward(Ws[li], cfg, x_ref, inp["condition"], inp["condition_map"], inp["y"], inp["rope"], m, orc_caches[li])
+            x_ref = ref
+            del x_in_hip
+    written = int(fx["cache_written"])
+    for li in range(n_layers):
+        raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, f"layer_{li}")
+        if li == 0:
+            assert_bf16_parity(raw[0, :written, 0], fx[f"cache_l{li}"][0, :written, 0], max_ulp=1, floor=1.0, max_mismatch_frac=0.05,
+                               what="cache K (LayerNorm + rotary)")
+            assert_bf16_parity(raw[1, :written, 0], fx[f"cache_l{li}"][1, :written, 0], max_ulp=1, floor=0.05, what="cache V")
+        else:
+            assert rel_l2(raw[:, :written].cpu(), fx[f"cache_l{li}"][:, :written]) < 1e-2
+
+
+def test_head_prep_vs_oracle():
+    """ifx_magi_head_prep on identical inputs (the fused projection output): q / k against fp32 LayerNorm + rotary, qx / kx
+    against the bf16 LayerNorm, v bit-exact, with the split destination (stored rows | scratch tail)."""
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    cfg = MB.MagiLayerConfig()
+    hq, hk, hd, rows = cfg.num_attention_heads, cfg.num_query_groups, 128, 333
+    mixed = (torch.randn(rows, (2 * hq + 2 * hk) * hd, generator=g) * 1.5).to(BF)
+    r = torch.rand(rows, 64, generator=g) * 6.0
+    rope = torch.cat([torch.sin(r), torch.cos(r)], dim=-1)
+    qn = (0.1 * torch.randn(hd, generator=g), 0.1 * torch.randn(hd, generator=g))
+    kn = (0.1 * torch.randn(hd, generator=g), 0.1 * torch.randn(hd, generator=g))
+    xn = ((0.1 * torch.randn(hd, generator=g)).to(BF), (0.1 * torch.randn(hd, generator=g)).to(BF))
+    cap, split = 400, 200
+    kc = torch.zeros(cap + rows, hk, hd, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    q_out = torch.empty(rows, hq * hd, dtype=BF, device="cuda")
+    qx_out = torch.empty_like(q_out)
+    ops.magi_head_prep(mixed.cuda(), layout=0, q_heads=hq, kv_heads=hk, eps=1e-6, layernorm_1p=True, k_out=kc, v_out=vc,
+                       kv_head_stride=hd, ld_kv=hk * hd, row0=100, split=split, row1=cap, rope=rope.cuda(),
+                       qn=[t.cuda() for t in qn], kn=[t.cuda() for t in kn], xn=[t.cuda() for t in xn], q_out=q_out, qx_out=qx_out)
+    Q, KV = hq * hd, hk * hd
+    sin, cos = rope[:, :64], rope[:, 64:]
+
+    def ref_qk(t, n):
+        t = MB.fused_layer_norm(t.reshape(rows, 1, -1, hd).float(), n[0], n[1], cfg)
+        return MB.apply_rotary(t.transpose(0, 1).contiguous(), cos, sin).to(BF)[0]
+    q_ref = ref_qk(mixed[:, :Q], qn)
+    k_ref = ref_qk(mixed[:, 2 * Q:2 * Q + KV], kn)
+    qx_ref = MB.fused_layer_norm(mixed[:, Q:2 * Q].reshape(rows, hq, hd), xn[0], xn[1], cfg)
+    v_ref = mixed[:, 2 * Q + KV:].reshape(rows, hk, hd)
+    assert_bf16_parity(q_out.view(rows, hq, hd), q_ref, max_ulp=1, floor=1.0, what="q (LayerNorm + rotary)")
+    assert_bf16_parity(qx_out.view(rows, hq, hd), qx_ref, max_ulp=1, floor=0.05, what="qx (bf16 LayerNorm)")
+    k_got = torch.cat([kc[100:100 + split], kc[cap:cap + rows - split]])
+    v_got = torch.cat([vc[100:100 + split], vc[cap:cap + rows - split]])
+    assert_bf16_parity(k_got, k_ref, max_ulp=1, floor=1.0, what="k (LayerNorm + rotary)")
+    assert torch.equal(v_got.cpu(), v_ref), "v is a copy"
+    assert int(kc[:100].abs().sum()) == 0 and int(kc[100 + split:cap].abs().sum()) == 0, "rows outside the destination touched"
+    # layout 1: the caption keys / values
+    yt = 77
+    kvx = torch.randn(yt, 2 * KV, generator=g).to(BF)
+    kx = torch.empty(yt, hk, hd, dtype=BF, device="cuda")
+    vx = torch.empty_like(kx)
+    ops.magi_head_prep(kvx.cuda(), layout=1, q_heads=0, kv_heads=hk, eps=1e-6, layernorm_1p=True, k_out=kx, v_out=vx,
+                       kv_head_stride=hd, ld_kv=hk * hd, xn=[t.cuda() for t in xn])
+    kv3 = kvx.view(yt, hk, 2 * hd)
+    assert_bf16_parity(kx, MB.fused_layer_norm(kv3[..., :hd], xn[0], xn[1], cfg), max_ulp=1, floor=0.05, what="kx")
+    assert torch.equal(vx.cpu(), kv3[..., hd:].contiguous())
+
+
+@pytest.mark.parametrize("rows,dim", [(96, 3072), (333, 256), (4050, 3072)])
+def test_gate_norm_residual_vs_oracle(rows, dim):
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(rows + dim)
+    x = torch.randn(rows, dim, generator=g).to(BF)
+    res = torch.randn(rows, dim, generator=g).to(BF)
+    gate = torch.tanh(torch.randn(3, 2 * dim, generator=g)).to(BF)
+    cmap = (torch.arange(rows) * 3 // rows).to(torch.int32)
+    w, b = 0.1 * torch.randn(dim, generator=g), 0.1 * torch.randn(dim, generator=g)
+    for half in (0, 1):
+        gv = gate[:, half * dim:(half + 1) * dim]
+        t = x.float() * gv.float()[cmap.long()]
+        ref = (torch.nn.functional.layer_norm(t, (dim,), w + 1, b, 1e-6) + res.float()).to(BF)
+        got = ops.magi_gate_norm_residual(x.cuda(), res.cuda(), cmap.cuda(), gate.cuda()[:, half * dim:(half + 1) * dim],
+                                          w.cuda(), b.cuda(), 1e-6, True)
+        assert_bf16_parity(got, ref, max_ulp=1, floor=1.0, what=f"bias_modulate_add half {half}")
+
+
+def test_gate_path_and_gelu_erf_epilogue():
+    """SiLU -> linear -> softcap (AdaModulateLayer + softcap) and the exact-GELU GEMM epilogue against torch on the same inputs."""
+    from inferix_amd import _hip
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(5, 768, generator=g) * 2).to(BF)
+    assert_bf16_parity(ops.act_rows(x.cuda(), _hip.IFX_ACT_SILU), torch.nn.functional.silu(x), max_ulp=1, what="silu")
+    assert_bf16_parity(ops.act_rows(x.cuda(), _hip.IFX_ACT_TANH), torch.tanh(x.float()).to(BF), max_ulp=1, what="softcap")
+    for M, N, K in ((96, 12288, 3072), (300, 512, 256), (4050, 12288, 3072)):
+        a = torch.randn(M, K, generator=g).to(BF).cuda()
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).cuda()
+        got = ops.linear(a, w, None, epilogue=_hip.IFX_EPI_GELU_ERF)
+        pre = (a.double() @ w.double().t()).to(BF)                     # exact product, one bf16 rounding (the fc1 output)
+        ref = torch.nn.functional.gelu(pre.float()).to(BF)
+        assert_bf16_parity(got, ref, max_ulp=2, floor=1.0, max_mismatch_frac=0.05, what=f"fc1 + exact GELU {M}x{N}x{K}")
+        plain = ops.linear(a, w, None)
+        assert_bf16_parity(got, torch.nn.functional.gelu(plain.float()).to(BF), max_ulp=1, max_mismatch_frac=0.01,
+                           what="epilogue == gelu(bf16 GEMM output)")
+
+
+def test_strided_attention_matches_dense():
+    """ifx_attn_fwd_paged_ld: query rows taken from, and output rows written into, column blocks of wider matrices — bit-identical
+    to the dense launch; neighbouring columns untouched.  Shapes of one MAGI rank and of a single-GPU layer."""
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    for rows, hq, hk, nk, start in ((300, 24, 8, 700, 0), (2025, 3, 1, 4000, 128), (96, 24, 8, 65, 40)):
+        q = torch.randn(rows, hq, 128, generator=g).to(BF).cuda()
+        k = torch.randn(nk, hk, 128, generator=g).to(BF).cuda()
+        v = torch.randn(nk, hk, 128, generator=g).to(BF).cuda()
+        view = ops.KvCacheView(k, v)
+        dense = ops.attention(q, view, nk, kv_start=start)
+        wide_q = torch.zeros(rows, 2 * hq * 128 + 64, dtype=BF, device="cuda")
+        wide_q[:, 64:64 + hq * 128] = q.view(rows, -1)
+        wide_o = torch.full((rows, 2 * hq * 128), 7.0, dtype=BF, device="cuda")
+        ops.attention_ld(wide_q[:, 64:], view, nk, wide_o[:, hq * 128:], hq, kv_start=start)
+        assert torch.equal(wide_o[:, hq * 128:].reshape(rows, hq, 128), dense)
+        assert bool((wide_o[:, :hq * 128] == 7.0).all())
+
+
+def test_static_and_per_tensor_quantisers_vs_reference_golden():
+    """ifx_quant_static with the bf16 intermediate == the reference's div_clamp_to bytes (tests/golden/quant_fp8.npz, generated by
+    importing inferix/models/magi/dit/dit_module.py); the static-scale FP8 linears on ifx_gemm_q8 against the reference modules'
+    outputs; the dynamic per-tensor quantiser against its definition."""
+    from inferix_amd import _hip
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.quant import StaticFp8Linear
+    fx = golden("quant_fp8.npz")
+    x = fx["x"].cuda()
+    K = x.shape[1]
+    for name in ("vec", "one"):
+        q = ops.quant_static(x, fx[f"div_{name}"].cuda(), _hip.IFX_Q_FP8_E4M3, via_bf16=True)
+        assert torch.equal(q.cpu(), fx[f"q_{name}"]), f"div_clamp_to bytes ({name}) differ from the reference's"
+    direct = ops.quant_static(x, fx["div_vec"].cuda(), _hip.IFX_Q_FP8_E4M3, via_bf16=False)
+    assert int((direct.cpu() != fx["q_vec"]).sum()) == int(fx["double_rounding_diffs"]), "single-rounding variant is the direct cast"
+    wq, ws, ins = fx["wq"].cuda(), fx["w_scale"].cuda(), fx["in_scale"].cuda()
+    xin = x.view(4, 24, K)
+    pt = StaticFp8Linear(wq, ws, ins, divisor=ins.expand(K).contiguous())
+    pc = StaticFp8Linear(wq, ws, ins, divisor=fx["div_vec"].cuda())
+    # the fp8 products are exact in fp32 up to summation order; one bf16 rounding at the end
+    assert_bf16_parity(pt(xin), fx["y_per_tensor"], max_ulp=1, max_mismatch_frac=0.01, what="PerTensorQuantizedFp8Linear")
+    assert_bf16_parity(pc(xin), fx["y_per_channel"], max_ulp=1, max_mismatch_frac=0.01, what="PerChannelQuantizedFp8Linear")
+    # dynamic per-tensor (the qconfig family next to per-token): s = amax / QMAX over the whole tensor
+    for fmt, qmax in ((_hip.IFX_Q_FP8_E4M3, 448.0), (_hip.IFX_Q_INT8, 127.0)):
+        q, s = ops.quant_per_tensor(x, fmt)
+        s_ref = x.float().abs().max() / qmax
+        assert torch.equal(s.cpu(), s_ref.cpu().expand(x.shape[0])), "per-tensor scale"
+        vals = (x.float() / s_ref).clamp(-qmax, qmax).cpu()
+        ref = vals.to(torch.float8_e4m3fn).view(torch.uint8) if fmt == _hip.IFX_Q_FP8_E4M3 else torch.round(vals).to(torch.int8).view(torch.uint8)
+        assert torch.equal(q.cpu(), ref)
+    z = torch.zeros(8, 256, dtype=BF, device="cuda")
+    q, s = ops.quant_per_tensor(z, _hip.IFX_Q_INT8)
+    assert float(s[0]) == 1.0 and int(q.sum()) == 0
+
+
+def test_full_size_chunk_properties():
+    """MAGI-4.5B at its workload size — one 720x720 chunk = 12150 tokens, 24 q-heads on 8 kv-groups, 2 denoising ranges, a
+    prefix of one stored chunk — where the CPU oracle is out of reach: size-independent properties of the layer.
+      * determinism: two runs, bit-identical;
+      * range independence: the first range's output rows do not change when the second range's inputs do;
+      * cache idempotence: re-running the storing forward leaves the cache bit-identical;
+      * one rank's view (3 q-heads on 1 kv-head over all tokens, the cp = 8 split) of the core attention equals the
+        corresponding head slice of the full launch."""
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.magi.dit import HipMagiTransformerLayer
+    from inferix_amd.magi.types import InferenceParams
+    cfg = MB.MagiLayerConfig()
+    mc, ec = _configs(cfg, 1)
+    W = MB.init_layer_weights(cfg, 77)
+    layer = HipMagiTransformerLayer(mc, ec, 0, "cuda")
+    layer.load_state_dict(W)
+    clip = 12150
+    g = torch.Generator().manual_seed(1)
+    s = 2 * clip
+    x = torch.randn(s, 1, cfg.hidden_size, generator=g).to(BF).cuda()
+    cond = torch.randn(1, 2, cfg.cond_size, generator=g).to(BF).cuda()
+    cmap = (torch.arange(s, dtype=torch.int32) // clip).reshape(s, 1).cuda()
+    y = torch.randn(2 * 200, cfg.xattn_size, generator=g).to(BF).cuda()
+    r = torch.rand(s, 64, generator=g) * 6.0
+    rope = torch.cat([torch.sin(r), torch.cos(r)], -1).cuda()
+    m = MB.LayerMeta(q_ranges=[(0, clip), (clip, 2 * clip)], k_ranges=[(0, clip), (0, 2 * clip)], cu_seqlens_q=[0, clip, 2 * clip],
+                     cu_seqlens_kv=[0, 200, 400], clip_token_nums=clip, slice_point=0, update_kv_cache=True, use_cache=True)
+    meta = _meta(m)
+    ip = InferenceParams(1, 4 * clip)
+    ip.update_kv_cache = True
+    out1 = layer(x, cond, cmap, y, rope, ip, meta)
+    cache1 = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0").clone()
+    out2 = layer(x, cond, cmap, y, rope, ip, meta)
+    assert torch.equal(out1, out2), "run-to-run determinism"
+    assert torch.equal(cache1[:, :s], ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0")[:, :s]), "cache idempotence"
+    assert torch.isfinite(out1.float()).all()
+    x2 = x.clone()
+    x2[clip:] = torch.randn(clip, 1, cfg.hidden_size, generator=g).to(BF).cuda()
+    out3 = layer(x2, cond, cmap, y, rope, ip, meta)
+    assert torch.equal(out3[:clip], out1[:clip]), "range 0 must not see range 1"
+    assert not torch.equal(out3[clip:], out1[clip:])
+    # one rank of cp = 8: query heads 3r..3r+2 read kv head r
+    raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0")
+    k_all, v_all = raw[0, :s, 0], raw[1, :s, 0]
+    q = torch.randn(clip, 24, 128, generator=g).to(BF).cuda()
+    full = ops.attention(q, ops.KvCacheView(k_all.contiguous(), v_all.contiguous()), s)
+    for rank in (0, 5):
+        part = ops.attention(q[:, 3 * rank:3 * rank + 3].contiguous(),
+                             ops.KvCacheView(k_all[:, rank:rank + 1].contiguous(), v_all[:, rank:rank + 1].contiguous()), s)
+        assert rel_l2(part, full[:, 3 * rank:3 * rank + 3]) < 2e-3
+        assert_bf16_parity(part, full[:, 3 * rank:3 * rank + 3], max_ulp=2, max_mismatch_frac=0.3, rel=2e-3, what="rank view")

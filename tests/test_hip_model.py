@@ -298,3 +298,53 @@ def test_wan_14b_channel_geometry_vs_oracle():
     ref, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=5.0, num_frame_per_block=3)
     r = rel_l2(out.cpu(), ref)
     assert torch.isfinite(out.float()).all() and r < 1e-2, f"14B geometry: rollout rel-L2 {r:.3e}"
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_block_full_size_vs_reference_golden(case):
+    """One block at the BASELINE size — 4680 tokens, dim 1536, 12 heads, ffn 8960 — over L = 4680 (case 0) and L = 32760 (case 1)
+    cached keys, against rows of the reference's own CausalWanAttentionBlock output (tests/golden/block_full_size.npz, generated
+    by oracle/gen_golden_block_full.py from the reference import; inputs regenerated from seeds).  Yardstick: the fixture's
+    `exact_rows` = the same rows with exact (fp64) self-attention; the reference sits `floor` from them, the HIP block must
+    not sit further than 1.25x that."""
+    import block_full_inputs as BI
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    fx = golden("block_full_size.npz")
+    cfg = BI.config()
+    W = O.init_weights(cfg, seed=3)
+    d = BI.make(case)
+    assert BI.checksum(d["x"]) == int(fx[f"c{case}_x_checksum"]), "seeded inputs drifted from the generator's"
+    start = int(fx[f"c{case}_start"])
+    m = build(cfg, W)
+    fs, nf = cfg.frame_seqlen, BI.FRAMES
+    n = nf * fs
+    kvm, req = KVCacheManager("cuda"), [KVCacheRequest("r")]
+    ad = m.blocks[0].kv_cache_manager
+    ad.allocate_kv_cache(kv_cache_manager=kvm, kv_cache_request=req[0], sequence_length=7 * n, dtype=BF)
+    ad.allocate_crossattn_cache(kv_cache_manager=kvm, kv_cache_request=req[0], crossattn_length=cfg.text_len, dtype=BF)
+    raw = kvm.get_raw(req[0], "layer_0")
+    if start:
+        assert (BI.checksum(d["prefix_k"]) ^ BI.checksum(d["prefix_v"])) == int(fx[f"c{case}_prefix_checksum"])
+        raw[0, :start, 0].copy_(d["prefix_k"])
+        raw[1, :start, 0].copy_(d["prefix_v"])
+    meta = {"global_end_index": torch.tensor([start]), "local_end_index": torch.tensor([start])}
+    cmeta = {"is_init": False}
+    x = d["x"][0].cuda().clone()
+    El = (m.mod_all[0] + d["e0"][0].cuda()).contiguous()
+    rope = ops.RopeGridSpec(m.freqs, start // fs, cfg.latent_h // 2, cfg.latent_w // 2)
+    st = dict(B=1, N=n, F_=nf, fs=fs, rows_per_group=fs, rope=rope, sink_tokens=0, current_start=start, ctx=d["ctx"][0].cuda())
+    m._run_block(0, x, El, st, meta, cmeta, kvm, req)
+    torch.cuda.synchronize()
+    sel = fx["sel"].long()
+    got = x[sel.cuda()].cpu()
+    ref, exact, floor = fx[f"c{case}_out_rows"], fx[f"c{case}_exact_rows"], float(fx[f"c{case}_floor"])
+    d_exact, d_ref = rel_l2(got, exact), rel_l2(got, ref)
+    print(f"full-size block case {case} (L = {start + n}): reference-vs-exact {floor:.3e}, hip-vs-exact {d_exact:.3e}, hip-vs-reference {d_ref:.3e}")
+    assert d_exact <= 1.25 * floor + 5e-4, (d_exact, floor)
+    assert_bf16_parity(got, ref, max_ulp=4, max_mismatch_frac=0.5, rel=1.25 * floor + 5e-4, floor=1.0, what="full-size block rows")
+    assert int(meta["local_end_index"]) == start + n and int(meta["global_end_index"]) == start + n
+    assert_bf16_parity(raw[0, start + sel.cuda(), 0], fx[f"c{case}_k_rows"], max_ulp=1, floor=1.0, what="cache K rows (post-RoPE)")
+    assert_bf16_parity(raw[1, start + sel.cuda(), 0], fx[f"c{case}_v_rows"], max_ulp=1, floor=0.05, what="cache V rows")
+    if start:
+        assert torch.equal(raw[0, :start, 0].cpu(), d["prefix_k"]), "the prefix must not be touched"
