@@ -64,54 +64,31 @@ def build_pipeline(device, parallel_config=None, num_layers=None):
     return model, gen, pipe
 
 
-def cpu_baseline(budget_layers: int = 4):
-    """The CPU oracle (port of the reference's CPU/PyTorch path, parity-pinned to it) on this box's host cores:
-    `budget_layers` real-size layers of one denoise forward at the prefix of block 0, 3 and 6 (L_kv = 4680, 18720,
-    32760; about 10-20 s of CPU work).  The clip = 7 blocks x 5 forwards x 30 layers is then priced with the
-    per-layer time interpolated linearly in the block index between the measured prefixes."""
+def cpu_baseline(layers: int = 30):
+    """BASELINE config 1 on this box's host cores, MEASURED end to end (nothing interpolated): Self-Forcing 480p, block_size 3,
+    ONE denoise step (`denoising_step_list=[1000]`) + the clean-context re-run, one block of 3 latent frames, all 30 layers,
+    NO_DECODE — `O.inference` of the CPU oracle (the port of the reference's CPU / PyTorch path that tests pin to the
+    reference bit for bit).  About 60-90 s of CPU work.  value = 3 latent frames / wall time of the two generator forwards."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wan_oracle as O
-    cfg = O.WanConfig(num_layers=budget_layers)
+    cfg = O.WanConfig(num_layers=layers)
     W = O.init_weights(cfg, seed=0)
     g = torch.Generator().manual_seed(0)
-    fs = cfg.frame_seqlen
-    n = BLOCK * fs
-    nblk = FRAMES // BLOCK
-    x0 = torch.randn(1, n, cfg.dim, generator=g).to(torch.bfloat16)
-    e0 = (torch.randn(1, BLOCK, 6, cfg.dim, generator=g) * 0.5).to(torch.bfloat16)
-    ctx = torch.randn(1, cfg.text_len, cfg.dim, generator=g).to(torch.bfloat16)
-    freqs = O.rope_freqs(cfg.head_dim)
-    state = O.CacheState.allocate(cfg, 1, torch.bfloat16, cache_tokens=nblk * n)
-    for l in state.layers:                      # a filled prefix (values are irrelevant for the timing)
-        l.k.normal_(generator=g)
-        l.v.normal_(generator=g)
-    per_layer = {}
-    total = 0.0
+    noise = torch.randn(1, BLOCK, *LATENT, generator=g).to(torch.bfloat16)
+    pe = torch.zeros(1, cfg.text_len, cfg.text_dim)
+    pe[:, :40] = torch.randn(1, 40, cfg.text_dim, generator=torch.Generator().manual_seed(1))
+    pe = pe.to(torch.bfloat16)
+    t0 = time.perf_counter()
     with torch.no_grad():
-        for b in (0, nblk // 2, nblk - 1):
-            for l in state.layers:
-                l.global_end = l.local_end = b * n
-            x = x0
-            t0 = time.perf_counter()
-            for i in range(budget_layers):
-                x = O.block_forward(x, e0, ctx, W, i, cfg, (BLOCK, 30, 52), freqs, state, b * n)
-            dt = time.perf_counter() - t0
-            total += dt
-            per_layer[b] = dt / budget_layers
-    bs = sorted(per_layer)
-
-    def interp(b):
-        lo = max(v for v in bs if v <= b)
-        hi = min(v for v in bs if v >= b)
-        return per_layer[lo] if lo == hi else per_layer[lo] + (per_layer[hi] - per_layer[lo]) * (b - lo) / (hi - lo)
-    clip_s = sum(interp(b) for b in range(nblk)) * (len(STEPS_LIST) + 1) * 30
-    return {"value": FRAMES / clip_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{budget_layers} of 30 layers of one generator forward at block 0 / {nblk // 2} / {nblk - 1} "
-                      f"(N = 4680 queries, L_kv = 4680 / {(nblk // 2 + 1) * n} / {nblk * n}; real Wan-1.3B dims, bf16 CPU "
-                      f"oracle), {total:.1f} s measured; clip = 7 blocks x 5 forwards x 30 layers, per-layer time "
-                      "interpolated linearly in the block index",
-            "ms_per_layer_forward_by_block": {str(k): round(v * 1e3, 1) for k, v in per_layer.items()},
-            "host_cpus": os.cpu_count()}
+        out, _ = O.inference(W, cfg, noise, list(pe), [1000], shift=5.0, num_frame_per_block=BLOCK)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+    extra = {} if layers == 30 else {"INVALID": f"debug run with {layers} of 30 layers"}
+    return {**extra, "value": BLOCK / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "BASELINE config 1, measured: Self-Forcing 480p, block_size 3, 1 denoise step + clean-context re-run = 2 "
+                      "generator forwards of the 30-layer Wan2.1-1.3B causal DiT over one 3-frame block (N = L_kv = 4680), "
+                      f"NO_DECODE, bf16 CPU oracle (O.inference); {dt:.1f} s wall",
+            "seconds": round(dt, 2), "ms_per_generator_forward": round(dt / 2 * 1e3, 1), "host_cpus": os.cpu_count()}
 
 
 def pmc_traffic(shards):
@@ -217,6 +194,209 @@ def text_encoder_leg():
             "tflops": round(flops / ms / 1e9, 1), "output": list(out.shape)}
 
 
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 / int8 MFMA (MI355X_MICROARCH.md)
+
+
+def config1_gpu(model, gen, device):
+    """The GPU side of BASELINE config 1 (what `cpu_baseline` measures on the host): 1 denoise step + context re-run, one block."""
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausalInferencePipeline
+    args = SimpleNamespace(denoising_step_list=[1000], warp_denoising_step=True, num_frame_per_block=BLOCK,
+                           independent_first_frame=False, context_noise=0, frame_seq_length=1560, kv_cache_tokens=BLOCK * 1560)
+    pe = torch.zeros(1, 512, 4096)
+    pe[:, :40] = torch.randn(1, 40, 4096, generator=torch.Generator().manual_seed(1))
+    pe = pe.to(torch.bfloat16).to(device)
+    pipe1 = CausalInferencePipeline(args, device, generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe}, vae=None)
+    noise = torch.randn(1, BLOCK, *LATENT, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16).to(device)
+    kvm, reqs = KVCacheManager(device), [KVCacheRequest("config1")]
+    run = lambda: pipe1.inference(noise=noise, text_prompts=["synthetic"], kv_cache_manager=kvm, kv_cache_requests=reqs,
+                                  decode_mode=DecodeMode.NO_DECODE, free_cache_before_vae=False)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    kvm.free(reqs[0])
+    return {"workload": "BASELINE config 1 on the GPU: 1 denoise step + context re-run, one 3-frame block, 30 layers, NO_DECODE",
+            "ms": round(ms, 2), "latent_frames_per_s": round(BLOCK / ms * 1e3, 2)}
+
+
+def quant_leg(fmt, gen, clip):
+    """BASELINE config 4: the same clip with every block linear as a dynamic per-token x per-channel 8-bit linear (fp8 e4m3 on
+    the fp8 MFMA / int8).  Two clips (one untimed), measured AFTER the headline region on the same model object; `roofline` is
+    the 8-bit GEMM's (all launches of the timed clip) against the dense 8-bit MFMA peak.  Parity of the scheme: unpinned vs DAX."""
+    from inferix_amd import hip_ops as ops
+    from inferix_amd import quant as Qz
+    qc = (Qz.get_dynamic_fp8_per_token_act_per_channel_weight_qconfig() if fmt == "fp8"
+          else Qz.get_dynamic_int8_per_token_act_per_channel_weight_qconfig())
+    Qz.quantize_dynamic(gen, {"": qc, "text_embedding": None, "proj_out": None, "head": None})
+    try:
+        clip()
+        t = ops.KernelTimer(names=("gemm_q8", "attn_self", "quant_per_token"))
+        ops.set_kernel_timer(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = clip()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        ops.set_kernel_timer(None)
+        assert torch.isfinite(out.float()).all()
+        ks = t.summary()
+        gq, qa = ks["gemm_q8"], ks.get("quant_per_token", dict(ms=0.0, launches=0, bytes=0.0))
+        tf = gq["flops"] / (gq["ms"] * 1e-3) / 1e12
+        return {"workload": f"config 4: Self-Forcing 480p clip, {qc.name} linears + bf16 attention", "clips_run": 2,
+                "ms_per_clip": round(ms, 1), "latent_frames_per_s": round(FRAMES / ms * 1e3, 3),
+                "roofline": {"kernel": f"ifx::gemm_q8_dma_kernel ({fmt} MFMA, per-token x per-channel dequant epilogue)", "bound": "mfma",
+                             "achieved": round(tf, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP8_TFLOPS, 4),
+                             "traffic": None, "launches": gq["launches"], "avg_launch_ms": round(gq["ms"] / gq["launches"], 4)},
+                "quantiser_gbps": round(qa["bytes"] / (qa["ms"] * 1e-3) / 1e9, 1) if qa["ms"] else None,
+                "quantiser_ms_per_clip": round(qa["ms"], 1), "gemm_ms_per_clip": round(gq["ms"], 1),
+                "parity": "bit-exact vs oracle/quant_oracle.py; unpinned vs DAX (absent from the reference tree)"}
+    finally:
+        ops.set_kernel_timer(None)
+        Qz.dequantize(gen)
+
+
+def causvid_720p_leg(model, device):
+    """BASELINE config 3: CausVid 720p bf16 with continuous-prompt KV rollover on the SAME 30-layer model object: latent 90 x 160
+    (3600 tokens / frame, 10800 / block), `denoising_step_list=[1000, 757, 522, 0]` (last entry dropped, no warp), shift 8.0,
+    3 segments of 21 latent frames, each in a NEW KVCacheRequest prefilled with the previous segment's last 3 latents
+    (inferix/pipeline/causvid/pipeline.py:224-309); the pixel-space re-encode of the boundary frame is outside the timing."""
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.kvcache_manager import KVCacheManager
+    from inferix_amd.pipeline import CausVidInferencePipeline
+    from inferix_amd.wan import HipCausVidDiffusionWrapper
+    H, Wd, fs = 90, 160, 3600
+    gen = HipCausVidDiffusionWrapper(model=model, timestep_shift=8.0)
+    args = SimpleNamespace(denoising_step_list=[1000, 757, 522, 0], warp_denoising_step=False, num_frame_per_block=BLOCK,
+                           frame_seq_length=fs, kv_cache_tokens=FRAMES * fs)
+    pes = []
+    for i in range(3):
+        pe = torch.zeros(1, 512, 4096)
+        pe[:, :40] = torch.randn(1, 40, 4096, generator=torch.Generator().manual_seed(10 + i))
+        pes.append(pe.to(torch.bfloat16).to(device))
+    table = {f"prompt {i}": pes[i] for i in range(3)}
+    pipe = CausVidInferencePipeline(args, device=device, generator=gen,
+                                    text_encoder=lambda text_prompts: {"prompt_embeds": table[text_prompts[0]]}, vae=None)
+    g = torch.Generator().manual_seed(2)
+    noises = [torch.randn(1, FRAMES, 16, H, Wd, generator=g).to(torch.bfloat16).to(device) for _ in range(3)]
+    kvm = KVCacheManager(device)
+    pipe.rollover(["prompt 0"], [noises[0][:, :BLOCK]], kvm, overlap_frames=BLOCK)          # warm: one block
+    pipe.is_kv_cache_initialized = False
+    kvm = KVCacheManager(device)
+    t = ops.KernelTimer(names=("attn_self",))
+    ops.set_kernel_timer(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = pipe.rollover(list(table), noises, kvm, overlap_frames=BLOCK)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    ops.set_kernel_timer(None)
+    assert all(torch.isfinite(o.float()).all() for o in outs)
+    ks = t.summary()["attn_self"]
+    tf = ks["flops"] / (ks["ms"] * 1e-3) / 1e12
+    new_frames = FRAMES + 2 * (FRAMES - BLOCK)                # segments 1, 2 regenerate nothing of their 3 prefilled frames
+    fwd = 7 * 4 + 2 * (1 + 6 * 4)
+    del pipe, kvm
+    torch.cuda.empty_cache()
+    return {"workload": "config 3: CausVid 720p (latent 90x160, block 10800 tokens, steps [1000, 757, 522], shift 8.0), 3 segments x 21 "
+                        "latent frames with per-segment request rollover (3 overlap latents prefilled), 30 layers, NO decode",
+            "ms_total": round(ms, 1), "ms_per_segment": round(ms / 3, 1), "generator_forwards": fwd,
+            "new_latent_frames": new_frames, "latent_frames_per_s": round(new_frames / ms * 1e3, 3),
+            "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (self-attention launches, N = 10800, L = 10800 .. 75600)", "bound": "mfma",
+                         "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                         "traffic": None, "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / ks["launches"], 4)}}
+
+
+def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34):
+    """BASELINE config 5, ONE rank of 8 emulated on one GPU (INVALID as a multi-GPU number: the all-to-alls are device copies of
+    the bytes the rank would receive, inferix_amd/magi/context_parallel.py `set_cp_emulation`): MAGI-4.5B transformer stack
+    (34 layers, hidden 3072, 24 q-heads / 8 kv-groups, ffn 12288), 720 x 720 -> 12150 tokens per chunk, window of 4 denoising
+    chunks in flight + 1 clean chunk in the cache (`noise2clean_kvrange = [5, 4, 3, 2]`, example/magi/configs/4.5B), so a forward
+    has 48600 query tokens of which this rank projects 6075 and attends all 48600 with 3 q-heads on 1 kv-head."""
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.magi import context_parallel as cpl
+    from inferix_amd.magi.dit import HipMagiTransformerLayer, synthetic_layer_state_dict
+    from inferix_amd.magi.types import InferenceParams, ModelMetaArgs, PackedCoreAttnParams, PackedCrossAttnParams
+    mc = SimpleNamespace(num_layers=layers, hidden_size=3072, ffn_hidden_size=12288, num_attention_heads=24, num_query_groups=8,
+                         kv_channels=128, layernorm_epsilon=1e-6, apply_layernorm_1p=True, gated_linear_unit=False,
+                         cond_hidden_ratio=0.25, xattn_cond_hidden_ratio=1.0, cond_gating_ratio=1.0)
+    ec = SimpleNamespace(cp_size=cp, cp_strategy="cp_ulysses", fp8_quant=False, kv_offload=False, ulysses_overlap_degree=1)
+    cpl.set_cp_emulation(cp, 0)
+    try:
+        stack = []
+        for li in range(layers):
+            layer = HipMagiTransformerLayer(mc, ec, li, device)
+            layer.load_state_dict(synthetic_layer_state_dict(mc, seed=li, device=device))
+            stack.append(layer)
+        clip, ranges, caption = 12150, 4, 100
+        s_all = ranges * clip
+        sizes = [s_all // cp + (1 if r < s_all % cp else 0) for r in range(cp)]
+        s_loc = sizes[0]
+        g = torch.Generator(device=device).manual_seed(0)
+        x = torch.randn(s_loc, 1, 3072, generator=g, device=device).to(torch.bfloat16)
+        cond = torch.randn(1, ranges, 768, generator=g, device=device).to(torch.bfloat16)
+        cmap = (torch.arange(s_loc, device=device, dtype=torch.int32) * ranges // s_loc).reshape(s_loc, 1)
+        y = torch.randn(ranges * caption, 3072, generator=g, device=device).to(torch.bfloat16)
+        ang = torch.rand(s_loc, 64, generator=g, device=device) * 6.0
+        rope = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
+        qr = torch.tensor([[i * clip, (i + 1) * clip] for i in range(ranges)], dtype=torch.int32)
+        kr = torch.tensor([[0, (2 + i) * clip] for i in range(ranges)], dtype=torch.int32)      # keys = [1 clean chunk | 4 new]
+        core = PackedCoreAttnParams(q_range=qr, k_range=kr, np_q_range=qr.numpy(), np_k_range=kr.numpy(), max_seqlen_q=clip,
+                                    max_seqlen_k=(ranges + 1) * clip)
+        # this rank's tokens all belong to denoising range 0 (6075 < 12150): one cross-attention segment
+        cross = PackedCrossAttnParams(q_ranges=torch.tensor([[0, s_loc]], dtype=torch.int32),
+                                      kv_ranges=torch.tensor([[0, caption]], dtype=torch.int32), max_seqlen_q=s_loc, max_seqlen_kv=caption)
+        meta = ModelMetaArgs(H=45, W=45, cp_pad_size=0, cp_split_sizes=sizes, slice_point=1, denoising_range_num=ranges,
+                             range_num=ranges + 1, extract_prefix_video_feature=False, fwd_extra_1st_chunk=False,
+                             distill_nearly_clean_chunk=False, clip_token_nums=clip, enable_cuda_graph=False, core_attn_params=core,
+                             cross_attn_params=cross)
+        ip = InferenceParams(1, 8 * clip, device=device)
+        ip.update_kv_cache = False
+        for layer in stack:                          # the clean chunk's keys / values: any finite contents will do for the timing
+            mgr = layer.self_attention.kv_cache_manager
+            mgr.allocate_key_value_memory(ip, ip.max_sequence_length, 1, torch.bfloat16, scratch_rows=s_all)
+            ip.kv_cache_manager.get_raw(ip.kv_cache_request, mgr.layer_name).normal_()
+
+        def forward():
+            h = x
+            for layer in stack:
+                h = layer(h, cond, cmap, y, rope, ip, meta)
+            return h
+        out = forward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        t = ops.KernelTimer(names=("attn_magi", "gemm"))
+        ops.set_kernel_timer(t)
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            forward()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        ops.set_kernel_timer(None)
+        ks = t.summary()
+        at, ge = ks["attn_magi"], ks["gemm"]
+        atf, gtf = at["flops"] / (at["ms"] * 1e-3) / 1e12, ge["flops"] / (ge["ms"] * 1e-3) / 1e12
+        return {"workload": f"config 5 (MAGI-4.5B, 720x720, chunk 12150 tokens, 4 denoising chunks + 1 clean chunk), ONE rank of cp={cp} "
+                            f"emulated on one GPU: {s_loc} local tokens, {cp and 24 // cp} q-heads on 1 kv-head over {s_all} queries x "
+                            f"{2 * clip}..{(ranges + 1) * clip} keys, {layers} layers; all-to-alls replaced by device copies",
+                "INVALID": "emulated rank: no xGMI transfer; not a multi-GPU measurement",
+                "ms_per_denoise_forward_rank": round(ms, 1),
+                "chunk_tokens_per_s_rank_view": round(s_all / ms * 1e3, 1),
+                "attn_ms": round(at["ms"] / n, 1), "gemm_ms": round(ge["ms"] / n, 1),
+                "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (MAGI range attention, 3 q-heads on 1 kv-head)", "bound": "mfma",
+                             "achieved": round(atf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(atf / PEAK_BF16_TFLOPS, 4),
+                             "traffic": None, "launches": at["launches"] // n, "avg_launch_ms": round(at["ms"] / at["launches"], 4)},
+                "gemm_tflops": round(gtf, 1)}
+    finally:
+        ops.set_kernel_timer(None)
+        cpl.set_cp_emulation(None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,10 +404,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=0, help="debug: fewer layers (makes the result INVALID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-layers", type=int, default=30, help="debug: layers of the CPU baseline run (fewer than 30 makes it INVALID)")
     ap.add_argument("--quant", choices=["none", "fp8", "int8"], default="none",
                     help="BASELINE config 4: dynamic per-token x per-channel 8-bit linears (not the headline dtype)")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed clip with every kernel timed")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the VAE decode / text encoder measurements after the timed region")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the config 3 / 4 / 5 legs (CausVid 720p, fp8 / int8, MAGI rank) after the timed region")
     ap.add_argument("--emulate-sp", type=int, default=0, metavar="P",
                     help="debug: time ONE rank of a P-way sequence-parallel run on one GPU, the K/V all-gather replaced "
                          "by a device copy (makes the result INVALID)")
@@ -389,8 +571,18 @@ def main():
             res["vae_decode"] = vae_decode_leg()
         if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
             res["text_encoder"] = text_encoder_leg()
+        if world == 1 and not a.no_config_legs and a.emulate_sp <= 1 and a.quant == "none" and not a.layers:
+            res["quant_fp8"] = quant_leg("fp8", gen, clip)
+            res["quant_int8"] = quant_leg("int8", gen, clip)
+            kvm.free(reqs[0])
+            torch.cuda.empty_cache()
+            res["causvid_720p"] = causvid_720p_leg(model, device)
+            res["config1_gpu"] = config1_gpu(model, gen, device)
+            res["magi_cp8_emulated"] = magi_cp8_emulated_leg(device)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(a.cpu_layers)
+            if "config1_gpu" in res:
+                res["cpu_baseline"]["gpu_same_config_frames_per_s"] = res["config1_gpu"]["latent_frames_per_s"]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -20,6 +20,7 @@ import torch.distributed as dist
 from .types import ModelMetaArgs, PackedCoreAttnParams, PackedCrossAttnParams
 
 _CP_GROUP = None
+_CP_EMULATED = None          # (world, rank): ONE rank of a cp-way run timed on one GPU, collectives replaced by copies of the same bytes
 
 
 def set_cp_group(group) -> None:
@@ -28,18 +29,56 @@ def set_cp_group(group) -> None:
     _CP_GROUP = group
 
 
+def set_cp_emulation(world: Optional[int], rank: int = 0) -> None:
+    """Benchmarking aid (bench.py `magi_cp8_emulated`): behave as rank `rank` of a `world`-way context-parallel run inside one
+    process.  Every all-to-all becomes a device copy that moves the bytes this rank would receive (its own shard repeated in
+    place of its peers'), so kernels see the real shapes and the copy stands in for the xGMI transfer; results are NOT those
+    of a real run.  `None` switches it off."""
+    global _CP_EMULATED
+    _CP_EMULATED = None if not world or world <= 1 else (int(world), int(rank))
+
+
 def get_cp_group():
     return _CP_GROUP if _CP_GROUP is not None else (dist.group.WORLD if dist.is_initialized() else None)
 
 
 def get_cp_world_size() -> int:
+    if _CP_EMULATED is not None:
+        return _CP_EMULATED[0]
     g = get_cp_group()
     return dist.get_world_size(g) if g is not None else 1
 
 
 def get_cp_rank() -> int:
+    if _CP_EMULATED is not None:
+        return _CP_EMULATED[1]
     g = get_cp_group()
     return dist.get_rank(g) if g is not None else 0
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_sizes=None, in_sizes=None):
+    """`dist.all_to_all_single` with two extras: under emulation a local copy of the same bytes; over gloo (CPU-only
+    all-to-all: the 1-GPU test box runs 2 ranks on one device) device tensors are staged through the host."""
+    if _CP_EMULATED is not None:
+        world, rank = _CP_EMULATED
+        o_sz = list(out_sizes) if out_sizes is not None else [out.shape[0] // world] * world
+        i_sz = list(in_sizes) if in_sizes is not None else [inp.shape[0] // world] * world
+        i_off = sum(i_sz[:rank])
+        off = 0
+        for r in range(world):                      # peer r's piece := this rank's own piece for itself (same size up to +-1 row)
+            n = min(o_sz[r], i_sz[rank])
+            out[off:off + n].copy_(inp[i_off:i_off + n])
+            if n < o_sz[r]:
+                out[off + n:off + o_sz[r]].copy_(inp[i_off:i_off + o_sz[r] - n])
+            off += o_sz[r]
+        return FakeHandle()
+    group = get_cp_group()
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host_out, inp.cpu(), output_split_sizes=out_sizes, input_split_sizes=in_sizes, group=group)
+        out.copy_(host_out)
+        return FakeHandle()
+    return dist.all_to_all_single(out, inp, output_split_sizes=out_sizes, input_split_sizes=in_sizes, group=group, async_op=True)
 
 
 def divide(a: int, b: int) -> int:
@@ -182,7 +221,7 @@ def all_to_all_input_split(tensor: torch.Tensor, cp_split_sizes: List[int]):
     assert cp_split_sizes is not None and tensor.is_contiguous()
     send = _heads_to_ranks(tensor, cp)
     out = torch.empty((sum(cp_split_sizes),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-    handle = dist.all_to_all_single(out, send, output_split_sizes=list(cp_split_sizes), group=get_cp_group(), async_op=True)
+    handle = _a2a(out, send, out_sizes=list(cp_split_sizes))
     return out, handle
 
 
@@ -193,7 +232,7 @@ def all_to_all_output_split(tensor: torch.Tensor, cp_split_sizes: List[int]):
         return tensor, FakeHandle()
     assert cp_split_sizes is not None and tensor.is_contiguous()
     out = torch.empty((cp_split_sizes[get_cp_rank()] * cp,) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
-    handle = dist.all_to_all_single(out, tensor, input_split_sizes=list(cp_split_sizes), group=get_cp_group(), async_op=True)
+    handle = _a2a(out, tensor, in_sizes=list(cp_split_sizes))
     return out, handle
 
 
@@ -207,7 +246,7 @@ def fused_qkv_communication(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, c
     heads = [qs.shape[1], ks.shape[1], vs.shape[1]]
     send = torch.cat([qs, ks, vs], dim=1).contiguous()
     out = torch.empty((sum(cp_split_sizes),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-    dist.all_to_all_single(out, send, output_split_sizes=list(cp_split_sizes), group=get_cp_group(), async_op=False)
+    _a2a(out, send, out_sizes=list(cp_split_sizes)).wait()
     return torch.split(out, heads, dim=1)
 
 

@@ -244,3 +244,29 @@ class HipMagiTransformerBlock:
         return hidden_states
 
     __call__ = forward
+
+
+def synthetic_layer_state_dict(model_config, seed: int = 0, device="cuda") -> Dict[str, torch.Tensor]:
+    """Random weights of ONE layer with the reference's state-dict keys and dtypes (bf16 parameters, fp32 q/k layer norms and post
+    norms — dit_model.py:620-637), generated on the device: benchmarks and smoke runs (no checkpoint exists offline).  Matrices
+    ~ N(0, 1/fan_in) so that activations keep unit scale through the stack."""
+    mc = model_config
+    g = torch.Generator(device=device).manual_seed(seed)
+    h, hd = mc.hidden_size, mc.kv_channels
+    q, kv, f = hd * mc.num_attention_heads, hd * mc.num_query_groups, mc.ffn_hidden_size
+    cond = int(h * getattr(mc, "cond_hidden_ratio", 0.25))
+    xat = int(h * getattr(mc, "xattn_cond_hidden_ratio", 1.0))
+    mat = lambda o, i: (torch.randn(o, i, generator=g, device=device) * i ** -0.5).to(BF16)
+    vec = lambda n, dt, mean=0.0: (mean + 0.1 * torch.randn(n, generator=g, device=device)).to(dt)
+    sd = {"ada_modulate_layer.proj.0.weight": mat(2 * h, cond), "ada_modulate_layer.proj.0.bias": vec(2 * h, BF16),
+          "self_attention.linear_qkv.layer_norm.weight": vec(h, BF16, 1.0), "self_attention.linear_qkv.layer_norm.bias": vec(h, BF16),
+          "self_attention.linear_qkv.q.weight": mat(q, h), "self_attention.linear_qkv.qx.weight": mat(q, h),
+          "self_attention.linear_qkv.k.weight": mat(kv, h), "self_attention.linear_qkv.v.weight": mat(kv, h),
+          "self_attention.linear_kv_xattn.weight": mat(2 * kv, xat), "self_attention.linear_proj.weight": mat(h, 2 * q),
+          "mlp.layer_norm.weight": vec(h, BF16, 1.0), "mlp.layer_norm.bias": vec(h, BF16),
+          "mlp.linear_fc1.weight": mat(f, h), "mlp.linear_fc2.weight": mat(h, f)}
+    for nm, n, dt in (("self_attention.q_layernorm", hd, torch.float32), ("self_attention.k_layernorm", hd, torch.float32),
+                      ("self_attention.q_layernorm_xattn", hd, BF16), ("self_attention.k_layernorm_xattn", hd, BF16),
+                      ("self_attn_post_norm", h, torch.float32), ("mlp_post_norm", h, torch.float32)):
+        sd[nm + ".weight"], sd[nm + ".bias"] = vec(n, dt), vec(n, dt)
+    return sd

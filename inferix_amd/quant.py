@@ -140,3 +140,16 @@ def quantize_dynamic(module, qconfig_dict: Dict[str, Optional[QConfig]]):
             n += 1
     model.quantized_linears = n
     return module
+
+
+def dequantize(module):
+    """Undo `quantize_dynamic` in place: drop the 8-bit copies, the bf16 weights (never removed) serve again."""
+    model = module
+    for attr in ("generator", "model"):
+        while hasattr(model, attr) and not hasattr(model, "blocks"):
+            model = getattr(model, attr)
+    for blk in model.blocks:
+        for k in [k for k in blk.w if k.endswith(("_q", "_s", "_fmt", "_act"))]:
+            del blk.w[k]
+    model.quantized_linears = 0
+    return module

@@ -294,3 +294,72 @@ def test_full_size_chunk_properties():
         # the same bf16-P products, i.e. the noise of two flash-attention evaluations (~1.5e-3 rel-L2 on random data)
         assert rel_l2(part, full[:, 3 * rank:3 * rank + 3]) < 2e-3
         assert_bf16_parity(part, full[:, 3 * rank:3 * rank + 3], max_ulp=4, max_mismatch_frac=0.3, rel=2e-3, what="rank view")
+
+
+# ---- the layer under cp_ulysses: 2 ranks on one GPU (gloo rendezvous; device tensors staged through the host by the exchange) --
+def _cp_worker(rank, world, port, ret):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dataclasses
+        torch.cuda.set_device(0)
+        from inferix_amd.magi import context_parallel as cpl
+        from inferix_amd.magi.dit import HipMagiTransformerLayer
+        from inferix_amd.magi.types import InferenceParams
+        cpl.set_cp_group(dist.group.WORLD)
+        fx = golden("magi_block_tiny.npz")
+        cfg, n_layers, clip, n_calls, wseed, max_tokens = MB.fixture_geometry(fx)
+        mc, ec = _configs(cfg, n_layers, cp_strategy="cp_ulysses")
+        ec.cp_size = world
+        layers = []
+        for li in range(n_layers):
+            layer = HipMagiTransformerLayer(mc, ec, li, "cuda")
+            layer.load_state_dict(MB.init_layer_weights(cfg, wseed + li))
+            layers.append(layer)
+        ip = InferenceParams(1, max_tokens)
+        outs = []
+        for ci in range(3):                          # store two chunks / prefix + nearly-clean rule / read-only window
+            inp, m = MB.fixture_call(fx, ci)
+            meta = _meta(m)
+            x, cmap, rope, pad, sizes, core_p, cross_p = cpl.cp_pre_process(
+                world, "cp_ulysses", inp["x"].cuda(), inp["condition_map"].cuda(), inp["rope"].cuda(), None, None,
+                meta.core_attn_params, meta.cross_attn_params)
+            meta = dataclasses.replace(meta, cp_pad_size=pad, cp_split_sizes=sizes, core_attn_params=core_p, cross_attn_params=cross_p)
+            ip.update_kv_cache = m.update_kv_cache
+            for layer in layers:
+                x = layer(x, inp["condition"].cuda(), cmap, inp["y"].cuda(), rope, ip, meta)
+            outs.append(x.cpu())
+        torch.cuda.synchronize()
+        ret[rank] = outs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layer_under_cp_ulysses_two_ranks_matches_single_device_golden():
+    """The algebraic identity that pins the context-parallel path: the rank-order concatenation of the 2 ranks'
+    outputs equals the single-device reference output.  4 q-heads / 2 kv-heads over 2 ranks = 2 q-heads on 1 kv-head each,
+    head-sharded cache, prefix read in place on the second and third forward."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_cp_worker, args=(world, port, ret), nprocs=world, join=True)
+        outs = [ret[r] for r in range(world)]
+    fx = golden("magi_block_tiny.npz")
+    for ci in range(3):
+        got = torch.cat([outs[r][ci] for r in range(world)], dim=0)
+        ref = fx[f"c{ci}_out_l1"]
+        assert got.shape == ref.shape
+        assert rel_l2(got, ref) < 1e-2, (ci, rel_l2(got, ref))
