@@ -1,0 +1,2 @@
+"""inferix/models/attention/flash_attention.py:42-200"""
+from inferix_amd.attention import attention, flash_attention  # noqa: F401

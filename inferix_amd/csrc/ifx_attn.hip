@@ -393,11 +393,21 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots)
 // (384-row tiles), 4 free-running, 5 software-pipelined, 6 software-pipelined in four-wave workgroups (128-row tiles, two per CU).
 // Auto (variant 0): 5, except for launches whose rows fill 128-row tiles markedly better than 256-row tiles — one rank's 585 rows
 // of an eight-way sequence-parallel shard: 5 x 128 (91 %) against 3 x 256 (76 %); one rank's clip 348 -> 332 ms
-static int attn_groups(int variant, int q_rows) {
+static int attn_groups(int variant, int q_rows, int heads = 0) {
   if (variant == 3 || variant == 4 || variant == 2 || variant == 6) return variant;
   if (variant == 0 && q_rows > 0) {
-    const float u256 = (float)q_rows / (256.f * ((q_rows + 255) / 256)), u128 = (float)q_rows / (128.f * ((q_rows + 127) / 128));
+    const int t256 = (q_rows + 255) / 256, t128 = (q_rows + 127) / 128;
+    const float u256 = (float)q_rows / (256.f * t256), u128 = (float)q_rows / (128.f * t128);
     if (u128 > 1.1f * u256) return 6;
+    // Launches of more than one round of workgroups: whole rounds are what costs.  256-row tiles run one per CU (256 slots), the
+    // 128-row four-wave tiles two per CU (512 slots) at 0.934 of the rate (1004 vs 1075 TFLOP/s).  CausVid 720p: 10800
+    // rows x 12 heads = 516 tiles = 2.02 rounds -> THREE rounds of 256-row tiles, but 1020 / 512 = 1.99 -> two of 128-row tiles
+    // (measured 778 -> see profiles/r2_*); the 480p block (228 tiles, one round either way) stays on the 256-row schedule.
+    if (heads > 0 && t256 * heads > 256) {
+      const float c5 = (float)((t256 * heads + 255) / 256);
+      const float c6 = (float)((t128 * heads + 511) / 512) / 0.934f;
+      if (c6 < 0.95f * c5) return 6;
+    }
   }
   return 5;
 }
@@ -428,11 +438,11 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
     IFX_REQUIRE(workspace && workspace_bytes >= (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits),
                 "ifx_attn_fwd_paged_split: workspace of %lld B too small for %d splits (need %lld B)",
                 (long long)workspace_bytes, splits, (long long)attn_pp_workspace_bytes(q_rows, heads, splits));
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant, q_rows),
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant, q_rows, heads),
                           (hipStream_t)stream, 0, 0, nullptr, ldq, ldo);
   }
   if (variant >= 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
-    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant, q_rows),
+    return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant, q_rows, heads),
                           (hipStream_t)stream, 0, 0, nullptr, ldq, ldo);
   AttnArgs a;
   a.q = q;
@@ -486,8 +496,8 @@ extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv
                                        int64_t* workspace_bytes) {
   int splits = 1;
   if (q_rows > 0 && heads > 0 && kv_len > kv_start)
-    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_qt(attn_groups(attn_variant(), q_rows)),
-                                     attn_slots(attn_groups(attn_variant(), q_rows)));
+    splits = attn_pp_split_heuristic(q_rows, heads, kv_len - kv_start, attn_qt(attn_groups(attn_variant(), q_rows, heads)),
+                                     attn_slots(attn_groups(attn_variant(), q_rows, heads)));
   if (workspace_bytes) *workspace_bytes = (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits);
   return splits;
 }
@@ -516,7 +526,7 @@ extern "C" int ifx_attn_fwd_partial(const ifx_bf16* q, const ifx_kv_view* kv, in
               "ifx_attn_fwd_partial: workspace of %lld B too small for %d slots", (long long)workspace_bytes, slot_cap);
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_partial: page_size must be > 0");
   return launch_attn_pp(q, nullptr, nullptr, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace,
-                        attn_groups(attn_variant(), q_rows), (hipStream_t)stream, slot_base, slot_cap, slots_used);
+                        attn_groups(attn_variant(), q_rows, heads), (hipStream_t)stream, slot_base, slot_cap, slots_used);
 }
 
 extern "C" int ifx_attn_merge_partials(const void* workspace, int32_t slot_cap, int32_t slots_used, ifx_bf16* out,

@@ -26,6 +26,7 @@ import torch.distributed as dist
 
 from ..core.types import DecodeMode, StreamingMode
 from ..kvcache_manager import KVCacheManager, KVCacheRequest
+from .base_pipeline import AbstractInferencePipeline
 from .causal_inference import CausalInferencePipeline
 
 
@@ -46,7 +47,7 @@ def _load_config(path_or_dict, default=None) -> SimpleNamespace:
     return SimpleNamespace(**merge(read(default), read(path_or_dict)))
 
 
-class SelfForcingPipeline:
+class SelfForcingPipeline(AbstractInferencePipeline):
     def __init__(self, config_path, default_config_path: Optional[str] = None, parallel_config=None,
                  profiling_config=None, *, text_encoder=None, vae=None, generator=None, device=None):
         from ..wan import ParallelConfig
@@ -58,11 +59,9 @@ class SelfForcingPipeline:
             raise RuntimeError("SelfForcingPipeline needs an MI355X: the HIP path has no CPU fallback")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.parallel_config = parallel_config or ParallelConfig()
-        self.profiling_config = profiling_config
-        self._profiling_enabled = bool(getattr(profiling_config, "enabled", False))
-        self._profiler = getattr(profiling_config, "profiler", None)
+        AbstractInferencePipeline.__init__(self, self.config, profiling_config)
         self._memory_mode = getattr(self.config, "memory_mode", "balanced")
-        self._vae_chunk_size = getattr(self.config, "vae_chunk_size", None)
+        self._vae_chunk_size = getattr(self.config, "vae_chunk_size", None)        # None = the inner pipeline's preset
         self._checkpoint_state_dict: Optional[Dict[str, torch.Tensor]] = None
         self.latent_shape = list(getattr(self.config, "latent_shape", [16, 60, 104]))
         torch.set_grad_enabled(False)
@@ -123,8 +122,6 @@ class SelfForcingPipeline:
             comp = getattr(self.pipeline, name)
             if isinstance(comp, torch.nn.Module):
                 comp.to(self.device)
-
-    setup = setup_devices
 
     # ------------------------------------------------------------------------------------------------------
     def _need(self, what: str):
@@ -212,25 +209,6 @@ class SelfForcingPipeline:
             model.clear_cache()
 
     # ------------------------------------------------------------------------------------------------------
-    def run_streaming_generation(self, prompts: List[str], stream_callback: Optional[Callable[[torch.Tensor], None]] = None,
-                                 num_segments: int = 1, segment_length: int = 21, overlap_frames: int = 3,
-                                 **kwargs) -> Optional[torch.Tensor]:
-        """Segment loop of base_pipeline.py:468-615: prompts cycle over segments, the last `overlap_frames` latent frames
-        of a segment condition the next one, videos are concatenated along time.  -> `[B, T_total, H, W, C]` on the host."""
-        videos = []
-        initial_latent = None
-        for seg in range(num_segments):
-            video, final_latent = self._generate_segment_with_streaming(
-                prompt=prompts[seg % len(prompts)], initial_latent=initial_latent, stream_callback=stream_callback,
-                segment_length=segment_length, **kwargs)
-            videos.append(video)
-            if seg < num_segments - 1:
-                initial_latent = final_latent[:, -overlap_frames:]
-            self._cleanup_segment_memory()
-        if not videos:
-            return None
-        return torch.cat(videos, dim=1) if len(videos) > 1 else videos[0]
-
     def _cleanup_segment_memory(self):
         self._clear_vae_cache()
 
