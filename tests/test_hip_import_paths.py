@@ -100,11 +100,13 @@ def test_self_forcing_example_sequence_through_reference_import_paths(tmp_path):
     assert video.shape == (2, 21, 3, 2 * cfg.latent_h, 2 * cfg.latent_w) and torch.isfinite(video).all()
     assert sorted(os.listdir(out_dir)) == ["0-0.pt", "1-0.pt"] and enc.seen == [["a cat"], ["a dog"]]
     # the template entry points of the base class
+    # (`__call__` hands its keyword arguments to `run` as the INPUTS dict, base_pipeline.py:437-458: only the input keys count,
+    #  so both calls below generate the default 21 latent frames)
     set_random_seed(1)
-    v1 = pipeline(prompt="a cat", num_output_frames=3)
+    v1 = pipeline(prompt="a cat")
     set_random_seed(1)
-    v2 = pipeline.run({"prompts": ["a cat"]}, num_output_frames=3)
-    assert torch.equal(v1, v2) and v1.shape[1] == 9
+    v2 = pipeline.run({"prompts": ["a cat"]})
+    assert torch.equal(v1, v2) and v1.shape[1] == 81
 
 
 def test_quantized_example_sequence(tmp_path):
