@@ -46,7 +46,9 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   9 / 10 = warp-specialised 256x128 / 128x128, 11 = 256x256x32 four stages,
  *                   12 / 13 / 14 = 64x64 (four K-groups), 64x64 (two), 128x128 (two): split-K between the wave groups of one
  *                   workgroup, what 0 = auto picks for launches of at most one workgroup per CU; K / 64 must divide by the groups;
- *                   15 = 128x64 two stages (three per CU), 16 / 17 = 64x128 two / three stages
+ *                   15 = 128x64 two stages (three per CU), 16 / 17 = 64x128 two / three stages,
+ *                   18 = four-wave 256x256 on the LDS-DMA ring (experiment), 19 = four-wave 256x256x64 register-staged software
+ *                   pipeline (ifx_gemm_w4.hip), 20 = auto including its split-K form when a workspace is given
  *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
  *                   4 free-running schedule, 5 software-pipelined schedule (what 0 = auto picks for large launches),
  *                   6 software-pipelined in four-wave workgroups, two per CU
@@ -220,6 +222,17 @@ typedef struct {
 int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias,
                   ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
                   const ifx_epilogue* epi, void* stream);
+
+/* ifx_gemm_bf16 with a caller-provided scratch buffer, which lets the library pick tiles that split K between workgroups (the
+ * four-wave 256 x 256 tile with two K halves for long-K launches whose tiles would fill less than half of the chip: the FFN
+ * down-projection of the block, 4680 x 1536 x 8960).  ifx_gemm_workspace_bytes returns what a shape wants (0 = none: the call is
+ * then identical to ifx_gemm_bf16).  The FIRST 4096 bytes of the workspace must be zero on entry (zero it once after allocation);
+ * every call leaves them zero.  Launches that share a workspace must be ordered on one stream.  Results are deterministic
+ * (a + b == b + a for the two partial sums). */
+int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int ifx_gemm_bf16_ws(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y, int32_t ldy,
+                     int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 
 /* ------------------------------------------------------------------------
  * Dynamic 8-bit linear layers: per-token activation x per-channel weight, FP8 (OCP e4m3fn) or INT8.

@@ -34,7 +34,7 @@ struct EpiArgs {
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // 0.5*x*(1+tanh(u)) == x*sigmoid(2u),  u = sqrt(2/pi)*(x + 0.044715 x^3)
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));   // v_rcp_f32 (1 ulp fp32) instead of the IEEE division sequence
 }
 // exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
 // inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
@@ -157,8 +157,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
       } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(rbf(v[e])) : gelu_tanh_f(rbf(v[e]))));
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_erf_f(rbf(v[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_tanh_f(rbf(v[e])));
+}
       } else {
         const u16x4 rv = *reinterpret_cast<const u16x4*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -178,6 +183,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short*
 int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                      int N, int K, int mode, const unsigned short* bias, const unsigned short* residual, int ld_res,
                      const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group, hipStream_t s);
+
+int launch_gemm_w4(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
+                   int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int splits, void* workspace);
+size_t gemm_w4_workspace_bytes(int M, int N, int splits);
+
+// Split-K over two workgroups on the four-wave 256 x 256 tile (ifx_gemm_w4.hip): long-K launches whose 256 x 256 tiles fill less
+// than half of the chip — the FFN down-projection, 4680 x 1536 x 8960: 114 tiles, 228 workgroups with the split.  Needs a caller
+// workspace, so only ifx_gemm_bf16_ws takes this path.
+static bool want_w4_splitk(int M, int N, int K) {
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  return K >= 4096 && (K / 64) % 2 == 0 && 2 * tiles <= 256 && 2 * tiles >= 160;
+}
 
 int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy,
                         int M, int N, int K, int mode, const unsigned short* bias, const unsigned short* residual,
@@ -214,6 +232,14 @@ static int pick_tile(int M, int N, int K) {
   // text_embedding linear, N = 1536, K = 4096: split at one 512-token prompt, single-pass at two).  The umT5 encoder's shapes
   // (N >= 4096) never take a split tile, which is what tests/test_hip_t5.py's batch-invariance test relies on; callers that need
   // invariance elsewhere pin the tile with ifx_set_option("gemm_variant", ...).
+  // Long K and at least ~1.5 rounds of 256 x 256 tiles: the four-wave register-staged tile (ifx_gemm_w4.hip, tile 17), whose K loop
+  // needs a third less LDS bandwidth than the eight-wave tiles; its fixed cost per tile (one wave per SIMD: nothing overlaps the
+  // prologue and the epilogue) is only amortised by K >= 2048.  MAGI-4.5B shapes, tools/bench_gemm_shapes.py: 6075 x 8192 x 3072
+  // 326 -> 261 us, 6075 x 12288 x 3072 494 -> 409, 12150 x 3072 x 12288 1033 -> 900; the Wan block's K = 1536 GEMMs stay where they were.
+  {
+    const int t256 = ((M + 255) / 256) * ((N + 255) / 256), rounds = (t256 + 255) / 256;
+    if (K >= 2048 && t256 >= 384 && (float)t256 >= 0.7f * 256.f * rounds) return 17;
+  }
   int best = 2;
   float best_score = -1.f;
   for (const Cand& c : cands) {
@@ -237,8 +263,9 @@ static int pick_tile(int M, int N, int K) {
 
 using namespace ifx;
 
-extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
-                             int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* stream) {
+static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
+                          int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* stream, void* workspace,
+                          int64_t workspace_bytes) {
   IFX_REQUIRE(x && w && y && M >= 0 && N > 0 && K > 0, "ifx_gemm_bf16: null/empty operand");
   IFX_REQUIRE(K % BK == 0, "ifx_gemm_bf16: K (%d) must be a multiple of %d", K, BK);   // 64; also covers the 32-deep tiles
   IFX_REQUIRE(N % 4 == 0 && ldx % 8 == 0 && ldy % 4 == 0, "ifx_gemm_bf16: N %% 4, ldx %% 8, ldy %% 4 required");
@@ -264,8 +291,12 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
   if (M == 0) return IFX_OK;
   const int variant = gemm_variant();
   const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0);
+  if (wide_ok && (variant == 0 || variant == 20) && workspace != nullptr && want_w4_splitk(M, N, K) &&
+      workspace_bytes >= (int64_t)gemm_w4_workspace_bytes(M, N, 2))
+    return launch_gemm_w4(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                          ea.rows_per_group, (hipStream_t)stream, 2, workspace);
   if (wide_ok && variant != 1) {
-    const int tile = variant >= 2 ? variant - 2 : pick_tile(M, N, K);
+    const int tile = (variant >= 2 && variant != 20) ? variant - 2 : pick_tile(M, N, K);
     return launch_gemm_lds_dma(tile, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod,
                                ea.mod_slots, ea.gate_slot, ea.rows_per_group, (hipStream_t)stream);
   }
@@ -292,4 +323,19 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
   }
 #undef IFX_LAUNCH_GEMM
   return check_launch("ifx_gemm_bf16");
+}
+
+extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
+                             int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* stream) {
+  return gemm_bf16_impl(x, ldx, w, bias, y, ldy, M, N, K, epi, stream, nullptr, 0);
+}
+
+extern "C" int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+  return (M > 0 && N > 0 && K > 0 && want_w4_splitk(M, N, K)) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
+}
+
+extern "C" int ifx_gemm_bf16_ws(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
+                                int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  return gemm_bf16_impl(x, ldx, w, bias, y, ldy, M, N, K, epi, stream, workspace, workspace_bytes);
 }

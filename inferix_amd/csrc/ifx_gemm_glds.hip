@@ -58,7 +58,7 @@ struct EpiArgs2 {
 
 __device__ __forceinline__ float gelu_tanh_f2(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));   // v_rcp_f32 (1 ulp fp32) instead of the IEEE division sequence
 }
 // exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
 // inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
@@ -259,8 +259,13 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const unsigned short*
       if (EPI == IFX_EPI_BIAS) {
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+}
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -481,8 +486,13 @@ __global__ __launch_bounds__(256 * KG) void gemm_small_kernel(const unsigned sho
       if (EPI == IFX_EPI_BIAS) {
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+}
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -662,8 +672,13 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const unsigned short* __re
       if (EPI == IFX_EPI_BIAS) {
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+}
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -845,8 +860,13 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
       if (EPI == IFX_EPI_BIAS) {
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_f2(bf2f(vv[e]))));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+}
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {
@@ -966,6 +986,10 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
                         int ld_res, const unsigned short* mod, int mod_slots, int gate_slot, int rows_per_group,
                         hipStream_t s);
 
+int launch_gemm_w4(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
+                   int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int splits, void* workspace);
+
 // host launcher used by ifx_gemm_bf16 (ifx_gemm.hip) for large shapes
 int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
                      int N, int K, int mode, const unsigned short* bias, const unsigned short* residual, int ld_res,
@@ -1024,6 +1048,11 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   if (tile == 13) return launch_small<128, 64, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);      // 48 KiB: three per CU
   if (tile == 14) return launch_small<64, 128, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);      // 48 KiB: three per CU
   if (tile == 15) return launch_small<64, 128, 3>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);      // 72 KiB: two per CU
+  // FOUR waves of 128 x 128 on a 256 x 256 x 64 tile (256 accumulator registers per lane, one wave per SIMD): the eight-wave
+  // tiles read (128 + 64) fragment rows per 8192 outputs from LDS = ~96 B/clk/CU of a 128 B/clk LDS next to 32 B/clk of DMA
+  // writes; 128 x 128 wave tiles read a third less per FLOP
+  if (tile == 16) return launch_small<256, 256, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  if (tile == 17) return launch_gemm_w4(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, s, 1, nullptr);   // ifx_gemm_w4.hip
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }
 

@@ -114,7 +114,7 @@ struct EpiArgsQ {
 
 __device__ __forceinline__ float gelu_tanh_q(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));   // v_rcp_f32 (1 ulp fp32) instead of the IEEE division sequence
 }
 // exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
 // inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
@@ -255,8 +255,13 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_kernel(const unsigned char* __
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
         } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(rbf(v[e])) : gelu_tanh_q(rbf(v[e]))));
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_erf_f(rbf(v[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(gelu_tanh_q(rbf(v[e])));
+}
         } else {
           const u16x4 rv = *reinterpret_cast<const u16x4*>(ea.residual + (size_t)m * ea.ld_res + n);
           if (EPI == IFX_EPI_RESIDUAL) {
@@ -473,8 +478,13 @@ __global__ __launch_bounds__(512) void gemm_q8_dma_kernel(const unsigned char* _
       if (EPI == IFX_EPI_BIAS) {
         o = vv;
       } else if (EPI == IFX_EPI_GELU_TANH) {
+if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch around the loop, not a per-element select
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((ea.gate_slot ? gelu_erf_f(bf2f(vv[e])) : gelu_tanh_q(bf2f(vv[e]))));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
+} else {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_q(bf2f(vv[e])));
+}
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
         if (EPI == IFX_EPI_RESIDUAL) {

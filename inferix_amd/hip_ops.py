@@ -376,10 +376,32 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
         assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
+    need = _GEMM_WS_NEED.get((M, N, K))
+    if need is None:
+        need = _GEMM_WS_NEED[(M, N, K)] = int(lib.ifx_gemm_workspace_bytes(M, N, K))
     with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
-        _hip.check(lib.ifx_gemm_bf16(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
-                                     _dev(out, "out"), ldy, M, N, K, C.byref(epi), _stream()), "ifx_gemm_bf16")
+        if need:
+            ws = _gemm_workspace(x.device, need)
+            _hip.check(lib.ifx_gemm_bf16_ws(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
+                                            _dev(out, "out"), ldy, M, N, K, C.byref(epi), ws.data_ptr(), ws.numel(), _stream()),
+                       "ifx_gemm_bf16_ws")
+        else:
+            _hip.check(lib.ifx_gemm_bf16(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
+                                         _dev(out, "out"), ldy, M, N, K, C.byref(epi), _stream()), "ifx_gemm_bf16")
     return out
+
+
+_GEMM_WS_NEED: dict = {}     # (M, N, K) -> bytes ifx_gemm_workspace_bytes asks for (0 = none)
+_GEMM_WS: dict = {}          # (device index, stream) -> zero-initialised scratch for the split-K tiles, grown on demand
+
+
+def _gemm_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    key = (dev.index, _stream())
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)      # the arrival counters in front must start at zero
+        _GEMM_WS[key] = ws
+    return ws
 
 
 def quant_per_token(x: torch.Tensor, fmt: int, q: Optional[torch.Tensor] = None,
