@@ -365,6 +365,10 @@ _GEMM_CASES = [(v, M, N, K) for v in range(1, 12) for M, N, K in [(585, 1536, 15
 # 12-14 split K between the wave groups of a workgroup: K/64 has to divide by the groups (4, 2, 2)
 _GEMM_CASES += [(v, M, N, K) for v in (15, 16, 17) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 64)]]
 _GEMM_CASES += [(v, M, N, K) for v in (12, 13, 14) for M, N, K in [(585, 1536, 1536), (300, 640, 256), (77, 64, 512), (585, 1536, 8960)]]
+# 18 = four-wave 256x256 on the LDS-DMA ring, 19 = the register-staged software-pipelined four-wave tile (ifx_gemm_w4.hip): one K step
+# (K = 64), odd step counts, ragged edges in both dimensions, a tile count that is not a multiple of the XCD count
+_GEMM_CASES += [(v, M, N, K) for v in (18, 19) for M, N, K in [(585, 1536, 1536), (300, 640, 64), (77, 64, 192), (1170, 4608, 1536),
+                                                                (2000, 2312, 3072)]]
 
 
 @pytest.mark.parametrize("variant,M,N,K", _GEMM_CASES)
@@ -391,6 +395,37 @@ def test_gemm_every_tile_variant(ops, variant, M, N, K):
         assert_bf16_parity(got, res + (y * gate).to(BF), max_ulp=2, floor=1.0, what=f"variant {variant} gate+residual")
     finally:
         ops.set_option("gemm_variant", 0)
+
+
+def test_gemm_four_wave_tile_auto_choice_and_split_k(ops):
+    """The long-K shapes the auto choice hands to the four-wave tile (MAGI-4.5B fc1 of one rank) agree with the eight-wave tile on
+    the same inputs; the split-K form (variant 20, two workgroups per tile through ifx_gemm_bf16_ws) equals the unsplit tile to
+    fp32 summation order, is deterministic run to run, and leaves its arrival counters zeroed for the next launch."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 6075, 12288, 3072
+    x, w = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5))
+    auto = ops.linear(x, w, None, epilogue=_hip.IFX_EPI_GELU_ERF)
+    ops.set_option("gemm_variant", 5)
+    try:
+        ref = ops.linear(x, w, None, epilogue=_hip.IFX_EPI_GELU_ERF)
+    finally:
+        ops.set_option("gemm_variant", 0)
+    assert torch.equal(auto, ref), "same MFMA summation order: the two tiles must agree bit for bit"
+    M, N, K = 4680, 1536, 8960
+    x, w, b, res = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1)), gpu(rnd(g, M, N))
+    mod = gpu(rnd(g, 3, 6, N, scale=0.5))
+    kw = dict(epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=5, rows_per_group=1560)
+    base = ops.linear(x, w, b, **kw)
+    ops.set_option("gemm_variant", 20)
+    try:
+        outs = [ops.linear(x, w, b, **kw) for _ in range(5)]
+        assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) > 0
+    finally:
+        ops.set_option("gemm_variant", 0)
+    assert all(torch.equal(o, outs[0]) for o in outs), "split-K result must not depend on which workgroup finishes last"
+    assert_bf16_parity(outs[0], base, max_ulp=1, max_mismatch_frac=0.02, floor=1.0, what="split-K vs single pass")
+    assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) == 0          # opt-in only
 
 
 def test_gemm_split_k_tiles_refuse_indivisible_k(ops):
