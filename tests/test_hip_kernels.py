@@ -424,7 +424,8 @@ def test_gemm_four_wave_tile_auto_choice_and_split_k(ops):
     finally:
         ops.set_option("gemm_variant", 0)
     assert all(torch.equal(o, outs[0]) for o in outs), "split-K result must not depend on which workgroup finishes last"
-    assert_bf16_parity(outs[0], base, max_ulp=1, max_mismatch_frac=0.02, floor=1.0, what="split-K vs single pass")
+    # two K halves summed once in fp32 instead of one running sum: a flipped bf16 rounding of y moves bf16(res + bf16(y * gate))
+    assert_bf16_parity(outs[0], base, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what="split-K vs single pass")
     assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) == 0          # opt-in only
 
 
