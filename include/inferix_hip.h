@@ -120,6 +120,16 @@ int ifx_attn_fwd_paged_ld(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t
                           int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale, int32_t num_splits,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Several (query range, key range) pairs of one cache in ONE launch — MAGI's core_attention (inferix/models/magi/dit/dit_module.py:
+ * 972-1015): per denoising range i, queries [q_ranges[i][0], q_ranges[i][1]) attend keys [k_ranges[i][0], k_ranges[i][1]), no mask
+ * inside a range.  One rank of cp = 8 has 3 query heads: a single range is 144 workgroups for 256 CUs, four ranges together fill
+ * the chip without splitting keys.  q_ranges / k_ranges are HOST arrays [n_ranges][2]; 1 <= n_ranges <= 8; ranges are tiled
+ * separately (a query tile never straddles two ranges) and scheduled longest key range first.  Strides as ifx_attn_fwd_paged_ld
+ * (0 = dense). */
+int ifx_attn_fwd_ranges(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t ldo, const ifx_kv_view* kv, int32_t q_rows,
+                        int32_t heads, int32_t n_ranges, const int32_t* q_ranges, const int32_t* k_ranges, float scale,
+                        void* stream);
+
 /* The same split-KV algebra in separate launches that share one workspace: under sequence parallelism the cached
  * prefix is attended while the collective that delivers the new block's keys is still in flight, then the new keys,
  * then ONE merge.  ifx_attn_fwd_partial writes the fp32 partials of up to `num_splits` key chunks of

@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(unsigned short* __restri
 
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
-                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0);
+                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0,
+                   int n_ranges = 0, const int* q_ranges = nullptr, const int* k_ranges = nullptr);
 int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsigned short* out, float* lse, int q_rows,
                       int heads, hipStream_t stream, int ldo = 0);
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
@@ -490,6 +491,33 @@ extern "C" int ifx_attn_fwd_paged_ld(const ifx_bf16* q, int32_t ldq, ifx_bf16* o
   IFX_REQUIRE(ldq > 0 && ldo > 0, "ifx_attn_fwd_paged_ld: row strides must be given");
   return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, workspace_bytes, stream,
                        ldq, ldo);
+}
+
+extern "C" int ifx_attn_fwd_ranges(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t ldo, const ifx_kv_view* kv, int32_t q_rows,
+                                   int32_t heads, int32_t n_ranges, const int32_t* q_ranges, const int32_t* k_ranges, float scale,
+                                   void* stream) {
+  IFX_REQUIRE(q && out && kv && kv->k && kv->v && q_ranges && k_ranges, "ifx_attn_fwd_ranges: null argument");
+  IFX_REQUIRE(kv->head_dim == HD, "ifx_attn_fwd_ranges: head_dim %d not built (128 only)", kv->head_dim);
+  IFX_REQUIRE(heads > 0 && kv->kv_heads > 0 && heads % kv->kv_heads == 0, "ifx_attn_fwd_ranges: heads %d / kv_heads %d", heads,
+              kv->kv_heads);
+  IFX_REQUIRE(n_ranges >= 1 && n_ranges <= 8, "ifx_attn_fwd_ranges: 1..8 ranges per launch (got %d)", n_ranges);
+  if (ldq <= 0) ldq = heads * HD;
+  if (ldo <= 0) ldo = heads * HD;
+  IFX_REQUIRE(ldq >= heads * HD && ldo >= heads * HD && ldq % 8 == 0 && ldo % 8 == 0, "ifx_attn_fwd_ranges: row strides (%d, %d)", ldq, ldo);
+  if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_ranges: page_size must be > 0");
+  int kmin = 0x7fffffff, kmax = 0, rows = 0;
+  for (int i = 0; i < n_ranges; ++i) {
+    const int q0 = q_ranges[2 * i], q1 = q_ranges[2 * i + 1], k0 = k_ranges[2 * i], k1 = k_ranges[2 * i + 1];
+    IFX_REQUIRE(q0 >= 0 && q1 > q0 && q1 <= q_rows, "ifx_attn_fwd_ranges: query range %d = [%d, %d) outside [0, %d)", i, q0, q1, q_rows);
+    IFX_REQUIRE(k0 >= 0 && k1 > k0 && k1 <= kv->num_slots, "ifx_attn_fwd_ranges: key range %d = [%d, %d) out of range (capacity %d)",
+                i, k0, k1, kv->num_slots);
+    kmin = k0 < kmin ? k0 : kmin;
+    kmax = k1 > kmax ? k1 : kmax;
+    rows += q1 - q0;
+  }
+  const int groups = attn_groups(attn_variant(), rows / n_ranges, heads * n_ranges);   // every range tiles separately
+  return launch_attn_pp(q, out, nullptr, kv, q_rows, heads, kmin, kmax, scale, 1, nullptr, groups == 5 || groups == 6 ? groups : 5,
+                        (hipStream_t)stream, 0, 0, nullptr, ldq, ldo, n_ranges, q_ranges, k_ranges);
 }
 
 extern "C" int32_t ifx_attn_split_plan(int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len,

@@ -93,6 +93,10 @@ struct AttnArgsPP {
   int kv_heads, q_per_kv;   // grouped-query attention: query head h reads kv head h / q_per_kv
   float* part_o;
   float* part_lse;
+  // multi-range launch (n_ranges > 0, unsplit kernels only): query rows [rq0[r], rq1[r]) attend keys [rk0[r], rk1[r]); q tile ids
+  // [rt0[r], rt0[r + 1]) of a head belong to range r (MAGI: the denoising chunks of one forward in ONE launch)
+  int n_ranges;
+  int rq0[8], rq1[8], rk0[8], rk1[8], rt0[9];
 };
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
@@ -180,12 +184,23 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     head = wi / A.q_tiles;
     qt = wi - head * A.q_tiles;
   }
-  const int kv_s = SPLIT ? A.kv_start + sp * A.chunk_tiles * KT : A.kv_start;
-  const int kv_e = SPLIT ? min(A.kv_len, kv_s + A.chunk_tiles * KT) : A.kv_len;
+  int kv_s = SPLIT ? A.kv_start + sp * A.chunk_tiles * KT : A.kv_start;
+  int kv_e = SPLIT ? min(A.kv_len, kv_s + A.chunk_tiles * KT) : A.kv_len;
+  int q_base = qt * QT, q_lim = A.q_rows;
+  if (!SPLIT && A.n_ranges > 0) {
+    int r = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if (i < A.n_ranges && qt >= A.rt0[i]) r = i;
+    q_base = A.rq0[r] + (qt - A.rt0[r]) * QT;
+    q_lim = A.rq1[r];
+    kv_s = A.rk0[r];
+    kv_e = A.rk1[r];
+  }
   const int row_stride = A.heads * HD;
 
-  const int qrow = qt * QT + wave * 32 + l31;
-  const int qrow_c = min(qrow, A.q_rows - 1);
+  const int qrow = q_base + wave * 32 + l31;
+  const int qrow_c = min(qrow, q_lim - 1);
   bf16x8 qf[8];
   {
     const unsigned short* qp = A.q + (size_t)qrow_c * A.ldq + head * HD + hi * 8;
@@ -907,7 +922,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     }
     return;
   }
-  if (qrow < A.q_rows) {
+  if (qrow < q_lim) {
     unsigned short* op = A.out + (size_t)qrow * A.ldo + head * HD + 4 * hi;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -1038,7 +1053,8 @@ static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid,
 //                [slot_base, slot_base + splits), no merge; *slots_used reports how many chunks were written.
 int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, const ifx_kv_view* kv, int q_rows,
                    int heads, int kv_start, int kv_len, float scale, int splits, void* workspace, int groups,
-                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0) {
+                   hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0,
+                   int n_ranges = 0, const int* q_ranges = nullptr, const int* k_ranges = nullptr) {
   using namespace pp;
   const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : 0));   // attn_variant 4 / 5 / 6
   if (fr_mode) groups = fr_mode == 3 ? 1 : 2;
@@ -1060,6 +1076,27 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.kv_heads = kv->kv_heads;
   a.q_per_kv = heads / kv->kv_heads;
   a.q_tiles = (q_rows + QT - 1) / QT;
+  a.n_ranges = 0;
+  if (n_ranges > 0) {
+    // longest key ranges first: tile ids are handed out in order, so the expensive tiles must not be the tail of the launch
+    int order[8];
+    for (int i = 0; i < n_ranges; ++i) order[i] = i;
+    for (int i = 1; i < n_ranges; ++i)
+      for (int j = i; j > 0 && k_ranges[2 * order[j] + 1] - k_ranges[2 * order[j]] > k_ranges[2 * order[j - 1] + 1] - k_ranges[2 * order[j - 1]]; --j) {
+        const int t = order[j];
+        order[j] = order[j - 1];
+        order[j - 1] = t;
+      }
+    a.n_ranges = n_ranges;
+    a.rt0[0] = 0;
+    for (int i = 0; i < n_ranges; ++i) {
+      const int r = order[i];
+      a.rq0[i] = q_ranges[2 * r], a.rq1[i] = q_ranges[2 * r + 1], a.rk0[i] = k_ranges[2 * r], a.rk1[i] = k_ranges[2 * r + 1];
+      a.rt0[i + 1] = a.rt0[i] + (a.rq1[i] - a.rq0[i] + QT - 1) / QT;
+    }
+    a.q_tiles = a.rt0[n_ranges];
+    splits = 1;
+  }
   const int nt = (kv_len - kv_start + KT - 1) / KT;
   splits = max(1, min(splits, nt));
   a.chunk_tiles = (nt + splits - 1) / splits;

@@ -661,3 +661,21 @@ def quant_per_tensor(x: torch.Tensor, fmt: int, q: Optional[torch.Tensor] = None
     _hip.check(_hip.load().ifx_quant_per_tensor(_dev(x, "x"), ldx, _dev(q, "q", torch.uint8), q.stride(0), _dev(scale, "scale", F32),
                                                 ws.data_ptr(), rows, K, int(fmt), _stream()), "ifx_quant_per_tensor")
     return q, scale
+
+
+def attention_ranges(q: torch.Tensor, kv: KvCacheView, q_ranges, k_ranges, out: torch.Tensor, heads: int, scale: float = 0.0,
+                     tag: str = "attn") -> torch.Tensor:
+    """Several (query range, key range) pairs in ONE launch (ifx_attn_fwd_ranges; MAGI core_attention).  `q` / `out` 2-D views
+    `[rows, >= heads*128]` (row strides are passed on); ranges are host sequences of (start, end)."""
+    n = len(q_ranges)
+    assert 1 <= n <= 8 and len(k_ranges) == n and q.dim() == 2 and out.dim() == 2 and q.stride(1) == 1 and out.stride(1) == 1
+    rows = q.shape[0]
+    qa = (C.c_int32 * (2 * n))(*[int(v) for r in q_ranges for v in r])
+    ka = (C.c_int32 * (2 * n))(*[int(v) for r in k_ranges for v in r])
+    ks = kv.struct()
+    d = heads * 128
+    flops = sum(4.0 * (qe - qs) * (ke - kb) * d for (qs, qe), (kb, ke) in zip(q_ranges, k_ranges))
+    with _timed(tag, flops, 0.0):
+        _hip.check(_hip.load().ifx_attn_fwd_ranges(_dev(q, "q"), q.stride(0), _dev(out, "out"), out.stride(0), C.byref(ks), rows, heads,
+                                                   n, qa, ka, float(scale), _stream()), "ifx_attn_fwd_ranges")
+    return out

@@ -120,11 +120,7 @@ class HipFullyParallelAttention:
                                k_out=handle.view.k, v_out=handle.view.v, kv_head_stride=self.hd, ld_kv=self.hk * self.hd,
                                row0=row0, split=split, row1=row1, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
                                xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
-            for i in range(meta_args.denoising_range_num):
-                qs, qe, ks, ke = int(cq[i, 0]), int(cq[i, 1]), int(ck[i, 0]), int(ck[i, 1])
-                if ke > handle.kv_len:
-                    raise ValueError(f"k_range[{i}] = [{ks}, {ke}) exceeds the {handle.kv_len} available keys")
-                ops.attention_ld(q_buf[qs:qe], handle.view, ke, attn_cat[qs:qe], self.hq, kv_start=ks, tag="attn_magi")
+            _range_attention(q_buf, handle, cq, ck, meta_args.denoising_range_num, attn_cat, self.hq)
         else:
             self._ulysses(mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p)
         # ---- cross-attention on the caption tokens (:954-970, :1047-1085); the local tokens attend the whole caption
@@ -156,10 +152,7 @@ class HipFullyParallelAttention:
 
         def core(qc, key, value):
             out = torch.empty_like(qc)
-            hq_c = qc.shape[1]
-            for i in range(meta_args.denoising_range_num):
-                qs, qe, ks, ke = int(cq[i, 0]), int(cq[i, 1]), int(ck[i, 0]), int(ck[i, 1])
-                ops.attention(qc[qs:qe], key.view, ke, out=out[qs:qe], kv_start=ks, tag="attn_magi")
+            _range_attention(qc.view(qc.shape[0], -1), key, cq, ck, meta_args.denoising_range_num, out.view(qc.shape[0], -1), qc.shape[1])
             return out
         Q = self.hq * self.hd
         core_out, _ = cpl.UlyssesScheduler.get_attn_and_xattn_with_fused_kv_comm(
@@ -167,6 +160,22 @@ class HipFullyParallelAttention:
             lambda kv: (self.kv_cache_manager.adjust_key_and_value_for_inference(kv, inference_params, meta_args),) * 2,
             core, lambda: None, getattr(self.engine_config, "ulysses_overlap_degree", 1), 1, cp, sizes)
         attn_cat[:, :Q].copy_(core_out.view(s_len, Q))
+
+
+def _range_attention(q2d: torch.Tensor, handle, q_range, k_range, n: int, out2d: torch.Tensor, heads: int) -> None:
+    """core_attention (:972-1015): per denoising range, queries attend their key range of the in-place cache.  Launches whose
+    single ranges would leave the chip half empty (a rank's 3 query heads) go out as ONE multi-range launch."""
+    qr = [(int(q_range[i, 0]), int(q_range[i, 1])) for i in range(n)]
+    kr = [(int(k_range[i, 0]), int(k_range[i, 1])) for i in range(n)]
+    for i, (ks, ke) in enumerate(kr):
+        if ke > handle.kv_len:
+            raise ValueError(f"k_range[{i}] = [{ks}, {ke}) exceeds the {handle.kv_len} available keys")
+    rows = max(qe - qs for qs, qe in qr)
+    if 1 < n <= 8 and rows >= 1024 and min(ke - ks for ks, ke in kr) > 1024:
+        ops.attention_ranges(q2d, handle.view, qr, kr, out2d, heads, tag="attn_magi")
+        return
+    for (qs, qe), (ks, ke) in zip(qr, kr):
+        ops.attention_ld(q2d[qs:qe], handle.view, ke, out2d[qs:qe], heads, kv_start=ks, tag="attn_magi")
 
 
 def _cross_segments(xp):

@@ -206,6 +206,31 @@ def test_strided_attention_matches_dense():
         assert bool((wide_o[:, :hq * 128] == 7.0).all())
 
 
+def test_multi_range_attention_equals_per_range_launches():
+    """ifx_attn_fwd_ranges: the four denoising ranges of a MAGI forward (one rank: 3 q-heads on 1 kv-head; and all 24 / 8 heads)
+    in one launch, ranges of unequal length with ragged tiles, equal the per-range launches bit for bit when those do not split
+    keys, and to flash-attention noise when they do; rows outside every range stay untouched."""
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(8)
+    for hq, hk, clip in ((3, 1, 2025), (24, 8, 1300)):
+        nk = 5 * clip
+        rows = 4 * clip + 77
+        q = torch.randn(rows, hq * 128, generator=g).to(BF).cuda()
+        k = torch.randn(nk, hk, 128, generator=g).to(BF).cuda()
+        v = torch.randn(nk, hk, 128, generator=g).to(BF).cuda()
+        view = ops.KvCacheView(k, v)
+        qr = [(i * clip, (i + 1) * clip) for i in range(4)]
+        kr = [(0, 2 * clip), (clip, 3 * clip + 11), (0, 4 * clip), (0, 5 * clip)]
+        out = torch.full((rows, hq * 128), 3.0, dtype=BF, device="cuda")
+        ops.attention_ranges(q, view, qr, kr, out, hq)
+        ref = torch.full_like(out, 3.0)
+        for (qs, qe), (ks, ke) in zip(qr, kr):
+            ref[qs:qe] = ops.attention(q[qs:qe].view(-1, hq, 128).contiguous(), view, ke, kv_start=ks, splits=1).view(qe - qs, -1)
+        assert torch.equal(out[4 * clip:], ref[4 * clip:]), "rows outside the ranges were written"
+        assert rel_l2(out, ref) < 2e-3
+        assert_bf16_parity(out, ref, max_ulp=4, max_mismatch_frac=0.3, rel=2e-3, what="multi-range vs per-range")
+
+
 def test_static_and_per_tensor_quantisers_vs_reference_golden():
     """ifx_quant_static with the bf16 intermediate == the reference's div_clamp_to bytes (tests/golden/quant_fp8.npz, generated by
     importing inferix/models/magi/dit/dit_module.py); the static-scale FP8 linears on ifx_gemm_q8 against the reference modules'
