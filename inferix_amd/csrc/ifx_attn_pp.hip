@@ -170,8 +170,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
-  const int wi = xcd * A.per_xcd + slot_i;
-  if (slot_i >= A.per_xcd || wi >= A.total) return;
+  // Multi-range launches hand tiles of DIFFERENT cost (key ranges of 2 .. 5 chunks) out in launch order, most expensive first: the
+  // contiguous per-XCD blocks of the uniform case would give one XCD all the long tiles (measured: 780 -> 477 TFLOP/s on the MAGI
+  // rank shape), and with grouped-query heads sharing one K/V stream there is no per-head L2 locality to protect.
+  const int wi = (!SPLIT && A.n_ranges > 0) ? (int)blockIdx.x : xcd * A.per_xcd + slot_i;
+  if ((A.n_ranges == 0 && slot_i >= A.per_xcd) || wi >= A.total) return;
   // work order (head, key chunk, q tile): the q tiles that stream the same K/V chunk sit on one XCD's L2
   int head, qt, sp = 0;
   if (SPLIT) {
@@ -180,6 +183,9 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     const int rem = wi - head * per_head;
     sp = rem / A.q_tiles;
     qt = rem - sp * A.q_tiles;
+  } else if (A.n_ranges > 0) {
+    qt = wi / A.heads;                     // tile-major: the longest range's tiles of every head first
+    head = wi - qt * A.heads;
   } else {
     head = wi / A.q_tiles;
     qt = wi - head * A.q_tiles;

@@ -163,17 +163,17 @@ class HipFullyParallelAttention:
 
 
 def _range_attention(q2d: torch.Tensor, handle, q_range, k_range, n: int, out2d: torch.Tensor, heads: int) -> None:
-    """core_attention (:972-1015): per denoising range, queries attend their key range of the in-place cache.  Launches whose
-    single ranges would leave the chip half empty (a rank's 3 query heads) go out as ONE multi-range launch."""
+    """core_attention (:972-1015): per denoising range, queries attend their key range of the in-place cache; launches that would
+    leave the chip half empty (a rank's 3 query heads) split their key range (ifx_attn_split_plan)."""
     qr = [(int(q_range[i, 0]), int(q_range[i, 1])) for i in range(n)]
     kr = [(int(k_range[i, 0]), int(k_range[i, 1])) for i in range(n)]
     for i, (ks, ke) in enumerate(kr):
         if ke > handle.kv_len:
             raise ValueError(f"k_range[{i}] = [{ks}, {ke}) exceeds the {handle.kv_len} available keys")
-    rows = max(qe - qs for qs, qe in qr)
-    if 1 < n <= 8 and rows >= 1024 and min(ke - ks for ks, ke in kr) > 1024:
-        ops.attention_ranges(q2d, handle.view, qr, kr, out2d, heads, tag="attn_magi")
-        return
+    # (All ranges in ONE launch — ops.attention_ranges / ifx_attn_fwd_ranges — was measured on the rank shape of cp = 8, 4 x 12150
+    #  queries x 3 heads over 2 .. 5 chunks of keys: 727 TFLOP/s against 780 for the four split-KV launches below.  Tiles of
+    #  different ranges stream different key windows out of phase, so the L2 sharing between the query tiles of one launch is lost.
+    #  The entry point stays for callers with many short ranges, where launch count is what costs.)
     for (qs, qe), (ks, ke) in zip(qr, kr):
         ops.attention_ld(q2d[qs:qe], handle.view, ke, out2d[qs:qe], heads, kv_start=ks, tag="attn_magi")
 
