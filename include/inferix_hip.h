@@ -65,7 +65,7 @@ int ifx_set_option(const char* key, int32_t value);
  * [num_slots][kv_heads][head_dim] bf16, token-major (manager tensor
  * (2, num_blocks, block_size, kv_heads, head_dim), kvcache_manager.py:222-244).
  * Logical token t lives in physical slot
- *     page_table ? page_table[t / page_size] * page_size + t % page_size : t
+ *     page_table ? page_table[t / page_size] * page_size + t % page_size : t     (or the two-segment map below)
  * so sink+rolling eviction (causal_model.py:282-300) is a page-table rotation
  * instead of a data move whenever the evicted span is page-aligned.
  * ---------------------------------------------------------------------- */
@@ -77,6 +77,12 @@ typedef struct {
   int32_t num_slots;           /* capacity in tokens */
   int32_t kv_heads;
   int32_t head_dim;            /* 128 */
+  /* Two-segment map for readers (the attention entry points), used when page_table == NULL and seg_split > 0: logical token
+   * t < seg_split lives in slot t, t >= seg_split in slot t + seg_delta.  MAGI's cache rule leaves the rows of a forward that the
+   * rule does not store outside the cache proper (inferix/kvcache_manager/model/magi_kv_cache_manager.py:76-187): here they sit in
+   * a scratch tail of the same allocation and this map splices them behind the prefix without a per-token table.  0 = off. */
+  int32_t seg_split;
+  int32_t seg_delta;
 } ifx_kv_view;
 
 /* ------------------------------------------------------------------------

@@ -34,7 +34,7 @@ class KvView(C.Structure):
     """ifx_kv_view"""
     _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("page_table", C.c_void_p),
                 ("page_size", C.c_int32), ("num_slots", C.c_int32), ("kv_heads", C.c_int32),
-                ("head_dim", C.c_int32)]
+                ("head_dim", C.c_int32), ("seg_split", C.c_int32), ("seg_delta", C.c_int32)]
 
 
 class RopeGrid(C.Structure):

@@ -451,7 +451,7 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
   a.lse = lse;
   a.k = kv->k;
   a.v = kv->v;
-  a.ka = KvAddr{kv->page_table, kv->page_size};
+  a.ka = KvAddr{kv->page_table, kv->page_size, kv->page_table ? 0 : kv->seg_split, kv->page_table ? 0 : kv->seg_delta};
   a.q_rows = q_rows;
   a.heads = heads;
   a.ldq = ldq;
@@ -468,7 +468,7 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
 
   const dim3 grid(a.per_xcd * 8), block(256);
   const bool short_kv = kv_len - kv_start <= 1024;
-  if (kv->page_table) {
+  if (kv->page_table || kv->seg_split > 0) {
     if (short_kv) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
   } else {

@@ -1071,7 +1071,7 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.lse = lse;
   a.k = kv->k;
   a.v = kv->v;
-  a.ka = KvAddr{kv->page_table, kv->page_size};
+  a.ka = KvAddr{kv->page_table, kv->page_size, kv->page_table ? 0 : kv->seg_split, kv->page_table ? 0 : kv->seg_delta};
   a.q_rows = q_rows;
   a.heads = heads;
   a.ldq = ldq > 0 ? ldq : heads * 128;
@@ -1126,11 +1126,11 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
     set_error("ifx_attn_fwd_paged_split: split / partial launches need a workspace");
     return IFX_EINVAL;
   }
-  if (fr_mode == 3) launch_pp_dual(a, kv->page_table != nullptr, write_partials, grid, stream);
-  else if (fr_mode == 2) launch_pp_fr<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
-  else if (fr_mode == 1) launch_pp_fr<1>(a, kv->page_table != nullptr, write_partials, grid, stream);
-  else if (groups == 3) launch_pp_ng<3>(a, kv->page_table != nullptr, write_partials, grid, stream);
-  else launch_pp_ng<2>(a, kv->page_table != nullptr, write_partials, grid, stream);
+  if (fr_mode == 3) launch_pp_dual(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else if (fr_mode == 2) launch_pp_fr<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else if (fr_mode == 1) launch_pp_fr<1>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else if (groups == 3) launch_pp_ng<3>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else launch_pp_ng<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   if (slots_used) *slots_used = a.splits;
   if (!partial && a.splits > 1) {
     const int pairs = q_rows * heads;

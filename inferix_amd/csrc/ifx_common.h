@@ -47,8 +47,9 @@ __device__ __forceinline__ float wave_max(float v) {
 struct KvAddr {
   const int32_t* pt;
   int32_t ps;
+  int32_t seg_split, seg_delta;   // no table: logical tokens >= seg_split (when > 0) live seg_delta slots further on (ifx_kv_view)
   __device__ __forceinline__ int slot(int t) const {
-    if (pt == nullptr) return t;
+    if (pt == nullptr) return (seg_split > 0 && t >= seg_split) ? t + seg_delta : t;
     int pg = t / ps;
     return pt[pg] * ps + (t - pg * ps);
   }

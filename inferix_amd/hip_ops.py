@@ -127,10 +127,13 @@ class KvCacheView:
     v: torch.Tensor
     page_table: Optional[torch.Tensor] = None
     page_size: int = 1
+    seg_split: int = 0          # two-segment map (no table): logical tokens >= seg_split live seg_delta slots further on
+    seg_delta: int = 0
 
     def struct(self) -> _hip.KvView:
         # checked and marshalled once per (k, v, page table): a layer's view is reused by every forward
-        key = (self.k.data_ptr(), self.v.data_ptr(), None if self.page_table is None else self.page_table.data_ptr(), self.page_size)
+        key = (self.k.data_ptr(), self.v.data_ptr(), None if self.page_table is None else self.page_table.data_ptr(), self.page_size,
+               self.seg_split, self.seg_delta)
         memo = self.__dict__.get("_memo")
         if memo is not None and memo[0] == key:
             return memo[1]
@@ -138,8 +141,9 @@ class KvCacheView:
         pt = 0
         if self.page_table is not None:
             pt = _dev(self.page_table, "page_table", torch.int32)
+        assert not (self.seg_split and self.page_table is not None), "a view has a page table or a two-segment map, not both"
         st = _hip.KvView(_dev(self.k, "kv.k"), _dev(self.v, "kv.v"), pt, int(self.page_size),
-                         self.k.shape[0], self.k.shape[1], self.k.shape[2])
+                         self.k.shape[0], self.k.shape[1], self.k.shape[2], int(self.seg_split), int(self.seg_delta))
         self.__dict__["_memo"] = (key, st)
         return st
 

@@ -37,6 +37,8 @@ class MagiKvHandle:
         if self.view.page_table is not None:
             ps = self.view.page_size
             t = self.view.page_table.long()[t // ps] * ps + t % ps
+        elif self.view.seg_split:
+            t = torch.where(t >= self.view.seg_split, t + self.view.seg_delta, t)
         return self.view.k[t].contiguous(), self.view.v[t].contiguous()
 
 
@@ -124,8 +126,11 @@ class MagiKVCacheManager:
             stored = n - meta_args.clip_token_nums * B if meta_args.distill_nearly_clean_chunk else n
             assert start + stored <= capacity, "KV cache overflow"
         kc, vc = raw[0, :, 0], raw[1, :, 0]
-        table = self._token_map(raw.device, start, stored, n - stored, capacity)
-        return MagiKvHandle(ops.KvCacheView(kc, vc, table, 1), start + n, hn), (start, stored, capacity)
+        # logical keys [0, start + stored) are in place, the n - stored unstored rows sit in the scratch tail at [capacity, ...):
+        # a two-segment map (no per-token table: the attention kernel's paged address path does one dependent load per key row)
+        unstored = n - stored
+        view = ops.KvCacheView(kc, vc, None, 1, start + stored if unstored else 0, capacity - (start + stored) if unstored else 0)
+        return MagiKvHandle(view, start + n, hn), (start, stored, capacity)
 
     def adjust_key_and_value_for_inference(self, key_and_value: torch.Tensor, inference_params: Optional[InferenceParams],
                                            meta_args: ModelMetaArgs) -> MagiKvHandle:

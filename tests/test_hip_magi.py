@@ -98,7 +98,7 @@ def test_attention_over_cache_with_unstored_tail():
     q_range, k_range = [[0, clip], [clip, 2 * clip]], [[0, 3 * clip], [clip, 4 * clip]]
     m1 = _meta(q_range, k_range, slice_point=2, distill_nearly_clean_chunk=True, clip_token_nums=clip)
     handle = mgr.adjust_key_and_value_for_inference(kv1.cuda(), ip, m1)
-    assert handle.view.page_table is not None and handle.kv_len == 4 * clip
+    assert handle.view.page_table is None and handle.view.seg_split == 3 * clip and handle.kv_len == 4 * clip     # two-segment map
     out = core_attention(q.cuda(), handle, None, 1, m1)
     kr, vr = oracle.adjust(kv1, slice_point=2, clip_token_nums=clip, update_kv_cache=True, distill_nearly_clean_chunk=True)
     ref = M.core_attention(q, kr, vr, q_range, k_range, out_dtype=torch.float64)
