@@ -126,6 +126,15 @@ int ifx_attn_fwd_paged_ld(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t
                           int32_t q_rows, int32_t heads, int32_t kv_start, int32_t kv_len, float scale, int32_t num_splits,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Attention over keys [0, kv_len) in which the LAST key stands for `last_key_multiplicity` identical (key, value) rows:
+ *   out = softmax over the kv_len - 1 + multiplicity implied keys — computed by adding ln(multiplicity) to the last key's score.
+ * Cross-attention of the block (inferix/models/wan_base/model.py:66-100) runs over text_len = 512 context rows of which all but
+ * the prompt's own tokens are the zero-padding (causal_model.py:948-953): those rows are identical after `text_embedding`, so are
+ * their K and V rows in every layer, and 512 keys become n_prompt + 1 — one 64-key tile instead of eight.  Exact algebra; the
+ * implied keys' probabilities are rounded to bf16 once (as one product) instead of `multiplicity` times.  kv_len <= 1024. */
+int ifx_attn_fwd_dedup(const ifx_bf16* q, ifx_bf16* out, const ifx_kv_view* kv, int32_t q_rows, int32_t heads, int32_t kv_len,
+                       int32_t last_key_multiplicity, float scale, void* stream);
+
 /* Several (query range, key range) pairs of one cache in ONE launch — MAGI's core_attention (inferix/models/magi/dit/dit_module.py:
  * 972-1015): per denoising range i, queries [q_ranges[i][0], q_ranges[i][1]) attend keys [k_ranges[i][0], k_ranges[i][1]), no mask
  * inside a range.  One rank of cp = 8 has 3 query heads: a single range is 144 workgroups for 256 CUs, four ranges together fill

@@ -47,6 +47,7 @@ struct AttnArgs {
   KvAddr ka;
   int q_rows, heads, kv_start, kv_len, q_tiles, per_xcd, total;   // keys [kv_start, kv_len)
   int ldq, ldo;             // elements between consecutive rows of q / out
+  float last_key_bias;      // added to the RAW score of the last key (ln(multiplicity) / scale): that key stands for `multiplicity` identical ones
   int kv_heads, q_per_kv;   // grouped-query attention: query head h reads kv head h / q_per_kv
   float scale, scale_log2;
 };
@@ -239,8 +240,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
       if (RAGGED) {
         const int kidx = t * KT + 32 * b + 4 * hi;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kidx + (r & 3) + 8 * (r >> 2) >= nkeys) sb[r] = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kidx + (r & 3) + 8 * (r >> 2);
+          if (kk >= nkeys) sb[r] = -INFINITY;
+          else if (kk == nkeys - 1) sb[r] += A.last_key_bias;     // a key that stands for several identical ones (0 otherwise)
+        }
       }
       if (t == 0 && b == 0) m_run = block_max(sb);       // O and l are still zero: nothing to rescale
       float ps = exp_block(sb, pb);
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs A) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if (nkeys & (KT - 1)) tile(NT - 1, (NT - 1) & 1, std::true_type{});
+  if ((nkeys & (KT - 1)) || A.last_key_bias != 0.f) tile(NT - 1, (NT - 1) & 1, std::true_type{});
   else tile(NT - 1, (NT - 1) & 1, std::false_type{});
 
   // ---------------- epilogue ----------------
@@ -421,7 +425,7 @@ using namespace ifx;
 
 static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx_kv_view* kv, int32_t q_rows,
                          int32_t heads, int32_t kv_start, int32_t kv_len, float scale, int32_t splits, void* workspace,
-                         int64_t workspace_bytes, void* stream, int32_t ldq = 0, int32_t ldo = 0) {
+                         int64_t workspace_bytes, void* stream, int32_t ldq = 0, int32_t ldo = 0, int32_t last_key_multiplicity = 1) {
   IFX_REQUIRE(q && out && kv && kv->k && kv->v, "ifx_attn_fwd_paged: null argument");
   if (ldq <= 0) ldq = heads * HD;
   if (ldo <= 0) ldo = heads * HD;
@@ -435,6 +439,10 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
   if (kv->page_table) IFX_REQUIRE(kv->page_size > 0, "ifx_attn_fwd_paged: page_size must be > 0");
   if (q_rows == 0) return IFX_OK;
   const int variant = attn_variant();
+  if (last_key_multiplicity > 1) {
+    IFX_REQUIRE(splits <= 1 && kv_len - kv_start <= 1024 && lse == nullptr,
+                "ifx_attn_fwd_dedup: the multiplicity form is built for short key ranges (<= 1024 keys), unsplit, without LSE");
+  }
   if (splits > 1) {
     IFX_REQUIRE(workspace && workspace_bytes >= (int64_t)attn_pp_workspace_bytes(q_rows, heads, splits),
                 "ifx_attn_fwd_paged_split: workspace of %lld B too small for %d splits (need %lld B)",
@@ -442,7 +450,7 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
     return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, splits, workspace, attn_groups(variant, q_rows, heads),
                           (hipStream_t)stream, 0, 0, nullptr, ldq, ldo);
   }
-  if (variant >= 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024))
+  if (last_key_multiplicity <= 1 && (variant >= 2 || (variant == 0 && q_rows >= 1024 && kv_len - kv_start > 1024)))
     return launch_attn_pp(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, 1, nullptr, attn_groups(variant, q_rows, heads),
                           (hipStream_t)stream, 0, 0, nullptr, ldq, ldo);
   AttnArgs a;
@@ -465,6 +473,7 @@ static int attn_dispatch(const ifx_bf16* q, ifx_bf16* out, float* lse, const ifx
   a.per_xcd = (a.total + 7) / 8;
   a.scale = scale > 0.f ? scale : 0.08838834764831845f;   // 1/sqrt(128)
   a.scale_log2 = a.scale * 1.4426950408889634f;
+  a.last_key_bias = last_key_multiplicity > 1 ? logf((float)last_key_multiplicity) / a.scale : 0.f;
 
   const dim3 grid(a.per_xcd * 8), block(256);
   const bool short_kv = kv_len - kv_start <= 1024;
@@ -491,6 +500,12 @@ extern "C" int ifx_attn_fwd_paged_ld(const ifx_bf16* q, int32_t ldq, ifx_bf16* o
   IFX_REQUIRE(ldq > 0 && ldo > 0, "ifx_attn_fwd_paged_ld: row strides must be given");
   return attn_dispatch(q, out, lse, kv, q_rows, heads, kv_start, kv_len, scale, num_splits, workspace, workspace_bytes, stream,
                        ldq, ldo);
+}
+
+extern "C" int ifx_attn_fwd_dedup(const ifx_bf16* q, ifx_bf16* out, const ifx_kv_view* kv, int32_t q_rows, int32_t heads,
+                                  int32_t kv_len, int32_t last_key_multiplicity, float scale, void* stream) {
+  IFX_REQUIRE(last_key_multiplicity >= 1, "ifx_attn_fwd_dedup: multiplicity %d", last_key_multiplicity);
+  return attn_dispatch(q, out, nullptr, kv, q_rows, heads, 0, kv_len, scale, 1, nullptr, 0, stream, 0, 0, last_key_multiplicity);
 }
 
 extern "C" int ifx_attn_fwd_ranges(const ifx_bf16* q, int32_t ldq, ifx_bf16* out, int32_t ldo, const ifx_kv_view* kv, int32_t q_rows,

@@ -683,3 +683,17 @@ def attention_ranges(q: torch.Tensor, kv: KvCacheView, q_ranges, k_ranges, out: 
         _hip.check(_hip.load().ifx_attn_fwd_ranges(_dev(q, "q"), q.stride(0), _dev(out, "out"), out.stride(0), C.byref(ks), rows, heads,
                                                    n, qa, ka, float(scale), _stream()), "ifx_attn_fwd_ranges")
     return out
+
+
+def attention_dedup(q: torch.Tensor, kv: KvCacheView, kv_len: int, last_key_multiplicity: int, out: Optional[torch.Tensor] = None,
+                    scale: float = 0.0, tag: str = "attn") -> torch.Tensor:
+    """Attention over keys [0, kv_len) whose LAST key stands for `last_key_multiplicity` identical rows (ifx_attn_fwd_dedup)."""
+    assert q.dim() == 3 and q.is_contiguous()
+    rows, heads, hd = q.shape
+    out = torch.empty_like(q) if out is None else out
+    ks = kv.struct()
+    nk = kv_len - 1 + last_key_multiplicity
+    with _timed(tag, 4.0 * rows * nk * heads * hd, 0.0):
+        _hip.check(_hip.load().ifx_attn_fwd_dedup(_dev(q, "q"), _dev(out, "out"), C.byref(ks), rows, heads, int(kv_len),
+                                                  int(last_key_multiplicity), float(scale), _stream()), "ifx_attn_fwd_dedup")
+    return out

@@ -128,6 +128,10 @@ class HipCausalWanModel(torch.nn.Module):
         self.mod_all: Optional[torch.Tensor] = None  # [L, 1, 6, dim]
         self.freqs = C.rope_table(self.head_dim).to(self.device_)     # [1024, 64, 2] fp64
         self._scratch: Dict[Tuple, torch.Tensor] = {}
+        # cross-attention over zero-padded prompts: request id -> (keys kept, multiplicity of the last one); `cross_dedup = False`
+        # attends all text_len keys as the reference does (same mathematics, different rounding of the padded keys' weight)
+        self.cross_dedup = True
+        self._cross_dedup: Dict[str, Tuple[int, int]] = {}
         self._roll_scratch: Optional[torch.Tensor] = None
         self.cp = None                                # set by inferix_amd.sequence_parallel when world_size > 1
 
@@ -346,8 +350,13 @@ class HipCausalWanModel(torch.nn.Module):
                 kx = self._lin(w, "ck", cb)
                 ops.rmsnorm(kx, w["cnk"], self.eps, out=cview.k.view(self.text_len, d))
                 self._lin(w, "cv", cb, out=cview.v.view(self.text_len, d))
-            ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), cview, self.text_len,
-                          out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
+            nkeys, mult = self._cross_dedup.get(req.request_id, (self.text_len, 1)) if self.cross_dedup else (self.text_len, 1)
+            if mult > 1:      # the zero-padded context rows are ONE key with a multiplicity (ifx_attn_fwd_dedup)
+                ops.attention_dedup(qb[b * N:(b + 1) * N].view(N, H, hd), cview, nkeys, mult,
+                                    out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
+            else:
+                ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), cview, self.text_len,
+                              out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
         cmeta["is_init"] = True
         self._lin(w, "co", ab, epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
         # ---------------- feed forward ----------------
@@ -417,6 +426,16 @@ class HipCausalWanModel(torch.nn.Module):
                 context = list(context)
             padded = torch.stack([torch.cat([u.to(dev, BF16), torch.zeros(self.text_len - u.size(0), u.size(1),
                                                                        device=dev, dtype=BF16)]) for u in context])
+            if self.cross_dedup:
+                # rows behind the prompt's own tokens are the zero padding: identical inputs -> identical text_embedding rows ->
+                # identical K / V rows in every layer.  Count the trailing run once per prompt (one host read per request and
+                # cache initialisation); cross-attention then runs over the distinct rows + one key with that multiplicity.
+                same = (padded == padded[:, -1:]).all(-1)                        # [B, text_len]
+                idx = torch.arange(self.text_len, device=dev).expand(B, -1)
+                first = (torch.where(same, -1, idx).amax(1) + 1).tolist()         # first row of the trailing identical run
+                for b, req in enumerate(kv_cache_requests or []):
+                    j0 = min(int(first[b]), self.text_len - 1)
+                    self._cross_dedup[req.request_id] = (j0 + 1, self.text_len - j0)
             c0 = ops.linear(padded.view(B * self.text_len, -1), self.g["text0_w"], self.g["text0_b"],
                             epilogue=_hip.IFX_EPI_GELU_TANH)
             ctx = ops.linear(c0, self.g["text2_w"], self.g["text2_b"])           # [B*text_len, d]

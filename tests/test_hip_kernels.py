@@ -289,6 +289,30 @@ def test_attention_480p_long_prefixes_vs_fp64_oracle(ops, kv_len, paged):
     assert (lse[:, sel.cuda()].cpu().double() - lse64[0]).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("distinct,total", [(40, 512), (63, 512), (64, 512), (1, 512), (200, 1024), (511, 512)])
+def test_attention_dedup_equals_attention_over_the_repeated_keys(ops, distinct, total):
+    """ifx_attn_fwd_dedup (cross-attention over a zero-padded prompt): `distinct` keys followed by ONE key of multiplicity
+    total - distinct equals plain attention over the `total` keys in which that row is repeated — against the fp64 oracle and
+    against the plain kernel on the explicit keys."""
+    g = torch.Generator().manual_seed(distinct + total)
+    rows, heads, hd = 4680 if total == 512 else 300, 12, 128
+    q = rnd(g, rows, heads, hd)
+    k = rnd(g, total, heads, hd)
+    v = rnd(g, total, heads, hd)
+    k[distinct:] = k[distinct]
+    v[distinct:] = v[distinct]
+    view = ops.KvCacheView(gpu(k), gpu(v))
+    got = ops.attention_dedup(gpu(q), view, distinct + 1, total - distinct)
+    plain = ops.attention(gpu(q), view, total)
+    sel = torch.arange(0, rows, max(rows // 96, 1))[:96]
+    ref64 = O.attention(q[sel][None], k[None], v[None], impl="math")[0]
+    e_d, e_p = rel_l2(got[sel.cuda()].cpu(), ref64), rel_l2(plain[sel.cuda()].cpu(), ref64)
+    assert e_d <= 1.25 * e_p + 5e-4, (e_d, e_p)          # as close to exact attention as the plain kernel
+    assert rel_l2(got.cpu(), plain.cpu()) < 3e-3
+    if distinct == total - 1:                              # multiplicity 1: the same launch as the plain kernel
+        assert torch.equal(got, plain)
+
+
 def test_attention_softmax_spike(ops):
     """Online-softmax rescale path: one key dominates late in the sequence (guide §5.4 rule 26)."""
     g = torch.Generator().manual_seed(3)
