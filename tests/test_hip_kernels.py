@@ -308,7 +308,8 @@ def test_attention_dedup_equals_attention_over_the_repeated_keys(ops, distinct, 
     ref64 = O.attention(q[sel][None], k[None], v[None], impl="math")[0]
     e_d, e_p = rel_l2(got[sel.cuda()].cpu(), ref64), rel_l2(plain[sel.cuda()].cpu(), ref64)
     assert e_d <= 1.25 * e_p + 5e-4, (e_d, e_p)          # as close to exact attention as the plain kernel
-    assert rel_l2(got.cpu(), plain.cpu()) < 3e-3
+    # two evaluations with bf16 probabilities: the repeated key's weight is rounded once here and `multiplicity` times there
+    assert rel_l2(got.cpu(), plain.cpu()) < 6e-3
     if distinct == total - 1:                              # multiplicity 1: the same launch as the plain kernel
         assert torch.equal(got, plain)
 
