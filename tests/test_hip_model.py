@@ -348,6 +348,8 @@ def test_block_full_size_vs_reference_golden(case):
     # elements land 2 ULP from the reference's (1 ULP holds on the small-grid fixture above)
     assert_bf16_parity(raw[0, start + sel.cuda(), 0], fx[f"c{case}_k_rows"], max_ulp=2, max_mismatch_frac=0.01, floor=1.0,
                        what="cache K rows (post-RoPE)")
-    assert_bf16_parity(raw[1, start + sel.cuda(), 0], fx[f"c{case}_v_rows"], max_ulp=1, floor=0.05, what="cache V rows")
+    # V is the raw GEMM output: one rounding; 2 ULP covers a flip across a binade boundary (1 in 10^3 elements differs at all)
+    assert_bf16_parity(raw[1, start + sel.cuda(), 0], fx[f"c{case}_v_rows"], max_ulp=2, max_mismatch_frac=0.01, floor=0.05,
+                       what="cache V rows")
     if start:
         assert torch.equal(raw[0, :start, 0].cpu(), d["prefix_k"]), "the prefix must not be touched"
