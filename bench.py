@@ -95,15 +95,22 @@ def pmc_traffic(shards):
     """HBM bytes per self-attention launch from the committed PMC pass (profiles/pmc_traffic.json: FETCH_SIZE /
     WRITE_SIZE of `rocprofv3 --pmc` on tools/pmc_micro.py at the clip's MEAN prefix L = 18720, N = 4680 — traffic
     is linear in L, so that launch is the clip average).  FETCH_SIZE is doubled per the gfx950 correction of
-    MI355X_MICROARCH.md §HBM.  Counters cannot be collected inside this process; null when absent / sharded."""
+    MI355X_MICROARCH.md §HBM.  Counters cannot be collected inside this process; the figure is tied to the kernel source it was
+    measured on (sha256 in the JSON) and is null when that source has changed since, when absent, or when sharded."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if shards != 1 or not os.path.exists(path):
         return {"traffic": None}
     with open(path) as f:
         t = json.load(f)["attn_self"]
+    src = os.path.join(ROOT, t.get("kernel_source", "inferix_amd/csrc/ifx_attn_pp.hip"))
+    import hashlib
+    have = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+    if t.get("kernel_source_sha256") != have:
+        return {"traffic": None, "traffic_note": "profiles/pmc_traffic.json was measured on a different ifx_attn_pp.hip: re-run "
+                                                 "tools/profile_bench.sh"}
     b = (2 * t["fetch_size_kib"] + t["write_size_kib"]) * 1024.0
     return {"traffic": round(b), "traffic_unit": "B/launch", "traffic_source": t["source"],
-            "algorithmic_bytes_per_launch": 2 * (2 * 4680 * 1536 + 2 * 18720 * 1536)}
+            "traffic_kernel_source_sha256": have[:16], "algorithmic_bytes_per_launch": 2 * (2 * 4680 * 1536 + 2 * 18720 * 1536)}
 
 
 def vae_decode_leg():

@@ -30,6 +30,16 @@ if "gemm" in which:
         ops.linear(x, wo, b1, epilogue=_hip.IFX_EPI_RESIDUAL, residual=x)
         u = ops.linear(x, w1, bf_, epilogue=_hip.IFX_EPI_GELU_TANH)
         ops.linear(u, w2, b1)
+if "w4" in which:
+    # long-K shapes of the MAGI layer (one rank of cp = 8): the four-wave register-staged tile (auto) against the eight-wave 256x256 tile
+    M, hdn, ffn = 6075, 3072, 12288
+    a, w1 = rnd(M, hdn), rnd(ffn, hdn)
+    for _ in range(reps):
+        ops.set_option("gemm_variant", 0)
+        ops.linear(a, w1, None)
+        ops.set_option("gemm_variant", 5)
+        ops.linear(a, w1, None)
+    ops.set_option("gemm_variant", 0)
 if "norm" in which:
     x = rnd(N, d)
     mod = rnd(3, 6, d)
