@@ -420,6 +420,11 @@ def main():
     ap.add_argument("--emulate-sp", type=int, default=0, metavar="P",
                     help="debug: time ONE rank of a P-way sequence-parallel run on one GPU, the K/V all-gather replaced "
                          "by a device copy (makes the result INVALID)")
+    ap.add_argument("--sp-exchange", choices=["auto", "allgather", "peer"], default="auto",
+                    help="N > 1: K/V exchange per layer — one RCCL all-gather, or direct peer stores through HIP IPC mappings; auto = peer "
+                         "stores when their self-test passes on every rank, else the all-gather")
+    ap.add_argument("--sp-fused-qkv", action="store_true", help="N > 1, debug: one fused q/k/v projection before the exchange starts "
+                                                                 "(default: K/V projection first, the exchange runs under the q projection)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -454,11 +459,39 @@ def main():
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     model, gen, pipe = build_pipeline(device, pc, a.layers or None)
+    exchange_used, rccl_ranks = None, None
     if world > 1:
-        attach_sequence_parallel(model, dist.group.WORLD)
+        from inferix_amd.sequence_parallel import PeerStoreExchange
+        # a real collective first: the rank count the line reports is what an all-gather over the group saw
+        seen = torch.empty(world, dtype=torch.int32, device=device)
+        me = torch.tensor([rank], dtype=torch.int32, device=device)
+        try:
+            dist.all_gather_into_tensor(seen, me)
+        except (RuntimeError, NotImplementedError):           # gloo builds without the flat form (the shared-GPU test mode)
+            dist.all_gather(list(seen.view(world, 1).unbind(0)), me)
+        rccl_ranks = len(set(seen.tolist()))
+        peer = None
+        if a.sp_exchange in ("auto", "peer"):
+            try:
+                peer = PeerStoreExchange(dist.group.WORLD)
+                if not peer.self_test():
+                    peer = None
+            except Exception as exc:                 # noqa: BLE001 — IPC mapping refused on this box: fall back (all ranks agree below)
+                print(f"[bench rank {rank}] peer-store exchange unavailable: {exc}", file=sys.stderr)
+                peer = None
+            votes = [None] * world
+            dist.all_gather_object(votes, peer is not None)
+            if not all(votes):
+                peer = None
+            if peer is None and a.sp_exchange == "peer":
+                raise SystemExit("--sp-exchange peer: the peer-store self-test failed")
+        exchange_used = "peer_store" if peer is not None else "allgather"
+        attach_sequence_parallel(model, dist.group.WORLD, peer=peer, kv_first=not a.sp_fused_qkv)
     elif a.emulate_sp > 1:
-        from inferix_amd.sequence_parallel import LoopbackExchange, attach_sequence_parallel
-        attach_sequence_parallel(model, exchange=LoopbackExchange(a.emulate_sp, 0))
+        from inferix_amd.sequence_parallel import LoopbackExchange, PeerStoreExchange, attach_sequence_parallel
+        peer = PeerStoreExchange(emulate_world=a.emulate_sp) if a.sp_exchange == "peer" else None
+        exchange_used = "peer_store(emulated)" if peer is not None else "allgather(emulated)"
+        attach_sequence_parallel(model, exchange=LoopbackExchange(a.emulate_sp, 0), peer=peer, kv_first=not a.sp_fused_qkv)
     if a.quant != "none":
         from inferix_amd import quant as Qz
         qc = (Qz.get_dynamic_fp8_per_token_act_per_channel_weight_qconfig() if a.quant == "fp8"
@@ -554,6 +587,7 @@ def main():
                        "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
                        "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
                        "layers": model.num_layers},
+            "rccl_ranks": rccl_ranks, "sp_exchange": exchange_used,
             "ms_per_denoise_step": round(sum(denoise_ms) / len(denoise_ms), 3),
             "ms_per_forward_by_block": per_block_ms,
             "generator_forwards_timed": forwards,

@@ -321,6 +321,43 @@ int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t evicted, int
 int ifx_kv_scatter_shards(const ifx_bf16* gathered, int32_t world, int32_t frames, int32_t hw_local,
                           int32_t frame_tokens, int32_t local_start, const ifx_kv_view* kv, void* stream);
 
+/* Sequence-parallel exchange WITHOUT a collective: every rank stores its post-RoPE K and raw V rows of the new block
+ * straight into the cache slots of every peer's replicated KV cache over xGMI.  Stands where the reference has the Ulysses
+ * all-to-all + ring p2p of inferix/models/attention/distributed.py:183-208,610-706 (and where this library's first design had one
+ * all-gather + ifx_kv_scatter_shards per layer).
+ *   ifx_peer_alloc / _free     device memory other processes can map (fine_grained != 0: visible to running kernels — flag blocks)
+ *   ifx_peer_export / _open / _close   64-byte HIP IPC handle of the allocation `ptr` lies in + the offset of `ptr` in it  <->  the
+ *                              allocation's base mapped into this process (add the offset)
+ *   ifx_rmsnorm_rope_kv_push   rows [rows, >= 2*dim] = (k | v) of the K/V-only projection: K <- RoPE(RMSNorm(k) * wk), V raw, row r
+ *                              (f = r / slot_hw_local, i = r % slot_hw_local) stored at the slot of logical token
+ *                              local_start + f*frame_tokens + slot_hw_offset + i of EVERY destination (same page table / segment map
+ *                              everywhere: `geometry` gives it, its k/v pointers are ignored).  One destination = the rank's own cache
+ *                              or staging buffer: the K/V-only form of ifx_rmsnorm_rope_kv_append.
+ *   ifx_peer_signal            flags[p][index] <- value in every peer's flag block, stream-ordered, released at system scope
+ *   ifx_peer_wait              stream-ordered wait until flags[i] >= value for i < count (this rank's own block); after timeout_ms
+ *                              the kernel gives up and stores 1 + i into *status (host checks it at a synchronisation point). */
+#define IFX_MAX_PEERS 8
+#define IFX_PEER_HANDLE_BYTES 64
+typedef struct {
+  int32_t count;
+  ifx_bf16* k[IFX_MAX_PEERS];
+  ifx_bf16* v[IFX_MAX_PEERS];
+} ifx_peer_caches;
+typedef struct {
+  int32_t count;
+  int32_t* flags[IFX_MAX_PEERS];
+} ifx_peer_flags;
+int ifx_peer_alloc(int64_t bytes, int32_t fine_grained, void** ptr);
+int ifx_peer_free(void* ptr);
+int ifx_peer_export(const void* ptr, uint8_t* handle, int64_t* offset);
+int ifx_peer_open(const uint8_t* handle, void** ptr);
+int ifx_peer_close(void* ptr);
+int ifx_rmsnorm_rope_kv_push(const ifx_bf16* kv_rows, int32_t kv_row_stride, const ifx_bf16* wk, const ifx_rope_grid* rope,
+                             const ifx_peer_caches* peers, const ifx_kv_view* geometry, int32_t local_start, int32_t frame_tokens,
+                             int32_t slot_hw_local, int32_t slot_hw_offset, int32_t rows, int32_t dim, float eps, void* stream);
+int ifx_peer_signal(const ifx_peer_flags* peers, int32_t index, int32_t value, void* stream);
+int ifx_peer_wait(const int32_t* flags, int32_t count, int32_t value, int32_t timeout_ms, int32_t* status, void* stream);
+
 /* ----------------------------------------------------------------------
  * VAE decoder: channels-last causal 3-D convolution.
  * Replaces CausalConv3d.forward + the feature-cache concatenation around it

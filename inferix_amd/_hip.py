@@ -71,6 +71,19 @@ class MagiHeadPrepDesc(C.Structure):
                 ("row0", C.c_int32), ("split", C.c_int32), ("row1", C.c_int32)]
 
 
+IFX_MAX_PEERS, IFX_PEER_HANDLE_BYTES = 8, 64
+
+
+class PeerCaches(C.Structure):
+    """ifx_peer_caches"""
+    _fields_ = [("count", C.c_int32), ("k", C.c_void_p * IFX_MAX_PEERS), ("v", C.c_void_p * IFX_MAX_PEERS)]
+
+
+class PeerFlags(C.Structure):
+    """ifx_peer_flags"""
+    _fields_ = [("count", C.c_int32), ("flags", C.c_void_p * IFX_MAX_PEERS)]
+
+
 # name -> (restype, argtypes); the complete export list of include/inferix_hip.h
 _vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
 SIGNATURES = {
@@ -88,6 +101,15 @@ SIGNATURES = {
     "ifx_t5_attention": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "ifx_t5_gated_gelu": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "ifx_kv_scatter_shards": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(KvView), _vp]),
+    "ifx_peer_alloc": (C.c_int, [C.c_int64, _i32, C.POINTER(C.c_void_p)]),
+    "ifx_peer_free": (C.c_int, [_vp]),
+    "ifx_peer_export": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
+    "ifx_peer_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ifx_peer_close": (C.c_int, [_vp]),
+    "ifx_rmsnorm_rope_kv_push": (C.c_int, [_vp, _i32, _vp, C.POINTER(RopeGrid), C.POINTER(PeerCaches), C.POINTER(KvView), _i32, _i32,
+                                           _i32, _i32, _i32, _i32, _f32, _vp]),
+    "ifx_peer_signal": (C.c_int, [C.POINTER(PeerFlags), _i32, _i32, _vp]),
+    "ifx_peer_wait": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ifx_attn_fwd_partial": (C.c_int, [_vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp, C.c_int64, _i32,
                                        _i32, C.POINTER(_i32), _vp]),
     "ifx_attn_merge_partials": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),

@@ -496,6 +496,111 @@ extern "C" int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t ld, ifx_b
   });
 }
 
+// K / V of this rank's rows of the new block, stored straight into the cache slots of EVERY peer (sequence-parallel exchange without a
+// collective: the destinations are the peers' KV caches opened through IPC handles — xGMI stores; `n_dest` = 1 with the rank's own
+// staging buffer gives the K/V-only form of rmsnorm_rope_append_kernel).  kv row = [k (dim) | v (dim)]; row r = local token
+// (f = r / hw_local, i = r % hw_local) -> logical token local_start + f * frame_tokens + hw_offset + i (the single-GPU order).
+struct PeerDest {
+  unsigned short* k[IFX_MAX_PEERS];
+  unsigned short* v[IFX_MAX_PEERS];
+  int n;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kv_push_kernel(
+    const unsigned short* __restrict__ kv, int ld, const unsigned short* __restrict__ wk, RopeArgs ra, int has_rope, PeerDest pd,
+    KvAddr ka, int local_start, int frame_tokens, int slot_hw_local, int slot_hw_offset, int rows, int dim, int head_dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const unsigned short* base = kv + (size_t)r * ld;
+  int pos_t = 0, pos_h = 0, pos_w = 0;
+  const int half = head_dim >> 1;
+  const int n_h = half / 3, n_t = half - 2 * n_h;
+  if (has_rope) {
+    const int f = r / ra.hw_local;
+    const int p = ra.hw_offset + (r - f * ra.hw_local);
+    pos_t = ra.start_frame + f;
+    pos_h = p / ra.width;
+    pos_w = p - pos_h * ra.width;
+  }
+  const int sf = r / slot_hw_local;
+  const size_t slot_off = (size_t)ka.slot(local_start + sf * frame_tokens + slot_hw_offset + (r - sf * slot_hw_local)) * dim;
+  Row<NCH> rowk;
+  u16x8 vraw[NCH];
+  rowk.load(base, dim, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col < dim) vraw[c] = *reinterpret_cast<const u16x8*>(base + dim + col);
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(rowk.sumsq()) / (float)dim + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col >= dim) continue;
+    u16x8 wv = *reinterpret_cast<const u16x8*>(wk + col);
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = rbf(rbf(rowk.v[c][i] * rs) * bf2f(wv[i]));
+    if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i]);
+    for (int p = 0; p < pd.n; ++p) {
+      *reinterpret_cast<u16x8*>(pd.k[p] + slot_off + col) = o;
+      *reinterpret_cast<u16x8*>(pd.v[p] + slot_off + col) = vraw[c];
+    }
+  }
+}
+
+extern "C" int ifx_rmsnorm_rope_kv_push(const ifx_bf16* kv_rows, int32_t ld, const ifx_bf16* wk, const ifx_rope_grid* rope,
+                                        const ifx_peer_caches* peers, const ifx_kv_view* geometry, int32_t local_start,
+                                        int32_t frame_tokens, int32_t slot_hw_local, int32_t slot_hw_offset, int32_t rows, int32_t dim,
+                                        float eps, void* stream) {
+  IFX_REQUIRE(kv_rows && wk && peers && geometry && rows >= 0 && dim > 0 && dim % 8 == 0 && ld % 8 == 0 && ld >= 2 * dim,
+              "ifx_rmsnorm_rope_kv_push: bad arguments");
+  IFX_REQUIRE(peers->count >= 1 && peers->count <= IFX_MAX_PEERS, "ifx_rmsnorm_rope_kv_push: %d destinations (1..%d)", peers->count,
+              IFX_MAX_PEERS);
+  IFX_REQUIRE(geometry->kv_heads * geometry->head_dim == dim, "ifx_rmsnorm_rope_kv_push: cache rows (heads %d x head_dim %d) != dim %d",
+              geometry->kv_heads, geometry->head_dim, dim);
+  IFX_REQUIRE(slot_hw_local > 0 && frame_tokens >= slot_hw_local && slot_hw_offset >= 0 && slot_hw_offset + slot_hw_local <= frame_tokens,
+              "ifx_rmsnorm_rope_kv_push: bad shard geometry (frame %d tokens, shard [%d, %d))", frame_tokens, slot_hw_offset,
+              slot_hw_offset + slot_hw_local);
+  if (rows == 0) return IFX_OK;
+  const int last_f = (rows - 1) / slot_hw_local;
+  const int last_token = local_start + last_f * frame_tokens + slot_hw_offset + (rows - 1 - last_f * slot_hw_local);
+  IFX_REQUIRE(local_start >= 0 && last_token < geometry->num_slots, "ifx_rmsnorm_rope_kv_push: token %d exceeds the cache capacity %d",
+              last_token, geometry->num_slots);
+  if (geometry->page_table) IFX_REQUIRE(geometry->page_size > 0, "ifx_rmsnorm_rope_kv_push: page_size must be > 0");
+  PeerDest pd{};
+  pd.n = peers->count;
+  for (int p = 0; p < pd.n; ++p) {
+    IFX_REQUIRE(peers->k[p] && peers->v[p], "ifx_rmsnorm_rope_kv_push: destination %d is null", p);
+    pd.k[p] = peers->k[p];
+    pd.v[p] = peers->v[p];
+  }
+  const int head_dim = geometry->head_dim;
+  RopeArgs ra{};
+  if (rope) {
+    IFX_REQUIRE(rope->freqs && rope->hw_local > 0 && rope->width > 0 && rope->height > 0, "ifx_rmsnorm_rope_kv_push: bad rope grid");
+    IFX_REQUIRE(head_dim % 16 == 0 && dim % head_dim == 0, "ifx_rmsnorm_rope_kv_push: head_dim %d", head_dim);
+    const int frames = (rows + rope->hw_local - 1) / rope->hw_local;
+    IFX_REQUIRE(rope->start_frame + frames <= rope->max_pos && rope->height <= rope->max_pos && rope->width <= rope->max_pos,
+                "ifx_rmsnorm_rope_kv_push: positions exceed rope table (%d)", rope->max_pos);
+    ra = RopeArgs{rope->freqs, rope->max_pos, rope->start_frame, rope->height, rope->width, rope->hw_offset, rope->hw_local};
+  }
+  const KvAddr ka{geometry->page_table, geometry->page_size, geometry->page_table ? 0 : geometry->seg_split,
+                  geometry->page_table ? 0 : geometry->seg_delta};
+  return dispatch_nch(dim, [&](auto nch) {
+    hipLaunchKernelGGL((rmsnorm_rope_kv_push_kernel<decltype(nch)::value>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       kv_rows, ld, wk, ra, rope ? 1 : 0, pd, ka, local_start, frame_tokens, slot_hw_local, slot_hw_offset, rows, dim,
+                       head_dim, eps);
+    return check_launch("ifx_rmsnorm_rope_kv_push");
+  });
+}
+
+
 extern "C" int ifx_kv_roll(const ifx_kv_view* kv, int32_t sink_tokens, int32_t evicted, int32_t rolled,
                            ifx_bf16* scratch, void* stream) {
   IFX_REQUIRE(kv && kv->k && kv->v && scratch, "ifx_kv_roll: null argument");

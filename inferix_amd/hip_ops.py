@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Sequence, Optional, Tuple
 
 import torch
 
@@ -353,6 +353,82 @@ def kv_scatter_shards(gathered: torch.Tensor, world: int, frames: int, hw_local:
     with _timed("kv_scatter", 0.0, 2.0 * gathered.numel() * 2):
         _hip.check(_hip.load().ifx_kv_scatter_shards(_dev(gathered, "gathered"), world, frames, hw_local, frame_tokens,
                                                      int(local_start), C.byref(ks), _stream()), "ifx_kv_scatter_shards")
+
+
+# ---- peer-to-peer K/V exchange (ifx_peer.hip): device memory other processes map, stream-ordered flags, the push kernel ----
+class PeerBuffer:
+    """A device allocation of libinferix_hip.so that other processes can map (`ifx_peer_alloc`); `fine_grained` for flag blocks."""
+
+    def __init__(self, nbytes: int, fine_grained: bool = False):
+        p = C.c_void_p()
+        _hip.check(_hip.load().ifx_peer_alloc(int(nbytes), 1 if fine_grained else 0, C.byref(p)), "ifx_peer_alloc")
+        self.ptr, self.nbytes = int(p.value), int(nbytes)
+
+    def free(self) -> None:
+        if self.ptr:
+            _hip.check(_hip.load().ifx_peer_free(self.ptr), "ifx_peer_free")
+            self.ptr = 0
+
+    def tensor(self, dtype: torch.dtype, shape) -> torch.Tensor:
+        """Zero-copy torch view of the allocation (the buffer must outlive it)."""
+        typestr = {torch.int32: "<i4", torch.bfloat16: "<u2", torch.uint8: "|u1", torch.float32: "<f4"}[dtype]
+        holder = type("_Cai", (), {"__cuda_array_interface__": {"shape": tuple(shape), "typestr": typestr, "data": (self.ptr, False),
+                                                                 "version": 2}, "_keep": self})()
+        t = torch.as_tensor(holder, device="cuda")
+        return t.view(torch.bfloat16) if dtype == torch.bfloat16 else t
+
+
+def peer_export(ptr: int) -> Tuple[bytes, int]:
+    """(64-byte IPC handle of the allocation `ptr` lies in, offset of `ptr` in it)."""
+    h = C.create_string_buffer(_hip.IFX_PEER_HANDLE_BYTES)
+    off = C.c_int64()
+    _hip.check(_hip.load().ifx_peer_export(int(ptr), h, C.byref(off)), "ifx_peer_export")
+    return h.raw, int(off.value)
+
+
+def peer_open(handle: bytes) -> int:
+    p = C.c_void_p()
+    _hip.check(_hip.load().ifx_peer_open(C.create_string_buffer(handle, _hip.IFX_PEER_HANDLE_BYTES), C.byref(p)), "ifx_peer_open")
+    return int(p.value)
+
+
+def peer_close(ptr: int) -> None:
+    _hip.check(_hip.load().ifx_peer_close(int(ptr)), "ifx_peer_close")
+
+
+def rmsnorm_rope_kv_push(kv_rows: torch.Tensor, wk: torch.Tensor, eps: float, rope: Optional[RopeGridSpec], dest_k: Sequence[int],
+                         dest_v: Sequence[int], geometry: KvCacheView, local_start: int, frame_tokens: int, slot_hw_local: int,
+                         slot_hw_offset: int, dim: int) -> None:
+    """K <- RoPE(RMSNorm(k) * wk), V raw, from rows `[rows, (k | v)]`, stored at the cache slots of the rows' logical tokens in every
+    destination (device addresses of caches with `geometry`'s layout: the peers' caches, or one staging buffer)."""
+    rows, cols, ld = _rows2d(kv_rows, "kv_rows")
+    assert cols >= 2 * dim and len(dest_k) == len(dest_v) and 1 <= len(dest_k) <= _hip.IFX_MAX_PEERS
+    pc = _hip.PeerCaches()
+    pc.count = len(dest_k)
+    for i, (a, b) in enumerate(zip(dest_k, dest_v)):
+        pc.k[i], pc.v[i] = int(a), int(b)
+    rs = rope.struct() if rope is not None else None
+    gs = geometry.struct()
+    with _timed("kv_push", 0.0, 2.0 * rows * dim * 2 * (1 + len(dest_k))):
+        _hip.check(_hip.load().ifx_rmsnorm_rope_kv_push(
+            _dev(kv_rows, "kv_rows"), ld, _dev(wk, "wk"), C.byref(rs) if rs is not None else None, C.byref(pc), C.byref(gs),
+            int(local_start), int(frame_tokens), int(slot_hw_local), int(slot_hw_offset), rows, dim, eps, _stream()),
+            "ifx_rmsnorm_rope_kv_push")
+
+
+def peer_signal(flag_blocks: Sequence[int], index: int, value: int) -> None:
+    """flag_blocks[p][index] <- value for every peer p, ordered after the work already on the current stream."""
+    pf = _hip.PeerFlags()
+    pf.count = len(flag_blocks)
+    for i, a in enumerate(flag_blocks):
+        pf.flags[i] = int(a)
+    _hip.check(_hip.load().ifx_peer_signal(C.byref(pf), int(index), int(value), _stream()), "ifx_peer_signal")
+
+
+def peer_wait(flags_ptr: int, count: int, value: int, timeout_ms: int, status: Optional[torch.Tensor]) -> None:
+    """The current stream waits until flags[i] >= value for all i < count (a timeout stores 1 + i into `status`)."""
+    _hip.check(_hip.load().ifx_peer_wait(int(flags_ptr), int(count), int(value), int(timeout_ms),
+                                         _dev(status, "status", torch.int32) if status is not None else None, _stream()), "ifx_peer_wait")
 
 
 def lse_merge(out_a: torch.Tensor, lse_a: torch.Tensor, out_b: torch.Tensor, lse_b: torch.Tensor) -> None:

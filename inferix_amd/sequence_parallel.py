@@ -115,14 +115,167 @@ class LoopbackExchange(SequenceParallelExchange):
         return out
 
 
-class HipSequenceParallel:
-    """GPU side: what HipCausalWanModel calls per layer when world_size > 1."""
+class PeerStoreExchange:
+    """Control plane of the exchange WITHOUT a collective: every rank stores its K/V rows of the new block straight into the cache
+    slots of every peer's replicated cache (`ifx_rmsnorm_rope_kv_push`), ordered by two per-layer flags in fine-grained peer memory
+    (`ifx_peer_signal` / `ifx_peer_wait`; protocol in csrc/ifx_peer.hip).  HIP IPC handles of the caches and flag blocks travel once
+    per cache tensor through `all_gather_object` on `group` (any backend); nothing else uses the process group per layer.
+    `emulate_world` > 0: one rank of that many, no peers — the rows are stored to `world` destinations that are all this rank's own
+    cache (the launch and the outbound bytes of a real rank; nothing arrives), for `bench.py --emulate-sp`."""
+    MAX_LAYERS = 64
+    READY, DONE = 0, 1
 
-    def __init__(self, group=None, overlap: bool = True, exchange: Optional[SequenceParallelExchange] = None):
+    def __init__(self, group=None, timeout_ms: int = 20000, emulate_world: int = 0, emulate_rank: int = 0):
+        from . import hip_ops as ops
+        from . import _hip
+        self.group = group
+        self.emulated = emulate_world > 0
+        self.world = emulate_world if self.emulated else dist.get_world_size(group)
+        self.rank = emulate_rank if self.emulated else dist.get_rank(group)
+        if self.world > _hip.IFX_MAX_PEERS:
+            raise ValueError(f"peer-store exchange is built for up to {_hip.IFX_MAX_PEERS} ranks, got {self.world}")
+        self.timeout_ms = timeout_ms
+        self._opened: Dict[bytes, int] = {}                 # IPC handle -> base address mapped into this process
+        self._views: Dict[Tuple[int, int], Tuple[List[int], List[int]]] = {}
+        self._epoch = [0] * self.MAX_LAYERS
+        self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.flags = ops.PeerBuffer(self.MAX_LAYERS * 2 * _hip.IFX_MAX_PEERS * 4, fine_grained=True)
+        self.peer_flags = [self.flags.ptr] if self.emulated else self._exchange_addresses(self.flags.ptr)
+
+    # ---- addresses ----
+    def _exchange_addresses(self, ptr: int) -> List[int]:
+        """This rank's device address `ptr` -> the same buffer of every rank, mapped into this process (rank order)."""
+        from . import hip_ops as ops
+        mine = ops.peer_export(ptr)
+        everyone: List = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        out = []
+        for p, (handle, offset) in enumerate(everyone):
+            if p == self.rank:
+                out.append(ptr)
+                continue
+            base = self._opened.get(handle)
+            if base is None:
+                base = ops.peer_open(handle)
+                self._opened[handle] = base
+            out.append(base + offset)
+        return out
+
+    def cache_addresses(self, view) -> Tuple[List[int], List[int]]:
+        """(K base, V base) of this (request, layer) cache on every rank; exchanged the first time a cache tensor is seen (a
+        collective: every rank reaches it at the same call)."""
+        key = (view.k.data_ptr(), view.v.data_ptr())
+        got = self._views.get(key)
+        if got is None:
+            if self.emulated:
+                got = ([key[0]], [key[1]])
+            else:
+                got = (self._exchange_addresses(key[0]), self._exchange_addresses(key[1]))
+            self._views[key] = got
+        return got
+
+    # ---- per layer ----
+    def _index(self, layer: int, kind: int) -> int:
+        from . import _hip
+        return (layer * 2 + kind) * _hip.IFX_MAX_PEERS
+
+    def push(self, layer: int, kv_rows: torch.Tensor, wk: torch.Tensor, eps: float, rope, view, local_start: int, frame_tokens: int,
+             dim: int) -> int:
+        """On the current stream: ready -> wait for every peer's ready -> store the rows everywhere -> done.  Returns the epoch."""
+        from . import hip_ops as ops
+        if layer >= self.MAX_LAYERS:
+            raise ValueError(f"layer {layer}: the flag block holds {self.MAX_LAYERS} layers")
+        ks, vs = self.cache_addresses(view)
+        self._epoch[layer] += 1
+        e = self._epoch[layer]
+        hw_local = rope.hw_local
+        if self.emulated:
+            # the launch a real rank issues: ONE kernel storing its rows to `world` destinations (all of them this rank's own cache
+            # here, so the peers' slots stay unwritten — timing only, bench.py marks the line INVALID)
+            ops.rmsnorm_rope_kv_push(kv_rows, wk, eps, rope, ks * self.world, vs * self.world, view, local_start, frame_tokens,
+                                     hw_local, self.rank * hw_local, dim)
+            return e
+        ops.peer_signal(self.peer_flags, self._index(layer, self.READY) + self.rank, e)
+        ops.peer_wait(self.flags.ptr + 4 * self._index(layer, self.READY), self.world, e, self.timeout_ms, self.status)
+        ops.rmsnorm_rope_kv_push(kv_rows, wk, eps, rope, ks, vs, view, local_start, frame_tokens, hw_local, self.rank * hw_local, dim)
+        ops.peer_signal(self.peer_flags, self._index(layer, self.DONE) + self.rank, e)
+        return e
+
+    def wait_done(self, layer: int, epoch: int) -> None:
+        """The current stream waits until every rank's rows of `epoch` are in this rank's cache."""
+        from . import hip_ops as ops
+        if not self.emulated:
+            ops.peer_wait(self.flags.ptr + 4 * self._index(layer, self.DONE), self.world, epoch, self.timeout_ms, self.status)
+
+    def self_test(self) -> bool:
+        """One ready / push / done round through a small scratch cache, checked on every rank and agreed on over the process group:
+        True only if every rank saw every rank's rows.  Call once after construction (collective); a False means "use the all-gather"."""
+        from . import hip_ops as ops
+        if self.emulated:
+            return True
+        ok = True
+        try:
+            H, hd, rows = 2, 128, 4
+            d = H * hd
+            dev = self.status.device
+            kc = torch.zeros(self.world * rows, H, hd, dtype=torch.bfloat16, device=dev)
+            vc = torch.zeros_like(kc)
+            view = ops.KvCacheView(kc, vc)
+            kv = torch.full((rows, 2 * d), float(self.rank + 1), dtype=torch.bfloat16, device=dev)
+            wk = torch.ones(d, dtype=torch.bfloat16, device=dev)
+            ks, vs = self.cache_addresses(view)
+            layer = self.MAX_LAYERS - 1
+            self._epoch[layer] += 1
+            e = self._epoch[layer]
+            ops.peer_signal(self.peer_flags, self._index(layer, self.READY) + self.rank, e)
+            ops.peer_wait(self.flags.ptr + 4 * self._index(layer, self.READY), self.world, e, self.timeout_ms, self.status)
+            ops.rmsnorm_rope_kv_push(kv, wk, 1e-6, None, ks, vs, view, 0, self.world * rows, rows, self.rank * rows, d)
+            ops.peer_signal(self.peer_flags, self._index(layer, self.DONE) + self.rank, e)
+            self.wait_done(layer, e)
+            torch.cuda.synchronize()
+            want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(rows)
+            ok = int(self.status.item()) == 0 and torch.equal(vc[:, 0, 0].float(), want) and bool((kc[:, 0, 0].float() > 0).all())
+        except Exception:                                      # noqa: BLE001 — any failure here means "do not use this path"
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        votes: List = [None] * self.world
+        dist.all_gather_object(votes, int(flag.item()), group=self.group)
+        self.status.zero_()
+        return all(v == 1 for v in votes)
+
+    def check(self) -> None:
+        """Raise if a wait gave up (synchronises: call at a point that synchronises anyway)."""
+        st = int(self.status.item())
+        if st:
+            raise RuntimeError(f"peer-store exchange: rank {self.rank} timed out after {self.timeout_ms} ms waiting for rank {st - 1}")
+
+    def close(self) -> None:
+        from . import hip_ops as ops
+        torch.cuda.synchronize()
+        for base in self._opened.values():
+            ops.peer_close(base)
+        self._opened.clear()
+        self._views.clear()
+        self.flags.free()
+
+
+class HipSequenceParallel:
+    """GPU side: what HipCausalWanModel calls per layer when world_size > 1.
+
+    `begin` takes the K/V-only projection of the layer's rows and starts the exchange on a side stream; the caller then computes the
+    q projection (which overlaps the exchange) and calls `finish`.  Two exchanges: one RCCL all-gather + `ifx_kv_scatter_shards`
+    (default), or direct peer stores (`peer` = a PeerStoreExchange)."""
+
+    def __init__(self, group=None, overlap: bool = True, exchange: Optional[SequenceParallelExchange] = None,
+                 peer: Optional[PeerStoreExchange] = None, kv_first: bool = True):
         self.ex = exchange if exchange is not None else SequenceParallelExchange(group)
+        self.peer = peer
+        self.kv_first = kv_first
         self.overlap = overlap
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._buf: Dict[Tuple, torch.Tensor] = {}
+        if peer is not None and (peer.world != self.ex.world or peer.rank != self.ex.rank):
+            raise ValueError("peer-store exchange and collective exchange disagree on (rank, world)")
 
     def _scratch(self, name, shape, dtype, device):
         key = (name, tuple(shape), dtype)
@@ -132,66 +285,102 @@ class HipSequenceParallel:
             self._buf[key] = b
         return b
 
-    def self_attention(self, model, l, b, view, qkv_b, q_out, a_out, w, rope, current_start, g_end, l_end,
-                       sink_tokens, mgr, req, name):
+    def begin(self, model, l, view, kv_rows, w, rope, current_start, g_end, l_end, sink_tokens, mgr, req, name) -> dict:
+        """kv_rows `[N/P, >= 2*dim]` = (k | v) of this rank's rows (any row stride).  Starts the exchange; returns the state `finish` needs."""
         from . import hip_ops as ops
         from .wan.causal_model import kv_index_update
         P = self.ex.world
-        n_local = qkv_b.shape[0]
+        n_local = kv_rows.shape[0]
         N = n_local * P
         H, hd, d = model.num_heads, model.head_dim, model.dim
-        dev = qkv_b.device
+        dev = kv_rows.device
         fs = rope.height * rope.width
         frames = n_local // rope.hw_local
         step = kv_index_update(g_end, l_end, current_start, N, view.k.shape[0], model.local_attn_size, sink_tokens)
         if step.evicted:
             model._evict(mgr, req, name, view, step)
             view = model._kv_view(mgr, req, name)
-        # this rank's K / V of the new block -> staging (laid out as a 1-page cache), q -> q_out
-        stage = self._scratch("kv_stage", (2, n_local, H, hd), torch.bfloat16, dev)
-        ops.rmsnorm_rope_kv_append(qkv_b, w["nq"], w["nk"], model.eps, rope, ops.KvCacheView(stage[0], stage[1]), 0,
-                                   d, q_out=q_out)
-        gathered = self._scratch("kv_gather", (P, 2, n_local, H, hd), torch.bfloat16, dev)
-        qv = q_out.view(n_local, H, hd)
-        av = a_out.view(n_local, H, hd)
         have_prefix = step.local_start > 0
+        side = self.overlap and dev.type == "cuda"
+        st = dict(step=step, view=view, n_local=n_local, side=side, have_prefix=have_prefix, layer=l, epoch=0)
+        main = torch.cuda.current_stream(dev) if side else None
+        if side:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=dev)
+            self.comm_stream.wait_stream(main)
 
         def exchange():
-            # one collective: [2, n_local, H, D] per rank -> [P, 2, n_local, H, D]; one kernel scatters K and V rows
-            # to their cache slots (through the page table when there is one)
+            if self.peer is not None:
+                st["epoch"] = self.peer.push(l, kv_rows, w["nk"], model.eps, rope, view, step.local_start, fs, d)
+                return
+            # this rank's K / V -> staging (a dense 1-shard cache), one collective [2, n_local, H, D] -> [P, 2, n_local, H, D], one
+            # kernel scatters K and V rows to their cache slots (through the page table when there is one)
+            stage = self._scratch("kv_stage", (2, n_local, H, hd), torch.bfloat16, dev)
+            gathered = self._scratch("kv_gather", (P, 2, n_local, H, hd), torch.bfloat16, dev)
+            sview = ops.KvCacheView(stage[0], stage[1])
+            ops.rmsnorm_rope_kv_push(kv_rows, w["nk"], model.eps, rope, [stage[0].data_ptr()], [stage[1].data_ptr()], sview, 0,
+                                     rope.hw_local, rope.hw_local, 0, d)
             self.ex.all_gather_rows(stage.view(2 * n_local, H * hd), gathered.view(P * 2 * n_local, H * hd))
             ops.kv_scatter_shards(gathered, P, frames, rope.hw_local, fs, step.local_start, view)
 
-        if self.overlap and have_prefix and dev.type == "cuda":
-            if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=dev)
-            main = torch.cuda.current_stream(dev)
-            self.comm_stream.wait_stream(main)
+        if side:
             with torch.cuda.stream(self.comm_stream):
                 exchange()
-            # main stream: attend to the old prefix while the collective is in flight; both launches write fp32 partials
-            # into one workspace and a single merge rounds to bf16 once
+        else:
+            exchange()
+        return st
+
+    def finish(self, model, st: dict, q_out, a_out) -> "KVIndexStep":
+        """q_out `[N/P, dim]` post-norm/RoPE queries -> a_out: attention over the old prefix while the exchange is in flight, then over
+        the new block; both launches write fp32 partials into one workspace and a single merge rounds to bf16 once."""
+        from . import hip_ops as ops
+        step, view, n_local = st["step"], st["view"], st["n_local"]
+        H, hd = model.num_heads, model.head_dim
+        qv = q_out.view(n_local, H, hd)
+        av = a_out.view(n_local, H, hd)
+        dev = q_out.device
+
+        def arrived():
+            if st["side"]:
+                torch.cuda.current_stream(dev).wait_stream(self.comm_stream)
+            if self.peer is not None:
+                self.peer.wait_done(st["layer"], st["epoch"])
+
+        if st["side"] and st["have_prefix"]:
             s1 = ops.attention_split_plan(n_local, H, step.local_start)
             s2 = ops.attention_split_plan(n_local, H, step.local_end - step.local_start)
             cap = s1 + s2
             ws = ops.attention_workspace(qv, cap)
             u1 = ops.attention_partial(qv, view, step.local_start, 0, s1, ws, 0, cap, tag="attn_self")
-            main.wait_stream(self.comm_stream)
+            arrived()
             u2 = ops.attention_partial(qv, view, step.local_end, step.local_start, s2, ws, u1, cap, tag="attn_self")
             ops.attention_merge(ws, cap, u1 + u2, av)
         else:
-            exchange()
+            arrived()
             ops.attention(qv, view, step.local_end, out=av, tag="attn_self")
         return step
 
+    def self_attention(self, model, l, b, view, qkv_b, q_out, a_out, w, rope, current_start, g_end, l_end,
+                       sink_tokens, mgr, req, name):
+        """Fused-projection form (8-bit linears): qkv_b `[N/P, 3*dim]` already computed."""
+        from . import hip_ops as ops
+        d = model.dim
+        st = self.begin(model, l, view, qkv_b[:, d:], w, rope, current_start, g_end, l_end, sink_tokens, mgr, req, name)
+        ops.rmsnorm_rope_kv_append(qkv_b[:, :d], w["nq"], None, model.eps, rope, None, 0, d, q_out=q_out)
+        return self.finish(model, st, q_out, a_out)
+
     def gather_head(self, y_local: torch.Tensor, batch: int, frames: int) -> torch.Tensor:
-        return self.ex.gather_head(y_local, batch, frames)
+        out = self.ex.gather_head(y_local, batch, frames)
+        if self.peer is not None and not self.peer.emulated:
+            self.peer.check()
+        return out
 
 
 def attach_sequence_parallel(model, group=None, overlap: bool = True,
-                             exchange: Optional[SequenceParallelExchange] = None) -> HipSequenceParallel:
+                             exchange: Optional[SequenceParallelExchange] = None, peer: Optional[PeerStoreExchange] = None,
+                             kv_first: bool = True) -> HipSequenceParallel:
     """Enable sequence parallelism on a HipCausalWanModel whose ParallelConfig has world_size > 1."""
-    sp = HipSequenceParallel(group, overlap, exchange)
+    sp = HipSequenceParallel(group, overlap, exchange, peer, kv_first)
     pc = model.parallel_config
     if pc.world_size != sp.ex.world or pc.rank != sp.ex.rank:
         raise ValueError(f"ParallelConfig (rank {pc.rank}/{pc.world_size}) does not match the process group "

@@ -305,14 +305,31 @@ class HipCausalWanModel(torch.nn.Module):
         ab = self._buf("a", B * N, d)
         ub = self._buf("u", B * N, self.ffn_dim)
         # ---------------- self attention ----------------
-        self._norm_lin(w, "qkv", xact, h, dict(mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group), out=qkv)
         explicit = st.get("explicit_slots")          # CausVid: (kv_start, kv_end) given by the caller
         if explicit is None:
             g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
         else:
             g_end = l_end = 0
         step = None
-        for b, req in enumerate(kv_cache_requests):
+        kv_first = self.cp is not None and self.cp.kv_first and "qkv_w" in w
+        if kv_first:
+            # sequence parallel: the K/V projection first, so that the exchange of the new block's K/V (side stream) runs under the
+            # q projection, its norm/RoPE and the attention over the old prefix (same GEMM rows as the fused projection)
+            ops.layernorm(xact, self.eps, out=h, mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group)
+            kvp = self._buf("kvp", B * N, 2 * d)
+            ops.linear(h, w["qkv_w"][d:], w["qkv_b"][d:], out=kvp)
+            name = blk.kv_cache_manager.self_name
+            pending = [self.cp.begin(self, l, self._kv_view(kv_cache_manager, req, name), kvp[b * N:(b + 1) * N], w, rope,
+                                     current_start, g_end, l_end, sink_tokens, kv_cache_manager, req, name)
+                       for b, req in enumerate(kv_cache_requests)]
+            qraw = self._buf("qraw", B * N, d)
+            ops.linear(h, w["qkv_w"][:d], w["qkv_b"][:d], out=qraw)
+            for b, pst in enumerate(pending):
+                ops.rmsnorm_rope_kv_append(qraw[b * N:(b + 1) * N], w["nq"], None, self.eps, rope, None, 0, d, q_out=qb[b * N:(b + 1) * N])
+                step = self.cp.finish(self, pst, qb[b * N:(b + 1) * N], ab[b * N:(b + 1) * N])
+        else:
+            self._norm_lin(w, "qkv", xact, h, dict(mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group), out=qkv)
+        for b, req in enumerate(() if kv_first else kv_cache_requests):
             name = blk.kv_cache_manager.self_name
             view = self._kv_view(kv_cache_manager, req, name)
             if self.cp is not None:

@@ -30,3 +30,25 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and rf["launches"] > 0
     cb = r["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["unit"]
+
+
+def test_bench_two_ranks_report_the_ranks_an_all_gather_saw_and_the_exchange_used():
+    """`bench.py --gpus 2` as the driver launches it, both ranks on the one GPU of the test box (IFX_BENCH_SHARE_GPU=1: gloo instead
+    of RCCL, everything else the N > 1 path): the line carries `rccl_ranks` counted from a collective and the per-layer K/V exchange
+    that ran — the peer-store path after its self-test between the two processes."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, IFX_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--layers", "2", "--no-decode-leg", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0
+    assert r["rccl_ranks"] == 2 and r["sp_exchange"] == "peer_store", (r["rccl_ranks"], r["sp_exchange"])

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, name, ret):
+def _worker(rank, world, port, overlap, name, ret, exchange="allgather"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -48,7 +48,11 @@ def _worker(rank, world, port, overlap, name, ret):
                               num_heads=cfg.num_heads, num_layers=cfg.num_layers, local_attn_size=cfg.local_attn_size,
                               sink_size=cfg.sink_size, eps=cfg.eps, parallel_config=pc)
         m.load_state_dict(O.init_weights(cfg, seed=0))
-        attach_sequence_parallel(m, overlap=overlap)
+        peer = None
+        if exchange == "peer":
+            from inferix_amd.sequence_parallel import PeerStoreExchange
+            peer = PeerStoreExchange(timeout_ms=10000)
+        attach_sequence_parallel(m, overlap=overlap, peer=peer)
         gen = HipWanDiffusionWrapper(model=m, timestep_shift=float(fx["shift"]), parallel_config=pc)
         args = SimpleNamespace(denoising_step_list=fx["steps"].tolist(), warp_denoising_step=True,
                                num_frame_per_block=3, independent_first_frame=False, context_noise=0,
@@ -74,6 +78,10 @@ def _worker(rank, world, port, overlap, name, ret):
         ok_trace = trace == fx["trace"].tolist()
         r = rel_l2(out.cpu(), fx["out"])
         ret[rank] = (ok_trace, r)
+        if peer is not None:
+            peer.check()
+            dist.barrier()
+            peer.close()
     finally:
         dist.destroy_process_group()
 
@@ -88,3 +96,79 @@ def test_sequence_parallel_rollout_matches_single_device_golden(overlap, name):
         ok_trace, r = ret[rank]
         assert ok_trace, f"rank {rank}: KV index trace differs from the single-device reference trace"
         assert r < 1e-2, f"rank {rank}: rollout rel-L2 {r:.3e}"
+
+
+@pytest.mark.parametrize("overlap,name", [(True, "rollout_tiny.npz"), (True, "rollout_tiny_local.npz"), (False, "rollout_tiny.npz")])
+def test_sequence_parallel_peer_store_rollout(overlap, name):
+    """The exchange without a collective: two PROCESSES (both on cuda:0) store their K/V rows into each other's cache through HIP IPC
+    mappings, ordered by the ready / done flags — same golden, same tolerance as the all-gather path."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), overlap, name, ret, "peer"), nprocs=world, join=True)
+    for rank in range(world):
+        ok_trace, r = ret[rank]
+        assert ok_trace, f"rank {rank}: KV index trace differs from the single-device reference trace"
+        assert r < 1e-2, f"rank {rank}: rollout rel-L2 {r:.3e}"
+
+
+def _push_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from inferix_amd import hip_ops as ops
+        from inferix_amd.sequence_parallel import PeerStoreExchange
+        from inferix_amd.wan import components as C
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        H, hd, frames, gh, gw = 12, 128, 3, 6, 8
+        d, fs = H * hd, gh * gw
+        hw_local = fs // world
+        n_local, N = frames * hw_local, frames * fs
+        slots, local_start, eps = 3 * N, N + 7, 1e-6
+        g = torch.Generator().manual_seed(11)
+        qkv_full = torch.randn(N, 3 * d, generator=g).to(torch.bfloat16).to(dev)       # single-device rows, (frame, hw) order
+        wq = (1 + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16).to(dev)
+        wk = (1 + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16).to(dev)
+        freqs = C.rope_table(hd).to(dev)
+        # what a single device writes
+        kc = torch.zeros(slots, H, hd, dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        rope1 = ops.RopeGridSpec(freqs, 2, gh, gw, 0, fs)
+        ops.rmsnorm_rope_kv_append(qkv_full, wq, wk, eps, rope1, ops.KvCacheView(kc, vc), local_start, d)
+        # this rank's rows: per frame the hw slice [rank * hw_local, (rank + 1) * hw_local)
+        mine = qkv_full.view(frames, fs, 3 * d)[:, rank * hw_local:(rank + 1) * hw_local].reshape(n_local, 3 * d).contiguous()
+        kp = torch.zeros(slots, H, hd, dtype=torch.bfloat16, device=dev)
+        vp = torch.zeros_like(kp)
+        view = ops.KvCacheView(kp, vp)
+        px = PeerStoreExchange(timeout_ms=10000)
+        ropeP = ops.RopeGridSpec(freqs, 2, gh, gw, rank * hw_local, hw_local)
+        ok = True
+        for it in range(3):                      # several epochs through the same flags
+            kp.zero_()
+            vp.zero_()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e = px.push(5, mine[:, d:], wk, eps, ropeP, view, local_start, fs, d)      # strided (k | v) view of the fused rows
+            px.wait_done(5, e)
+            torch.cuda.synchronize()
+            px.check()
+            ok = ok and torch.equal(kp, kc) and torch.equal(vp, vc)
+            dist.barrier()
+        ret[rank] = ok
+        px.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_store_push_two_processes_bit_exact():
+    """`ifx_rmsnorm_rope_kv_push` through IPC mappings: after ready / push / done, each of the two processes' caches holds exactly
+    the bytes one device writes with `ifx_rmsnorm_rope_kv_append` for the whole block."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_push_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
