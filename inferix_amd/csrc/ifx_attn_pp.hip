@@ -624,9 +624,12 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           if (PP_SWP_PACKED) {
             pp_f32x2& a2 = (j & 1) ? accp[1] : accp[0];
             const pp_f32x2 pv = {p0, p1};
-            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2) : "v"(pv));
+            asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1" : "+v"(a2) : "v"(pv));
           } else {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j) & 3]) : "v"(p0));
+            // p0 / p1 come straight out of v_exp_f32: a VALU instruction that reads a transcendental's result needs one wait state
+            // behind it, and the hazard recogniser does not look into inline asm.  Latent until a recompile puts the exponential
+            // directly in front of this add: seen as -inf row sums in lanes 0-3 of every 8 in a build with a loop around the kernel body.
+            asm volatile("s_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j) & 3]) : "v"(p0));
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc4[(2 * j + 1) & 3]) : "v"(p1));
           }
         }
