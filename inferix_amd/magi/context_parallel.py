@@ -3,8 +3,9 @@
 Mirror of the reference's `inferix/distributed/parallelism/context_parallel.py` for the `cp_ulysses` strategy — the same
 function names, argument meaning and results — on torch.distributed, whose "nccl" backend is RCCL on ROCm.  The
 all-to-all is the natural collective of the fully connected xGMI mesh (every pair of GPUs has its own link, so all
-P-1 peer messages of a rank move concurrently); `cp_shuffle_overlap`, the reference's strategy for PCIe-attached
-consumer GPUs (context_parallel.py:258-307), is not built and raises.
+P-1 peer messages of a rank move concurrently); `cp_shuffle_overlap` (context_parallel.py:258-307, 604-665: every rank holds a
+slice of every denoising chunk, queries and outputs of neighbouring chunks travel under the attention of the current one) is the
+reference's strategy for PCIe-attached GPUs and is built for parity.
 
 The process group is held by this module (`set_cp_group`), where the reference asks `parallel_state`
 (distributed/parallel_state.py:498-503,620-634).  All functions also run on CPU tensors over gloo, which is how
@@ -96,28 +97,53 @@ class FakeHandle:
 # ---------------------------------------------------------------------------------------------------------------
 def scatter_to_context_parallel_region(input_: torch.Tensor, cp_split_sizes: Sequence[int], cp_shuffle_num: int = 1,
                                        cp_pad_size: int = 0) -> torch.Tensor:
-    """This rank's rows `[sum(sizes[:rank]), +sizes[rank])` of the first dimension."""
+    """This rank's rows of the first dimension.  Plain: `[sum(sizes[:rank]), +sizes[rank])` of the (zero-padded) sequence.
+    Shuffled (`cp_shuffle_num` = dn > 1, cp_shuffle_overlap): the sequence is dn chunks; every chunk is zero-padded by pad/dn rows
+    and every rank takes its window of EVERY chunk, chunk-major (context_parallel.py:30-54)."""
     if get_cp_world_size() == 1:
         return input_
-    if cp_shuffle_num != 1 or cp_pad_size != 0:
-        raise NotImplementedError("cp_shuffle_overlap (shuffled / padded split) is not built; use cp_ulysses")
     rank = get_cp_rank()
+    if cp_shuffle_num > 1:
+        dn = cp_shuffle_num
+        m = divide(cp_split_sizes[rank], dn)                      # rows of one chunk on this rank
+        lo = sum(divide(s, dn) for s in cp_split_sizes[:rank])
+        c = divide(input_.shape[0], dn)                           # unpadded chunk length
+        assert lo + m <= c + divide(cp_pad_size, dn)
+        out = input_.new_zeros((dn, m) + tuple(input_.shape[1:]))
+        hi = min(lo + m, c)
+        if hi > lo:
+            out[:, :hi - lo] = input_.reshape((dn, c) + tuple(input_.shape[1:]))[:, lo:hi]
+        return out.reshape((dn * m,) + tuple(input_.shape[1:]))
     off = sum(cp_split_sizes[:rank])
-    return input_[off:off + cp_split_sizes[rank]].contiguous()
+    n = cp_split_sizes[rank]
+    if cp_pad_size == 0:
+        return input_[off:off + n].contiguous()
+    out = input_.new_zeros((n,) + tuple(input_.shape[1:]))
+    hi = min(off + n, input_.shape[0])
+    if hi > off:
+        out[:hi - off] = input_[off:hi]
+    return out
 
 
 def gather_from_context_parallel_region(input_: torch.Tensor, cp_split_sizes: Sequence[int], cp_shuffle_num: int = 1,
                                         cp_pad_size: int = 0) -> torch.Tensor:
-    """Rank-order concatenation of every rank's rows (one all-gather; shards may have different lengths)."""
+    """Inverse of the scatter: one all-gather (shards may have different lengths), the shuffled form re-ordered chunk-major and
+    every chunk's padding dropped (context_parallel.py:57-88)."""
     world = get_cp_world_size()
     if world == 1:
         return input_
-    if cp_shuffle_num != 1 or cp_pad_size != 0:
-        raise NotImplementedError("cp_shuffle_overlap (shuffled / padded gather) is not built; use cp_ulysses")
     input_ = input_.contiguous()
-    out = torch.empty((sum(cp_split_sizes),) + tuple(input_.shape[1:]), dtype=input_.dtype, device=input_.device)
+    tail = tuple(input_.shape[1:])
+    out = torch.empty((sum(cp_split_sizes),) + tail, dtype=input_.dtype, device=input_.device)
     dist.all_gather(list(torch.split(out, list(cp_split_sizes), dim=0)), input_, group=get_cp_group())
-    return out
+    if cp_shuffle_num > 1:
+        dn = cp_shuffle_num
+        m = divide(cp_split_sizes[0], dn)
+        assert all(s == cp_split_sizes[0] for s in cp_split_sizes), "shuffled shards are equal by construction"
+        keep = world * m - divide(cp_pad_size, dn)
+        out = out.reshape((world, dn, m) + tail).transpose(0, 1).reshape((dn, world * m) + tail)[:, :keep]
+        return out.reshape((dn * keep,) + tail)
+    return out[:out.shape[0] - cp_pad_size] if cp_pad_size else out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -125,31 +151,36 @@ def gather_from_context_parallel_region(input_: torch.Tensor, cp_split_sizes: Se
 # ---------------------------------------------------------------------------------------------------------------
 def cp_update_cross_attn_qkv_range(cross_attn_params: PackedCrossAttnParams, batch_size: int, cp_split_sizes: List[int],
                                    device, cp_shuffle_num: int = 1, cp_pad_size: int = 0) -> PackedCrossAttnParams:
-    """Clip every packed query segment to this rank's token window (per batch element), keep the key segment of the
-    pieces that survive, and re-base the query ranges to the rank-local packed order.  Pure host-side integer work."""
-    if cp_shuffle_num != 1 or cp_pad_size != 0:
-        raise NotImplementedError("cp_shuffle_overlap ranges are not built; use cp_ulysses")
+    """Clip every packed query segment to this rank's token window(s), keep the key segment of the pieces that survive, and
+    re-base the query ranges to the rank-local packed order.  One window per batch element, or — shuffled — one per (batch
+    element, denoising chunk), each chunk padded by pad/dn rows, which shifts packed segment s by s * pad/dn.  Pure host-side
+    integer work (context_parallel.py:135-226)."""
     rank = get_cp_rank()
-    total = sum(cp_split_sizes)
-    lo0, hi0 = sum(cp_split_sizes[:rank]), sum(cp_split_sizes[:rank + 1])
-    cq = cross_attn_params.cu_seqlens_q.tolist()
+    dn = max(int(cp_shuffle_num), 1)
+    per = [divide(s, dn) for s in cp_split_sizes]
+    total = sum(per)                                           # padded chunk (or sequence) length
+    lo0, hi0 = sum(per[:rank]), sum(per[:rank + 1])
+    shift = divide(cp_pad_size, dn)
+    cq = [int(v) + i * shift for i, v in enumerate(cross_attn_params.cu_seqlens_q.tolist())]
     ck = cross_attn_params.cu_seqlens_kv.tolist()
     q_rows: List[List[int]] = []
     k_rows: List[List[int]] = []
     base = 0
     for b in range(batch_size):
-        lo, hi = lo0 + b * total, hi0 + b * total
-        piece_q, piece_k = [], []
-        for s in range(len(cq) - 1):
-            a, e = max(lo, cq[s]), min(hi, cq[s + 1])
-            if a < e:
-                piece_q.append((a, e))
-                piece_k.append([ck[s], ck[s + 1]])
-        first = min(a for a, _ in piece_q)
-        rebased = [[a - first + base, e - first + base] for a, e in piece_q]
-        base = rebased[-1][1]
-        q_rows += rebased
-        k_rows += piece_k
+        for j in range(dn):
+            off = (b * dn + j) * total
+            lo, hi = lo0 + off, hi0 + off
+            piece_q, piece_k = [], []
+            for sgm in range(len(cq) - 1):
+                a, e = max(lo, cq[sgm]), min(hi, cq[sgm + 1])
+                if a < e:
+                    piece_q.append((a, e))
+                    piece_k.append([ck[sgm], ck[sgm + 1]])
+            first = min(a for a, _ in piece_q)
+            rebased = [[a - first + base, e - first + base] for a, e in piece_q]
+            base = rebased[-1][1]
+            q_rows += rebased
+            k_rows += piece_k
     q_ranges = torch.tensor(q_rows, dtype=torch.int32, device=device)
     kv_ranges = torch.tensor(k_rows, dtype=torch.int32, device=device)
     return PackedCrossAttnParams(q_ranges=q_ranges, kv_ranges=kv_ranges, cu_seqlens_q=torch.unique(q_ranges),
@@ -186,8 +217,41 @@ def cp_pre_process(cp_size: int, cp_strategy: str, x: torch.Tensor, condition_ma
                                                                               xattn_mask_for_cuda_graph, cross_attn_params)
         return x, condition_map, rope, 0, sizes, core_attn_params, cross_attn_params
     if cp_strategy == "cp_shuffle_overlap":
-        raise NotImplementedError("cp_shuffle_overlap targets PCIe consumer GPUs upstream; MI355X uses cp_ulysses over xGMI")
+        return cp_shuffle_overlap_process(cp_size, x, condition_map, rope, xattn_mask_for_cuda_graph, ardf_meta, core_attn_params,
+                                          cross_attn_params)
     raise ValueError(f"Invalid CP strategy: {cp_strategy}, expected cp_ulysses or cp_shuffle_overlap")
+
+
+def cp_shuffle_overlap_process(cp_size: int, x: torch.Tensor, condition_map: torch.Tensor, rope: torch.Tensor,
+                               xattn_mask_for_cuda_graph, ardf_meta: dict, core_attn_params: Optional[PackedCoreAttnParams],
+                               cross_attn_params: PackedCrossAttnParams):
+    """Context shuffle (context_parallel.py:258-307): every rank gets a slice of EVERY denoising chunk, so that all ranks have
+    work in every attention range; chunks are padded to a multiple of cp and the query ranges stretched accordingly."""
+    import math
+
+    import numpy as np
+    seq_len, N, _ = x.shape
+    assert seq_len == rope.size(0), f"seq_len: {seq_len} != rope.size(0): {rope.size(0)}"
+    assert condition_map.size(0) == seq_len, f"condition_map.size(0): {condition_map.size(0)} != seq_len: {seq_len}"
+    if xattn_mask_for_cuda_graph is not None:
+        raise NotImplementedError("static-length cross-attention masks (CUDA-graph mode of the reference) are not built")
+    dn = int(ardf_meta["denoising_range_num"])
+    chunk = divide(seq_len, dn)
+    cp_pad_size = (cp_size - chunk % cp_size) * dn if chunk % cp_size else 0
+    cp_split_sizes = [(seq_len + cp_pad_size) // cp_size] * cp_size
+    x = scatter_to_context_parallel_region(x, cp_split_sizes, dn, cp_pad_size)
+    condition_map = scatter_to_context_parallel_region(condition_map, cp_split_sizes, dn, cp_pad_size)
+    rope = scatter_to_context_parallel_region(rope, cp_split_sizes, dn, cp_pad_size)
+    g = math.gcd(seq_len, seq_len + cp_pad_size)
+    num, den = (seq_len + cp_pad_size) // g, seq_len // g
+    q_range = ardf_meta["q_range"] * num // den
+    k_range = ardf_meta["k_range"]
+    core_attn_params = PackedCoreAttnParams(q_range=q_range, k_range=k_range, np_q_range=np.asarray(q_range.cpu().numpy()),
+                                            np_k_range=np.asarray(k_range.cpu().numpy()),
+                                            max_seqlen_q=ardf_meta["max_seqlen_q"] * num // den,
+                                            max_seqlen_k=ardf_meta["max_seqlen_k"])
+    cross_attn_params = cp_update_cross_attn_qkv_range(cross_attn_params, N, cp_split_sizes, x.device, dn, cp_pad_size)
+    return x, condition_map, rope, cp_pad_size, cp_split_sizes, core_attn_params, cross_attn_params
 
 
 def cp_post_process(cp_size: int, cp_strategy: str, x: torch.Tensor, meta_args: ModelMetaArgs) -> torch.Tensor:
@@ -196,7 +260,7 @@ def cp_post_process(cp_size: int, cp_strategy: str, x: torch.Tensor, meta_args: 
     if cp_strategy == "cp_ulysses":
         return gather_from_context_parallel_region(x, meta_args.cp_split_sizes)
     if cp_strategy == "cp_shuffle_overlap":
-        raise NotImplementedError("cp_shuffle_overlap is not built; use cp_ulysses")
+        return gather_from_context_parallel_region(x, meta_args.cp_split_sizes, meta_args.denoising_range_num, meta_args.cp_pad_size)
     raise ValueError(f"Invalid CP strategy: {cp_strategy}, expected cp_ulysses or cp_shuffle_overlap")
 
 
@@ -338,3 +402,73 @@ class UlyssesScheduler:
         sq = n // (cp_size * batch_size)
         core = core.view(cp_size, sq, batch_size, hn, hd).permute(1, 2, 0, 3, 4).reshape(sq, batch_size, cp_size * hn * hd)
         return core.contiguous(), xattn_out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# context shuffle overlap: attention pipeline                  (context_parallel.py:604-665)
+# ---------------------------------------------------------------------------------------------------------------
+def cso_communication(input: torch.Tensor, cp_world_size: int, cp_split_sizes: List[int], comm_type: Optional[str] = None):
+    """One all-to-all of equal pieces, rows grouped by destination rank.  `comm_type` "kv": `[rows, cp*hn, hd]` (heads repeated
+    first when there are fewer kv heads than ranks) is re-ordered rank-major so that every rank receives all rows of its heads."""
+    if cp_world_size == 1:
+        return input, FakeHandle()
+    assert cp_split_sizes is not None
+    if comm_type == "kv":
+        input = _heads_to_ranks(input, cp_world_size)
+    input = input.contiguous()
+    output = torch.empty_like(input)
+    handle = _a2a(output, input, in_sizes=list(cp_split_sizes))
+    return output, handle
+
+
+class CSOHelper:
+    """Order of the query / output messages of one attention layer under cp_shuffle_overlap: the queries of denoising chunk i+1
+    travel (together with the finished output of chunk i-1) while chunk i is attended to; outputs come back in chunk order."""
+
+    def __init__(self, cp_shuffle_num: int, cp_world_size: int, cp_split_sizes: List[int]):
+        self.cp_shuffle_num = cp_shuffle_num
+        self.cp_world_size = cp_world_size
+        self.cp_split_sizes = [divide(x, cp_shuffle_num) for x in cp_split_sizes]
+
+    def split_query_for_overlap(self, query: torch.Tensor):
+        """`[(dn rows), (cp hn), hd]` -> dn messages `[(cp rows), hn, hd]` (destination-rank major); the first is sent at once."""
+        dn, cp = self.cp_shuffle_num, self.cp_world_size
+        rows, heads, hd = query.shape
+        m = divide(rows, dn)
+        q = query.view(dn, m, cp, divide(heads, cp), hd).permute(0, 2, 1, 3, 4).reshape(dn * cp * m, heads // cp, hd).contiguous()
+        querys = list(torch.chunk(q, dn, dim=0))
+        querys[0], handle_q = cso_communication(querys[0], cp, self.cp_split_sizes)
+        return querys, handle_q
+
+    def overlap(self, fattn: Callable, qs: List[torch.Tensor], k, v):
+        """`fattn(q, k, v, i)` = attention of chunk i's queries (all rows of this rank's heads).  Returns the per-chunk outputs
+        back in (source-rank, rows) order on their home ranks + the handle of the last message."""
+        dn, cp = self.cp_shuffle_num, self.cp_world_size
+        outs: List[torch.Tensor] = []
+        handle_attn = FakeHandle()
+        loop_var, loop_handle, o = None, None, None
+        for i in range(dn):
+            if dn == 1:
+                q = qs[0]
+            elif i == 0:
+                q = qs[0]
+                loop_var, loop_handle = cso_communication(qs[1], cp, self.cp_split_sizes)
+            else:
+                loop_handle.wait()
+                if loop_var.numel() == qs[0].numel():
+                    q = loop_var
+                else:                                            # (next queries | finished output) travelled side by side
+                    assert loop_var.numel() == qs[0].numel() * 2
+                    q, ready_o = torch.chunk(loop_var, 2, dim=-1)
+                    outs.append(ready_o)
+                loop_var = torch.concat([qs[i + 1], o], dim=-1) if i < dn - 1 else o
+                loop_var, loop_handle = cso_communication(loop_var, cp, self.cp_split_sizes)
+            o = fattn(q, k, v, i)
+            if i == dn - 1:
+                if i != 0:
+                    loop_handle.wait()
+                    assert loop_var.numel() == qs[0].numel()
+                    outs.append(loop_var)
+                last_o, handle_attn = cso_communication(o, cp, self.cp_split_sizes)
+                outs.append(last_o)
+        return outs, handle_attn

@@ -2,7 +2,7 @@
 
 Mirrors `inferix/models/magi/dit/dit_module.py`:
   `TransformerLayer` (:1201-1319)            -> `HipMagiTransformerLayer`   (forward: same seven arguments)
-  `FullyParallelAttention` (:833-1195)       -> `HipFullyParallelAttention` (`cp_strategy` "none" and "cp_ulysses")
+  `FullyParallelAttention` (:833-1195)       -> `HipFullyParallelAttention` (`cp_strategy` "none", "cp_ulysses", "cp_shuffle_overlap")
   `TransformerBlock` (:1322-1390)            -> `HipMagiTransformerBlock`   (the layer stack + fp32 final LayerNorm)
 State-dict keys are the reference's (`self_attention.linear_qkv.q.weight`, ...), loaded with `load_state_dict`.
 
@@ -109,8 +109,6 @@ class HipFullyParallelAttention:
         rope = rotary_pos_emb if rotary_pos_emb.dtype == torch.float32 else rotary_pos_emb.float()
         strategy = getattr(self.engine_config, "cp_strategy", "none")
         cp = cpl.get_cp_world_size() if strategy != "none" else 1
-        if strategy == "cp_shuffle_overlap":
-            raise NotImplementedError("cp_shuffle_overlap targets PCIe consumer GPUs upstream; MI355X uses cp_ulysses over xGMI")
         cq = meta_args.core_attn_params.np_q_range
         ck = meta_args.core_attn_params.np_k_range
         if cp == 1:
@@ -121,6 +119,8 @@ class HipFullyParallelAttention:
                                row0=row0, split=split, row1=row1, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
                                xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
             _range_attention(q_buf, handle, cq, ck, meta_args.denoising_range_num, attn_cat, self.hq)
+        elif strategy == "cp_shuffle_overlap":
+            self._cso(mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p)
         else:
             self._ulysses(mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p)
         # ---- cross-attention on the caption tokens (:954-970, :1047-1085); the local tokens attend the whole caption
@@ -160,6 +160,48 @@ class HipFullyParallelAttention:
             lambda kv: (self.kv_cache_manager.adjust_key_and_value_for_inference(kv, inference_params, meta_args),) * 2,
             core, lambda: None, getattr(self.engine_config, "ulysses_overlap_degree", 1), 1, cp, sizes)
         attn_cat[:, :Q].copy_(core_out.view(s_len, Q))
+
+
+    def _cso(self, mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p):
+        """cp_shuffle_overlap (:1156-1188): this rank holds a slice of every denoising chunk.  K/V of all chunks go to the head
+        owners in one message; the queries travel chunk by chunk, each message overlapping the attention of the chunk before
+        (`CSOHelper.overlap`), whose output rides back with the next queries."""
+        w = self.w
+        s_len = mixed.shape[0]
+        sizes = [int(v) for v in meta_args.cp_split_sizes]
+        dn = int(meta_args.denoising_range_num)
+        kv_stage = torch.empty(s_len, self.hk, 2 * self.hd, dtype=BF16, device=mixed.device)
+        ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
+                           k_out=kv_stage, v_out=kv_stage.view(-1)[self.hd:], kv_head_stride=2 * self.hd,
+                           ld_kv=self.hk * 2 * self.hd, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
+                           xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
+        kv, handle_kv = cpl.cso_communication(kv_stage, cp, sizes, "kv")               # [(cp dn m), hk_local, 2 hd]
+        helper = cpl.CSOHelper(dn, cp, sizes)
+        qs, handle_q = helper.split_query_for_overlap(q_buf.view(s_len, self.hq, self.hd))
+        handle_kv.wait()
+        m = s_len // dn
+        # (cp dn m) -> dn (cp m), every chunk's padding rows dropped: the cache rule sees the chunks as a single device does
+        kv = kv.view(cp, dn, m, kv.shape[1], kv.shape[2]).transpose(0, 1).reshape(dn, cp * m, kv.shape[1], kv.shape[2])
+        kv = kv[:, :meta_args.clip_token_nums].flatten(0, 1).contiguous()
+        handle = self.kv_cache_manager.adjust_key_and_value_for_inference(kv, inference_params, meta_args)
+        handle_q.wait()
+        ck = meta_args.core_attn_params.np_k_range
+
+        def fattn(q, key, value, i):            # full_attention (:1017-1045): every (padded) query row of chunk i over its key range
+            q = q.contiguous()
+            out = torch.empty_like(q)
+            rows, heads = q.shape[0], q.shape[1]
+            ks, ke = int(ck[i, 0]), int(ck[i, 1])
+            if ke > handle.kv_len:
+                raise ValueError(f"k_range[{i}] = [{ks}, {ke}) exceeds the {handle.kv_len} available keys")
+            ops.attention_ld(q.view(rows, -1), handle.view, ke, out.view(rows, -1), heads, kv_start=ks, tag="attn_magi")
+            return out
+        outs, handle_attn = helper.overlap(fattn, qs, handle, handle)
+        handle_attn.wait()
+        Q = self.hq * self.hd
+        cat = torch.concat(outs, dim=0)                                                # (dn cp m) hn hd -> (dn m) (cp hn hd)
+        core = cat.view(dn, cp, m, cat.shape[1], self.hd).permute(0, 2, 1, 3, 4).reshape(s_len, Q)
+        attn_cat[:, :Q].copy_(core)
 
 
 def _range_attention(q2d: torch.Tensor, handle, q_range, k_range, n: int, out2d: torch.Tensor, heads: int) -> None:

@@ -322,7 +322,7 @@ def test_full_size_chunk_properties():
 
 
 # ---- the layer under cp_ulysses: 2 ranks on one GPU (gloo rendezvous; device tensors staged through the host by the exchange) --
-def _cp_worker(rank, world, port, ret):
+def _cp_worker(rank, world, port, ret, strategy="cp_ulysses"):
     import os
     import sys
     import torch.distributed as dist
@@ -341,7 +341,7 @@ def _cp_worker(rank, world, port, ret):
         cpl.set_cp_group(dist.group.WORLD)
         fx = golden("magi_block_tiny.npz")
         cfg, n_layers, clip, n_calls, wseed, max_tokens = MB.fixture_geometry(fx)
-        mc, ec = _configs(cfg, n_layers, cp_strategy="cp_ulysses")
+        mc, ec = _configs(cfg, n_layers, cp_strategy=strategy)
         ec.cp_size = world
         layers = []
         for li in range(n_layers):
@@ -353,13 +353,18 @@ def _cp_worker(rank, world, port, ret):
         for ci in range(3):                          # store two chunks / prefix + nearly-clean rule / read-only window
             inp, m = MB.fixture_call(fx, ci)
             meta = _meta(m)
+            ardf = dict(denoising_range_num=meta.denoising_range_num, q_range=meta.core_attn_params.q_range,
+                        k_range=meta.core_attn_params.k_range, max_seqlen_q=meta.core_attn_params.max_seqlen_q,
+                        max_seqlen_k=meta.core_attn_params.max_seqlen_k)
             x, cmap, rope, pad, sizes, core_p, cross_p = cpl.cp_pre_process(
-                world, "cp_ulysses", inp["x"].cuda(), inp["condition_map"].cuda(), inp["rope"].cuda(), None, None,
+                world, strategy, inp["x"].cuda(), inp["condition_map"].cuda(), inp["rope"].cuda(), None, ardf,
                 meta.core_attn_params, meta.cross_attn_params)
             meta = dataclasses.replace(meta, cp_pad_size=pad, cp_split_sizes=sizes, core_attn_params=core_p, cross_attn_params=cross_p)
             ip.update_kv_cache = m.update_kv_cache
             for layer in layers:
                 x = layer(x, inp["condition"].cuda(), cmap, inp["y"].cuda(), rope, ip, meta)
+            if strategy == "cp_shuffle_overlap":      # the shuffled shards are re-assembled by the strategy's own gather
+                x = cpl.cp_post_process(world, strategy, x.cpu(), meta)
             outs.append(x.cpu())
         torch.cuda.synchronize()
         ret[rank] = outs
@@ -388,3 +393,27 @@ def test_layer_under_cp_ulysses_two_ranks_matches_single_device_golden():
         ref = fx[f"c{ci}_out_l1"]
         assert got.shape == ref.shape
         assert rel_l2(got, ref) < 1e-2, (ci, rel_l2(got, ref))
+
+
+def test_layer_under_cp_shuffle_overlap_two_ranks_matches_single_device_golden():
+    """The reference's second context-parallel strategy on the HIP layer: every rank holds a slice of EVERY denoising chunk
+    (padded to a multiple of the ranks), K/V in one message, queries / outputs chunk by chunk under the attention of the
+    neighbouring chunk; gathered with the strategy's own `cp_post_process`, the result equals the single-device reference."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_cp_worker, args=(world, port, ret, "cp_shuffle_overlap"), nprocs=world, join=True)
+        outs = [ret[r] for r in range(world)]
+    fx = golden("magi_block_tiny.npz")
+    for ci in range(3):
+        ref = fx[f"c{ci}_out_l1"]
+        for r in range(world):
+            got = outs[r][ci]
+            assert got.shape == ref.shape
+            assert rel_l2(got, ref) < 1e-2, (ci, r, rel_l2(got, ref))

@@ -134,11 +134,6 @@ def _worker(rank, world, port, ret):
                              clip_token_nums=SEQ, enable_cuda_graph=False, core_attn_params=None, cross_attn_params=cross_p)
         check("post_x", cp.cp_post_process(CP, "cp_ulysses", xe, meta))
         try:
-            cp.cp_pre_process(CP, "cp_shuffle_overlap", fx["in_x"], fx["in_condition_map"], fx["in_rope"], None, {}, None, cross)
-            bad.append("cp_shuffle_overlap did not raise")
-        except NotImplementedError:
-            pass
-        try:
             cp.cp_pre_process(CP, "nope", fx["in_x"], fx["in_condition_map"], fx["in_rope"], None, {}, None, cross)
             bad.append("bad strategy did not raise")
         except ValueError:
@@ -166,3 +161,84 @@ def test_single_rank_is_identity():
     t, h = cp.all_to_all_input_split(x, None)
     h.wait()
     assert t is x
+
+
+def _cso_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from inferix_amd.magi import context_parallel as cp
+        from inferix_amd.magi.types import ModelMetaArgs, PackedCrossAttnParams
+        fx = golden("magi_cso.npz")
+        CP, DN, CHUNK, B, DIM, ROPE, HQ, HK, HD = [int(v) for v in fx["geom"].tolist()]
+        cp.set_cp_group(dist.group.WORLD)
+        bad = []
+
+        def check(name, got):
+            ref = fx[f"r{rank}_{name}"]
+            if tuple(got.shape) != tuple(ref.shape) or not torch.equal(got.to(ref.dtype), ref):
+                bad.append(name)
+        cross = PackedCrossAttnParams(cu_seqlens_q=fx["cu_q"].to(torch.int32), cu_seqlens_kv=fx["cu_k"].to(torch.int32),
+                                      max_seqlen_q=CHUNK, max_seqlen_kv=7)
+        ardf = dict(denoising_range_num=DN, q_range=fx["ardf_q_range"].to(torch.int32), k_range=fx["ardf_k_range"].to(torch.int32),
+                    max_seqlen_q=CHUNK, max_seqlen_k=DN * CHUNK)
+        x, cond, rope, pad, sizes, core_p, cross_p = cp.cp_pre_process(CP, "cp_shuffle_overlap", fx["in_x"], fx["in_condition_map"],
+                                                                         fx["in_rope"], None, ardf, None, cross)
+        assert pad == int(fx[f"r{rank}_pad"]) == 6 and sizes == fx[f"r{rank}_sizes"].tolist() == [9, 9, 9, 9]
+        check("pre_x", x), check("pre_cond", cond), check("pre_rope", rope)
+        check("core_q_range", core_p.q_range), check("core_k_range", core_p.k_range)
+        assert int(core_p.max_seqlen_q) == int(fx[f"r{rank}_core_max_q"]) and int(core_p.max_seqlen_k) == int(fx[f"r{rank}_core_max_k"])
+        assert core_p.np_q_range.tolist() == core_p.q_range.tolist() and core_p.np_k_range.tolist() == core_p.k_range.tolist()
+        check("xq_ranges", cross_p.q_ranges), check("xk_ranges", cross_p.kv_ranges)
+        check("xcu_q", cross_p.cu_seqlens_q), check("xcu_k", cross_p.cu_seqlens_kv)
+        assert cross_p.max_seqlen_q == int(fx[f"r{rank}_xmax_q"]) and cross_p.max_seqlen_kv == int(fx[f"r{rank}_xmax_k"])
+        meta = ModelMetaArgs(H=1, W=1, cp_pad_size=pad, cp_split_sizes=sizes, slice_point=0, denoising_range_num=DN, range_num=DN,
+                             extract_prefix_video_feature=False, fwd_extra_1st_chunk=False, distill_nearly_clean_chunk=False,
+                             clip_token_nums=CHUNK, enable_cuda_graph=False, core_attn_params=core_p, cross_attn_params=cross_p)
+        post = cp.cp_post_process(CP, "cp_shuffle_overlap", x, meta)
+        check("post_x", post)
+        if not torch.equal(post, fx["in_x"]):
+            bad.append("gather(scatter(x)) != x")
+        # the attention layer's exchange with exact attention injected (dit_module.py:1156-1188)
+        bs = [s * B for s in sizes]
+        q_loc, kv_loc = fx[f"r{rank}_in_q"], fx[f"r{rank}_in_kv"]
+        kv, hkv = cp.cso_communication(kv_loc, CP, bs, "kv")
+        helper = cp.CSOHelper(DN, CP, bs)
+        qs, hq = helper.split_query_for_overlap(q_loc)
+        hkv.wait()
+        check("kv_a2a", kv)
+        m = kv.shape[0] // (CP * DN)
+        kvu = kv.view(CP, DN, m, *kv.shape[1:]).transpose(0, 1).reshape(DN, CP * m, *kv.shape[1:])[:, :CHUNK].flatten(0, 1).contiguous()
+        check("kv_unpadded", kvu)
+        key, value = [t.contiguous() for t in torch.chunk(kvu, 2, dim=-1)]
+        hq.wait()
+        check("q0_a2a", qs[0])
+        kr = core_p.np_k_range
+
+        def fattn(q, k, v, i):
+            return M.exact_attention(q, k[kr[i, 0]:kr[i, 1]], v[kr[i, 0]:kr[i, 1]]).to(torch.bfloat16).contiguous()
+        outs, h = helper.overlap(fattn, qs, key, value)
+        h.wait()
+        assert len(outs) == DN
+        for i, o in enumerate(outs):
+            check(f"overlap_out{i}", o)
+        cat = torch.concat(outs, dim=0)                               # (dn cp sq b) hn hd -> (dn sq) b (cp hn hd)
+        sq = cat.shape[0] // (DN * CP * B)
+        core = cat.view(DN, CP, sq, B, *cat.shape[1:]).permute(0, 2, 3, 1, 4, 5).reshape(DN * sq, B, -1)
+        check("core_attn_out", core)
+        ret[rank] = bad
+    finally:
+        dist.destroy_process_group()
+
+
+def test_product_context_shuffle_overlap_gloo_world4_matches_reference_golden():
+    """cp_shuffle_overlap (the reference's second CP strategy): shuffled + padded scatter / gather, stretched query ranges,
+    cross-attention ranges per (batch, chunk) window, the "kv" message, and CSOHelper's interleaving of query / output messages
+    with the per-chunk attention — bit-exact against what the reference's own functions produced under gloo with 4 ranks."""
+    world = 4
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_cso_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert len(ret) == world
+        for r in range(world):
+            assert ret[r] == [], f"rank {r}: mismatching entries {ret[r]}"
