@@ -32,6 +32,7 @@ import torch.distributed as dist
 
 from .. import _hip
 from .. import hip_ops as ops
+from ..quant import StaticFp8Linear
 from . import context_parallel as cpl
 from .attention import MagiKVCacheManager
 from .types import InferenceParams, ModelMetaArgs
@@ -64,16 +65,23 @@ class HipFullyParallelAttention:
                                                    hidden_size_per_attention_head=self.hd, engine_config=engine_config)
         self.adapt_linear_quant = bool(getattr(engine_config, "fp8_quant", False)) and layer_number != 0 and \
             layer_number != model_config.num_layers - 1
-        if self.adapt_linear_quant:
-            raise NotImplementedError("fp8_quant checkpoints (static-scale FP8 linears) load through inferix_amd.quant."
-                                      "StaticFp8Linear; wiring them into this layer is not built yet")
         self.w: Dict[str, torch.Tensor] = {}
+        self.fp8: Dict[str, StaticFp8Linear] = {}      # fp8_quant layers: q / qx / k / v / proj on the static-scale FP8 linears
 
     def load(self, W: Dict[str, torch.Tensor], prefix: str) -> None:
         dev, Q = self.device, self.hq * self.hd
         g = lambda k: W[prefix + k].to(dev)
-        self.w["qkv"] = torch.cat([g("linear_qkv.q.weight"), g("linear_qkv.qx.weight"), g("linear_qkv.k.weight"),
-                                   g("linear_qkv.v.weight")], dim=0).to(BF16).contiguous()
+        quant = prefix + "linear_qkv.q.weight_scale" in W
+        if quant != self.adapt_linear_quant:
+            raise ValueError(f"layer {self.layer_number}: engine_config.fp8_quant says {'FP8' if self.adapt_linear_quant else 'bf16'} "
+                             f"linears, the checkpoint holds {'FP8' if quant else 'bf16'} ones")
+        if quant:                                    # PerTensorQuantizedFp8Linear x 4 (dit_module.py:408-413): own divisor each
+            for nm in ("q", "qx", "k", "v"):
+                k = f"linear_qkv.{nm}."
+                self.fp8[nm] = StaticFp8Linear(g(k + "weight"), g(k + "weight_scale"), g(k + "input_scale"), g(k + "input_scale"))
+        else:
+            self.w["qkv"] = torch.cat([g("linear_qkv.q.weight"), g("linear_qkv.qx.weight"), g("linear_qkv.k.weight"),
+                                       g("linear_qkv.v.weight")], dim=0).to(BF16).contiguous()
         self.w["ln_w"], self.w["ln_b"] = g("linear_qkv.layer_norm.weight").to(BF16), g("linear_qkv.layer_norm.bias").to(BF16)
         self.w["kvx"] = g("linear_kv_xattn.weight").to(BF16).contiguous()
         # attn_linear_proj (:1287): the module multiplies linear_proj.weight with rearrange(cat([core, xattn]),
@@ -83,7 +91,12 @@ class HipFullyParallelAttention:
         j = torch.arange(2 * Q)
         n, rem = j // Q, j % Q
         src = (rem // c) * (2 * c) + n * c + rem % c
-        self.w["proj"] = g("linear_proj.weight").to(BF16)[:, src.to(dev)].contiguous()
+        if quant:                                    # PerChannelQuantizedFp8Linear (:867): bytes and smooth_scale permuted alike
+            pw = g("linear_proj.weight").view(torch.uint8).reshape(-1, 2 * Q)[:, src.to(dev)].contiguous()
+            self.fp8["proj"] = StaticFp8Linear(pw, g("linear_proj.weight_scale"), g("linear_proj.input_scale"),
+                                               g("linear_proj.smooth_scale").reshape(-1)[src.to(dev)])
+        else:
+            self.w["proj"] = g("linear_proj.weight").to(BF16)[:, src.to(dev)].contiguous()
         for nm in ("q_layernorm", "k_layernorm"):
             self.w[nm] = (g(nm + ".weight").float().contiguous(), g(nm + ".bias").float().contiguous())
         for nm in ("q_layernorm_xattn", "k_layernorm_xattn"):
@@ -101,7 +114,15 @@ class HipFullyParallelAttention:
         Q = self.hq * self.hd
         x2 = hidden_states.view(s_len, h)
         hln = ops.layernorm(x2, eps, gamma=w["ln_w"], beta=w["ln_b"])
-        mixed = ops.linear(hln, w["qkv"], None)                                          # [s, q | qx | k | v]
+        if self.fp8:                                                                      # [s, q | qx | k | v]
+            KV = self.hk * self.hd
+            mixed = torch.empty(s_len, 2 * Q + 2 * KV, dtype=BF16, device=x2.device)
+            off = 0
+            for nm, n in (("q", Q), ("qx", Q), ("k", KV), ("v", KV)):
+                self.fp8[nm](hln, out=mixed[:, off:off + n])
+                off += n
+        else:
+            mixed = ops.linear(hln, w["qkv"], None)
         if attn_cat is None:
             attn_cat = torch.empty(s_len, 2 * Q, dtype=BF16, device=x2.device)
         q_buf = torch.empty(s_len, Q, dtype=BF16, device=x2.device)
@@ -237,6 +258,7 @@ class HipMagiTransformerLayer:
             raise NotImplementedError("gated_linear_unit (flashinfer silu_and_mul) is not used by MAGI-4.5B and not built")
         self.self_attention = HipFullyParallelAttention(model_config, engine_config, layer_number, device)
         self.w: Dict[str, torch.Tensor] = {}
+        self.fp8: Dict[str, StaticFp8Linear] = {}
 
     def load_state_dict(self, W: Dict[str, torch.Tensor], prefix: str = "") -> None:
         dev = self.device
@@ -246,7 +268,13 @@ class HipMagiTransformerLayer:
         for nm in ("self_attn_post_norm", "mlp_post_norm"):
             self.w[nm] = (g(nm + ".weight").float().contiguous(), g(nm + ".bias").float().contiguous())
         self.w["mlp_ln"] = (g("mlp.layer_norm.weight").to(BF16), g("mlp.layer_norm.bias").to(BF16))
-        self.w["fc1"], self.w["fc2"] = g("mlp.linear_fc1.weight").to(BF16).contiguous(), g("mlp.linear_fc2.weight").to(BF16).contiguous()
+        if prefix + "mlp.linear_fc1.weight_scale" in W:          # fp8_quant: fc1 per-tensor form, fc2 per-channel form (:526, :539)
+            self.fp8["fc1"] = StaticFp8Linear(g("mlp.linear_fc1.weight"), g("mlp.linear_fc1.weight_scale"),
+                                              g("mlp.linear_fc1.input_scale"), g("mlp.linear_fc1.input_scale"))
+            self.fp8["fc2"] = StaticFp8Linear(g("mlp.linear_fc2.weight"), g("mlp.linear_fc2.weight_scale"),
+                                              g("mlp.linear_fc2.input_scale"), g("mlp.linear_fc2.smooth_scale"))
+        else:
+            self.w["fc1"], self.w["fc2"] = g("mlp.linear_fc1.weight").to(BF16).contiguous(), g("mlp.linear_fc2.weight").to(BF16).contiguous()
 
     def gate(self, condition: torch.Tensor) -> torch.Tensor:
         """softcap(AdaModulateLayer(condition)) `[b * ranges, 2h]` (:196-198, :1300-1303)."""
@@ -265,12 +293,16 @@ class HipMagiTransformerLayer:
         if cmap.dtype != torch.int32:
             cmap = cmap.to(torch.int32)
         attn_cat = self.self_attention.forward(hidden_states, y_xattn_flat, inference_params, rotary_pos_emb, meta_args)
-        proj = ops.linear(attn_cat, self.self_attention.w["proj"], None)
+        sa = self.self_attention
+        proj = sa.fp8["proj"](attn_cat) if sa.fp8 else ops.linear(attn_cat, sa.w["proj"], None)
         gate = self.gate(condition)
         hs = ops.magi_gate_norm_residual(proj, x2, cmap, gate[:, :h], *w["self_attn_post_norm"], eps, one_p)
         m = ops.layernorm(hs, eps, gamma=w["mlp_ln"][0], beta=w["mlp_ln"][1])
-        m = ops.linear(m, w["fc1"], None, epilogue=_hip.IFX_EPI_GELU_ERF)
-        m = ops.linear(m, w["fc2"], None)
+        if self.fp8:
+            m = self.fp8["fc2"](self.fp8["fc1"](m, epilogue=_hip.IFX_EPI_GELU_ERF))
+        else:
+            m = ops.linear(m, w["fc1"], None, epilogue=_hip.IFX_EPI_GELU_ERF)
+            m = ops.linear(m, w["fc2"], None)
         out = ops.magi_gate_norm_residual(m, hs, cmap, gate[:, h:], *w["mlp_post_norm"], eps, one_p)
         return out.view(s_len, bsz, h)
 

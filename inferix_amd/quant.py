@@ -78,14 +78,17 @@ class StaticFp8Linear:
         self.in_scale = input_scale.reshape(-1)[:1].float().to(dev).contiguous()
         self.divisor = divisor.reshape(-1).float().to(dev).contiguous()
         assert self.divisor.numel() in (1, self.in_features)
+        self._sx: Optional[torch.Tensor] = None          # per-row activation scale (one value repeated), kept between calls
 
-    def __call__(self, x: torch.Tensor, **epilogue) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, **epilogue) -> torch.Tensor:
+        """`out`: optional `[rows, out_features]` destination (any row stride: a column block of a wider buffer)."""
         from . import hip_ops as ops
         x2 = x.reshape(-1, self.in_features)
         q = ops.quant_static(x2, self.divisor, _hip.IFX_Q_FP8_E4M3, via_bf16=True)
-        sx = self.in_scale.expand(x2.shape[0]).contiguous()
-        y = ops.linear_q8(q, sx, self.weight, self.w_scale, None, _hip.IFX_Q_FP8_E4M3, **epilogue)
-        return y.view(*x.shape[:-1], self.out_features)
+        sx = self._sx if self._sx is not None and self._sx.shape[0] == x2.shape[0] else self.in_scale.expand(x2.shape[0]).contiguous()
+        self._sx = sx
+        y = ops.linear_q8(q, sx, self.weight, self.w_scale, None, _hip.IFX_Q_FP8_E4M3, out=out, **epilogue)
+        return y if out is not None else y.view(*x.shape[:-1], self.out_features)
 
 
 def quantize_weight(w: torch.Tensor, qc: QConfig) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -60,7 +60,7 @@ def scenario(cfg: MB.MagiLayerConfig, clip: int, caps, seed: int):
     return calls
 
 
-def run_reference(cfg: MB.MagiLayerConfig, n_layers: int, calls, wseed: int, max_tokens: int):
+def run_reference(cfg: MB.MagiLayerConfig, n_layers: int, calls, wseed: int, max_tokens: int, fp8: bool = False):
     import importlib
     dm = _refstub.import_magi_dit()
     cfgm = importlib.import_module("inferix.core.config")
@@ -73,7 +73,7 @@ def run_reference(cfg: MB.MagiLayerConfig, n_layers: int, calls, wseed: int, max
                           params_dtype=BF, cond_hidden_ratio=cfg.cond_hidden_ratio,
                           xattn_cond_hidden_ratio=cfg.xattn_cond_hidden_ratio, cond_gating_ratio=cfg.cond_gating_ratio,
                           gated_linear_unit=cfg.gated_linear_unit)
-    ec = cfgm.EngineConfig(cp_size=1, cp_strategy="none", fp8_quant=False, kv_offload=False)
+    ec = cfgm.EngineConfig(cp_size=1, cp_strategy="none", fp8_quant=fp8, kv_offload=False)
     layers = []
     for li in range(n_layers):
         layer = dm.TransformerLayer(mc, ec, layer_number=li)
@@ -82,7 +82,7 @@ def run_reference(cfg: MB.MagiLayerConfig, n_layers: int, calls, wseed: int, max
                 continue
             if any(t in name for t in ("q_layernorm", "k_layernorm", "self_attn_post_norm", "mlp_post_norm")):
                 sub.float()
-        W = MB.init_layer_weights(cfg, wseed + li)
+        W = MB.init_layer_weights(cfg, wseed + li, fp8=fp8 and MB.layer_is_fp8(li, max(n_layers, 3)))
         missing = layer.load_state_dict(W, strict=True)
         assert not missing.missing_keys and not missing.unexpected_keys
         for n, p in layer.named_parameters():
@@ -123,8 +123,8 @@ def run_reference(cfg: MB.MagiLayerConfig, n_layers: int, calls, wseed: int, max
     return outs, caches
 
 
-def run_oracle(cfg, n_layers, calls, wseed, max_tokens, want_taps=False):
-    Ws = [MB.init_layer_weights(cfg, wseed + li) for li in range(n_layers)]
+def run_oracle(cfg, n_layers, calls, wseed, max_tokens, want_taps=False, fp8=False):
+    Ws = [MB.init_layer_weights(cfg, wseed + li, fp8=fp8 and MB.layer_is_fp8(li, max(n_layers, 3))) for li in range(n_layers)]
     caches = [MB.MagiLayerCache(max_tokens, cfg.num_query_groups, cfg.kv_channels) for _ in range(n_layers)]
     outs, taps_all = [], []
     for inp, m in calls:
@@ -151,13 +151,14 @@ TAPS = ("q", "k", "v", "core", "xattn", "proj", "gate", "attn_res", "mlp")
 
 
 def build(name: str, cfg: MB.MagiLayerConfig, n_layers: int, clip: int, caps, seed: int, wseed: int, n_calls: int,
-          tap_names=TAPS):
+          tap_names=TAPS, fp8: bool = False):
     calls = scenario(cfg, clip, caps, seed)[:n_calls]
     max_tokens = 4 * clip
-    ref_outs, ref_caches = run_reference(cfg, n_layers, calls, wseed, max_tokens)
-    orc_outs, orc_caches, taps = run_oracle(cfg, n_layers, calls, wseed, max_tokens, want_taps=True)
+    ref_outs, ref_caches = run_reference(cfg, n_layers, calls, wseed, max_tokens, fp8)
+    orc_outs, orc_caches, taps = run_oracle(cfg, n_layers, calls, wseed, max_tokens, want_taps=True, fp8=fp8)
     fx = {"geom": torch.tensor([cfg.hidden_size, cfg.ffn_hidden_size, cfg.num_attention_heads, cfg.num_query_groups,
-                                cfg.kv_channels, n_layers, clip, len(calls), wseed, max_tokens])}
+                                cfg.kv_channels, n_layers, clip, len(calls), wseed, max_tokens]),
+          "fp8_quant": torch.tensor(int(fp8))}
     written = 0
     for ci, (inp, m) in enumerate(calls):
         for k, v in inp.items():
@@ -193,6 +194,9 @@ def main():
     # 2 x 48 tokens: not a multiple of the 64-row kernel tiles; two intermediate tensors only (bf16 noise does not compress)
     build("magi_block_real", MB.MagiLayerConfig(), n_layers=1, clip=48, caps=(40, 25), seed=12, wseed=600, n_calls=2,
           tap_names=("core", "attn_res"))
+    # engine_config.fp8_quant (the 4.5B distill-quant config): three layers, the middle one on the static-scale FP8 linears
+    build("magi_block_fp8_tiny", MB.tiny_config(), n_layers=3, clip=24, caps=(7, 5), seed=13, wseed=700, n_calls=3,
+          tap_names=("proj", "mlp"), fp8=True)
 
 
 if __name__ == "__main__":

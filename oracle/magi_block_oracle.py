@@ -90,7 +90,38 @@ def param_shapes(cfg: MagiLayerConfig) -> Dict[str, Tuple[int, ...]]:
     }
 
 
-def init_layer_weights(cfg: MagiLayerConfig, seed: int) -> Dict[str, torch.Tensor]:
+FP8_PER_TENSOR = ("self_attention.linear_qkv.q", "self_attention.linear_qkv.qx", "self_attention.linear_qkv.k",
+                  "self_attention.linear_qkv.v", "mlp.linear_fc1")            # PerTensorQuantizedFp8Linear (dit_module.py:413, :526)
+FP8_PER_CHANNEL = ("self_attention.linear_proj", "mlp.linear_fc2")           # PerChannelQuantizedFp8Linear (:867, :539)
+
+
+def layer_is_fp8(layer_number: int, num_layers: int) -> bool:
+    """Which layers of an fp8_quant model hold FP8 linears: all but the first and the last (dit_module.py:410, :526, :864-866)."""
+    return layer_number != 0 and layer_number != num_layers - 1
+
+
+def to_fp8_layer_weights(W: Dict[str, torch.Tensor], seed: int) -> Dict[str, torch.Tensor]:
+    """The parameter set of a layer built with `engine_config.fp8_quant` (layers other than the first and the last): the seven
+    linears hold e4m3 weights `[1, out, in]` + `weight_scale [1]` + `input_scale` (`[in]` per-tensor form / `[1]` per-channel
+    form) + `smooth_scale [1, in]` (per-channel form).  Synthetic scales: weight_scale = amax / 448; activation divisors
+    around 0.03 with +-20 % spread per input channel, so that x / divisor stays well inside +-448 for unit-scale activations."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    out = dict(W)
+    for name in FP8_PER_TENSOR + FP8_PER_CHANNEL:
+        w = W[name + ".weight"].float()
+        ws = (w.abs().max() / 448.0).reshape(1)
+        out[name + ".weight"] = (w / ws).to(torch.float8_e4m3fn).unsqueeze(0)
+        out[name + ".weight_scale"] = ws.float()
+        spread = 0.03 * (1.0 + 0.2 * (2 * torch.rand(w.shape[1], generator=g) - 1))
+        if name in FP8_PER_TENSOR:
+            out[name + ".input_scale"] = spread.float()
+        else:
+            out[name + ".input_scale"] = torch.tensor([0.03])
+            out[name + ".smooth_scale"] = spread.float().unsqueeze(0)
+    return out
+
+
+def init_layer_weights(cfg: MagiLayerConfig, seed: int, fp8: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded synthetic weights (no checkpoint exists offline): matrices ~ N(0, 1/fan_in) so that activations keep unit
     scale through the layer, norm weights ~ N(0, 0.1) (they are `1 + w` under apply_layernorm_1p), biases ~ N(0, 0.1).
     The golden generator loads exactly these into the reference module."""
@@ -104,7 +135,7 @@ def init_layer_weights(cfg: MagiLayerConfig, seed: int) -> Dict[str, torch.Tenso
         else:
             t = 0.1 * torch.randn(shape, generator=g)
         W[name] = t.float() if name.startswith(FP32_PARAMS) else t.to(BF)
-    return W
+    return to_fp8_layer_weights(W, seed) if fp8 else W
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -201,19 +232,25 @@ def layer_forward(W: Dict[str, torch.Tensor], cfg: MagiLayerConfig, x: torch.Ten
     s_len, bsz, h = x.shape
     assert bsz == 1, "the cached MAGI path runs batch 1 (3-cfg folds ranges into the batch upstream)"
     tap = (lambda k, v: taps.__setitem__(k, v)) if taps is not None else (lambda k, v: None)
+
+    def lin(t: torch.Tensor, name: str) -> torch.Tensor:         # nn.Linear, or the static-scale FP8 linear of an fp8_quant layer
+        if name + ".weight_scale" in W:
+            div = W[name + ".smooth_scale"] if name + ".smooth_scale" in W else W[name + ".input_scale"]
+            return fp8_static_linear(t, W[name + ".weight"], W[name + ".weight_scale"], W[name + ".input_scale"], div)
+        return F.linear(t, W[name + ".weight"])
     sin_emb, cos_emb = rope.tensor_split(2, -1)                                          # :1097
     # ---- CustomLayerNormLinear.forward_ln + the four projections (:415-431)
     hln = F.layer_norm(x, (h,), W[p + "linear_qkv.layer_norm.weight"], W[p + "linear_qkv.layer_norm.bias"], eps)
     tap("hln", hln)
 
     def qk(name: str, ln: str) -> torch.Tensor:                                          # get_q / get_k (:902-934)
-        t = F.linear(hln, W[p + f"linear_qkv.{name}.weight"])
+        t = lin(hln, p + f"linear_qkv.{name}")
         t = t.reshape(s_len, bsz, -1, hd).float()
         t = fused_layer_norm(t, W[p + ln + ".weight"], W[p + ln + ".bias"], cfg)
         t = apply_rotary(t.transpose(0, 1).contiguous(), cos_emb, sin_emb).to(BF)
         return t.transpose(0, 1).reshape(s_len * bsz, -1, hd).contiguous()               # "b sq hn hd -> (sq b) hn hd"
     q, k = qk("q", "q_layernorm"), qk("k", "k_layernorm")
-    v = F.linear(hln, W[p + "linear_qkv.v.weight"]).reshape(s_len * bsz, -1, hd).contiguous()
+    v = lin(hln, p + "linear_qkv.v").reshape(s_len * bsz, -1, hd).contiguous()
     tap("q", q), tap("k", k), tap("v", v)
     if cache is not None:
         key, value = cache.adjust(k, v, slice_point=meta.slice_point, clip=meta.clip_token_nums,
@@ -227,7 +264,7 @@ def layer_forward(W: Dict[str, torch.Tensor], cfg: MagiLayerConfig, x: torch.Ten
     core = core.reshape(s_len, bsz, -1)
     tap("core", core)
     # ---- cross_attention / get_xqkv (:954-970, :1047-1085)
-    qx = F.linear(hln, W[p + "linear_qkv.qx.weight"]).transpose(0, 1).reshape(bsz * s_len, -1, hd)
+    qx = lin(hln, p + "linear_qkv.qx").transpose(0, 1).reshape(bsz * s_len, -1, hd)
     qx = fused_layer_norm(qx, W[p + "q_layernorm_xattn.weight"], W[p + "q_layernorm_xattn.bias"], cfg)
     kvx = torch.cat([torch.matmul(y_xattn_flat, w.t()) for w in torch.chunk(W[p + "linear_kv_xattn.weight"], 8, dim=0)],
                     dim=1)
@@ -242,7 +279,7 @@ def layer_forward(W: Dict[str, torch.Tensor], cfg: MagiLayerConfig, x: torch.Ten
     # ---- attn_linear_proj (:1281-1295): "sq b (n hn hd) -> sq b (hn n hd)", n = 2, hn = 8 HARD-CODED
     a = torch.cat([core, xo], dim=2)
     a = a.reshape(s_len, bsz, 2, 8, -1).transpose(2, 3).reshape(s_len, bsz, -1)
-    a = F.linear(a, W[p + "linear_proj.weight"])
+    a = lin(a, p + "linear_proj")
     tap("proj", a)
     # ---- gating_and_mlp (:1297-1319)
     gate = F.linear(F.silu(condition), W["ada_modulate_layer.proj.0.weight"], W["ada_modulate_layer.proj.0.bias"])
@@ -259,13 +296,13 @@ def layer_forward(W: Dict[str, torch.Tensor], cfg: MagiLayerConfig, x: torch.Ten
     hs = bias_modulate_add(a, x, gate_msa, "self_attn_post_norm")
     tap("attn_res", hs)
     m = F.layer_norm(hs, (h,), W["mlp.layer_norm.weight"], W["mlp.layer_norm.bias"], eps)  # CustomMLP.forward (:545-557)
-    m = F.linear(m, W["mlp.linear_fc1.weight"])
+    m = lin(m, "mlp.linear_fc1")
     if cfg.gated_linear_unit:
         d = m.shape[-1] // 2
         m = F.silu(m[..., :d]) * m[..., d:]                                              # flashinfer silu_and_mul (published)
     else:
         m = F.gelu(m)
-    m = F.linear(m, W["mlp.linear_fc2.weight"])
+    m = lin(m, "mlp.linear_fc2")
     tap("mlp", m)
     return bias_modulate_add(m, hs, gate_mlp, "mlp_post_norm")
 

@@ -417,3 +417,56 @@ def test_layer_under_cp_shuffle_overlap_two_ranks_matches_single_device_golden()
             got = outs[r][ci]
             assert got.shape == ref.shape
             assert rel_l2(got, ref) < 1e-2, (ci, r, rel_l2(got, ref))
+
+
+def test_fp8_quant_layer_stack_vs_reference_golden():
+    """`engine_config.fp8_quant` (the 4.5B distill-quant config of BASELINE config 5): three layers, the middle one on the
+    static-scale FP8 linears (q / qx / k / v / fc1 per-tensor form, linear_proj / fc2 per-channel form, dit_module.py:408-413,
+    :434-490, :526-539, :867).  Every layer gets the REFERENCE's input of that layer (teacher forcing).  Yardstick for the FP8
+    layer: an e4m3 code flips when a bf16 rounding in front of `div_clamp_to` differs, and the layer re-quantises five times, so
+    two correct evaluations are far apart by bf16 standards — the reference layer ITSELF (the oracle, bit-identical to it) moves
+    by 1.7e-2 rel-L2 when 5 % of its input elements move by one bf16 ULP; the HIP layer must be closer to the reference than that."""
+    from inferix_amd.magi.dit import HipMagiTransformerLayer
+    from inferix_amd.magi.types import InferenceParams
+    fx = golden("magi_block_fp8_tiny.npz")
+    assert int(fx["fp8_quant"]) == 1
+    cfg, n_layers, clip, n_calls, wseed, max_tokens = MB.fixture_geometry(fx)
+    mc, ec = _configs(cfg, n_layers)
+    ec.fp8_quant = True
+    layers, Ws = [], []
+    for li in range(n_layers):
+        layer = HipMagiTransformerLayer(mc, ec, li, "cuda")
+        Ws.append(MB.init_layer_weights(cfg, wseed + li, fp8=MB.layer_is_fp8(li, mc.num_layers)))
+        layer.load_state_dict(Ws[li])
+        assert bool(layer.fp8) == (li == 1) and bool(layer.self_attention.fp8) == (li == 1)
+        layers.append(layer)
+    with pytest.raises(ValueError, match="FP8"):           # a bf16 checkpoint in a layer the config says is quantised
+        HipMagiTransformerLayer(mc, ec, 1, "cuda").load_state_dict(MB.init_layer_weights(cfg, wseed + 1))
+    ip = InferenceParams(1, max_tokens)
+    g = torch.Generator().manual_seed(0)
+    for ci in range(n_calls):
+        inp, m = MB.fixture_call(fx, ci)
+        meta = _meta(m)
+        ip.update_kv_cache = m.update_kv_cache
+        x_in = inp["x"]
+        for li, layer in enumerate(layers):
+            ref = fx[f"c{ci}_out_l{li}"]
+            got = layer(x_in.cuda(), inp["condition"].cuda(), inp["condition_map"].cuda(), inp["y"].cuda(), inp["rope"].cuda(), ip, meta)
+            r = rel_l2(got.cpu(), ref)
+            bar = 6e-3
+            if li == 1 and ci == 0:                          # the reference layer's own response to a 1-ULP nudge of 5 % of its input
+                xi = x_in.view(torch.int16).clone()
+                mask = torch.rand(x_in.shape, generator=g) < 0.05
+                xi[mask] += (torch.randint(0, 2, x_in.shape, generator=g) * 2 - 1).to(torch.int16)[mask]
+                cache = MB.MagiLayerCache(max_tokens, cfg.num_query_groups, cfg.kv_channels)
+                nudged = MB.layer_forward(Ws[1], cfg, xi.view(BF), inp["condition"], inp["condition_map"], inp["y"], inp["rope"], m, cache)
+                bar = rel_l2(nudged, ref)
+                assert bar > 8e-3, bar                       # the yardstick really is of that size
+            elif li == 1:
+                bar = 2e-2
+            print(f"fp8 stack call {ci} layer {li} ({'fp8' if li == 1 else 'bf16'}): hip-vs-ref {r:.3e}  (bar {bar:.3e})")
+            assert r < bar, (ci, li, r, bar)
+            x_in = ref
+    written = int(fx["cache_written"])
+    raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_1")           # K / V of the FP8 layer: fp8 GEMM outputs
+    assert rel_l2(raw[:, :written].cpu(), fx["cache_l1"][:, :written]) < 1.5e-2
