@@ -318,12 +318,13 @@ def causvid_720p_leg(model, device):
                          "traffic": None, "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / ks["launches"], 4)}}
 
 
-def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34):
+def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34, fp8_quant: bool = True):
     """BASELINE config 5, ONE rank of 8 emulated on one GPU (INVALID as a multi-GPU number: the all-to-alls are device copies of
     the bytes the rank would receive, inferix_amd/magi/context_parallel.py `set_cp_emulation`): MAGI-4.5B transformer stack
     (34 layers, hidden 3072, 24 q-heads / 8 kv-groups, ffn 12288), 720 x 720 -> 12150 tokens per chunk, window of 4 denoising
     chunks in flight + 1 clean chunk in the cache (`noise2clean_kvrange = [5, 4, 3, 2]`, example/magi/configs/4.5B), so a forward
-    has 48600 query tokens of which this rank projects 6075 and attends all 48600 with 3 q-heads on 1 kv-head."""
+    has 48600 query tokens of which this rank projects 6075 and attends all 48600 with 3 q-heads on 1 kv-head.  `fp8_quant`: the
+    named config is `4.5B_distill_quant` (`engine_config.fp8_quant = true`): layers 1 .. 32 run the static-scale FP8 linears."""
     from inferix_amd import hip_ops as ops
     from inferix_amd.magi import context_parallel as cpl
     from inferix_amd.magi.dit import HipMagiTransformerLayer, synthetic_layer_state_dict
@@ -331,13 +332,13 @@ def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34):
     mc = SimpleNamespace(num_layers=layers, hidden_size=3072, ffn_hidden_size=12288, num_attention_heads=24, num_query_groups=8,
                          kv_channels=128, layernorm_epsilon=1e-6, apply_layernorm_1p=True, gated_linear_unit=False,
                          cond_hidden_ratio=0.25, xattn_cond_hidden_ratio=1.0, cond_gating_ratio=1.0)
-    ec = SimpleNamespace(cp_size=cp, cp_strategy="cp_ulysses", fp8_quant=False, kv_offload=False, ulysses_overlap_degree=1)
+    ec = SimpleNamespace(cp_size=cp, cp_strategy="cp_ulysses", fp8_quant=fp8_quant, kv_offload=False, ulysses_overlap_degree=1)
     cpl.set_cp_emulation(cp, 0)
     try:
         stack = []
         for li in range(layers):
             layer = HipMagiTransformerLayer(mc, ec, li, device)
-            layer.load_state_dict(synthetic_layer_state_dict(mc, seed=li, device=device))
+            layer.load_state_dict(synthetic_layer_state_dict(mc, seed=li, device=device, fp8=fp8_quant and 0 < li < layers - 1))
             stack.append(layer)
         clip, ranges, caption = 12150, 4, 100
         s_all = ranges * clip
@@ -376,7 +377,7 @@ def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34):
         out = forward()
         torch.cuda.synchronize()
         assert torch.isfinite(out.float()).all()
-        t = ops.KernelTimer(names=("attn_magi", "gemm"))
+        t = ops.KernelTimer(names=("attn_magi", "gemm", "gemm_q8"))
         ops.set_kernel_timer(t)
         t0 = time.perf_counter()
         n = 2
@@ -387,6 +388,7 @@ def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34):
         ops.set_kernel_timer(None)
         ks = t.summary()
         at, ge = ks["attn_magi"], ks["gemm"]
+        g8 = ks.get("gemm_q8", {"ms": 0.0, "flops": 0.0, "launches": 0})
         atf, gtf = at["flops"] / (at["ms"] * 1e-3) / 1e12, ge["flops"] / (ge["ms"] * 1e-3) / 1e12
         return {"workload": f"config 5 (MAGI-4.5B, 720x720, chunk 12150 tokens, 4 denoising chunks + 1 clean chunk), ONE rank of cp={cp} "
                             f"emulated on one GPU: {s_loc} local tokens, {cp and 24 // cp} q-heads on 1 kv-head over {s_all} queries x "
@@ -398,7 +400,9 @@ def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34):
                 "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (MAGI range attention, 3 q-heads on 1 kv-head)", "bound": "mfma",
                              "achieved": round(atf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(atf / PEAK_BF16_TFLOPS, 4),
                              "traffic": None, "launches": at["launches"] // n, "avg_launch_ms": round(at["ms"] / at["launches"], 4)},
-                "gemm_tflops": round(gtf, 1)}
+                "gemm_tflops": round(gtf, 1), "fp8_quant": bool(fp8_quant),
+                "gemm_fp8_ms": round(g8["ms"] / n, 1),
+                "gemm_fp8_tflops": round(g8["flops"] / (g8["ms"] * 1e-3) / 1e12, 1) if g8["ms"] else None}
     finally:
         ops.set_kernel_timer(None)
         cpl.set_cp_emulation(None)
@@ -619,7 +623,9 @@ def main():
             torch.cuda.empty_cache()
             res["causvid_720p"] = causvid_720p_leg(model, device)
             res["config1_gpu"] = config1_gpu(model, gen, device)
-            res["magi_cp8_emulated"] = magi_cp8_emulated_leg(device)
+            res["magi_cp8_emulated"] = magi_cp8_emulated_leg(device)                          # the named config: fp8_quant
+            bf = magi_cp8_emulated_leg(device, fp8_quant=False)
+            res["magi_cp8_emulated"]["bf16_weights"] = {k: bf[k] for k in ("ms_per_denoise_forward_rank", "attn_ms", "gemm_ms", "gemm_tflops")}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_layers)
             if "config1_gpu" in res:

@@ -329,7 +329,7 @@ class HipMagiTransformerBlock:
     __call__ = forward
 
 
-def synthetic_layer_state_dict(model_config, seed: int = 0, device="cuda") -> Dict[str, torch.Tensor]:
+def synthetic_layer_state_dict(model_config, seed: int = 0, device="cuda", fp8: bool = False) -> Dict[str, torch.Tensor]:
     """Random weights of ONE layer with the reference's state-dict keys and dtypes (bf16 parameters, fp32 q/k layer norms and post
     norms — dit_model.py:620-637), generated on the device: benchmarks and smoke runs (no checkpoint exists offline).  Matrices
     ~ N(0, 1/fan_in) so that activations keep unit scale through the stack."""
@@ -352,4 +352,18 @@ def synthetic_layer_state_dict(model_config, seed: int = 0, device="cuda") -> Di
                       ("self_attention.q_layernorm_xattn", hd, BF16), ("self_attention.k_layernorm_xattn", hd, BF16),
                       ("self_attn_post_norm", h, torch.float32), ("mlp_post_norm", h, torch.float32)):
         sd[nm + ".weight"], sd[nm + ".bias"] = vec(n, dt), vec(n, dt)
+    if fp8:       # an inner layer of an fp8_quant checkpoint: e4m3 weights [1, out, in] + static scales (dit_module.py:434-490)
+        for nm, per_channel in (("self_attention.linear_qkv.q", False), ("self_attention.linear_qkv.qx", False),
+                                ("self_attention.linear_qkv.k", False), ("self_attention.linear_qkv.v", False),
+                                ("mlp.linear_fc1", False), ("self_attention.linear_proj", True), ("mlp.linear_fc2", True)):
+            wf = sd[nm + ".weight"].float()
+            ws = (wf.abs().max() / 448.0).reshape(1)
+            sd[nm + ".weight"] = (wf / ws).to(torch.float8_e4m3fn).unsqueeze(0)
+            sd[nm + ".weight_scale"] = ws
+            spread = 0.03 * (1.0 + 0.2 * (2 * torch.rand(wf.shape[1], generator=g, device=device) - 1))
+            if per_channel:
+                sd[nm + ".input_scale"] = torch.full((1,), 0.03, device=device)
+                sd[nm + ".smooth_scale"] = spread.unsqueeze(0)
+            else:
+                sd[nm + ".input_scale"] = spread
     return sd
