@@ -139,26 +139,54 @@ class PeerStoreExchange:
         self._views: Dict[Tuple[int, int], Tuple[List[int], List[int]]] = {}
         self._epoch = [0] * self.MAX_LAYERS
         self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        self.flags = ops.PeerBuffer(self.MAX_LAYERS * 2 * _hip.IFX_MAX_PEERS * 4, fine_grained=True)
-        self.peer_flags = [self.flags.ptr] if self.emulated else self._exchange_addresses(self.flags.ptr)
+        try:
+            self.flags = ops.PeerBuffer(self.MAX_LAYERS * 2 * _hip.IFX_MAX_PEERS * 4, fine_grained=True)
+        except Exception:                                   # noqa: BLE001 — reported through the collective below, on every rank
+            self.flags = None
+        if self.emulated:
+            if self.flags is None:
+                raise RuntimeError("peer-store exchange: could not allocate the flag block")
+            self.peer_flags = [self.flags.ptr]
+        else:
+            self.peer_flags = self._exchange_addresses(self.flags.ptr if self.flags is not None else None)
 
     # ---- addresses ----
-    def _exchange_addresses(self, ptr: int) -> List[int]:
-        """This rank's device address `ptr` -> the same buffer of every rank, mapped into this process (rank order)."""
+    def _exchange_addresses(self, ptr: Optional[int]) -> List[int]:
+        """This rank's device address `ptr` -> the same buffer of every rank, mapped into this process (rank order).  Every rank
+        runs the same two collectives whatever fails locally, and all ranks raise together: a rank must never sit in a collective
+        its peers have left (the caller falls back to the all-gather exchange)."""
         from . import hip_ops as ops
-        mine = ops.peer_export(ptr)
+        mine = None
+        if ptr is not None:
+            try:
+                mine = ops.peer_export(ptr)
+            except Exception as exc:                        # noqa: BLE001
+                mine = None
+                self._last_error = str(exc)
         everyone: List = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.group)
-        out = []
-        for p, (handle, offset) in enumerate(everyone):
-            if p == self.rank:
-                out.append(ptr)
-                continue
-            base = self._opened.get(handle)
-            if base is None:
-                base = ops.peer_open(handle)
-                self._opened[handle] = base
-            out.append(base + offset)
+        out: List[int] = []
+        ok = all(e is not None for e in everyone)
+        if ok:
+            try:
+                for p, (handle, offset) in enumerate(everyone):
+                    if p == self.rank:
+                        out.append(ptr)
+                        continue
+                    base = self._opened.get(handle)
+                    if base is None:
+                        base = ops.peer_open(handle)
+                        self._opened[handle] = base
+                    out.append(base + offset)
+            except Exception as exc:                        # noqa: BLE001
+                ok = False
+                self._last_error = str(exc)
+        votes: List = [None] * self.world
+        dist.all_gather_object(votes, bool(ok), group=self.group)
+        if not all(votes):
+            bad = [r for r, v in enumerate(votes) if not v]
+            raise RuntimeError(f"peer-store exchange: IPC export / mapping failed on rank(s) {bad}"
+                               + (f" ({self._last_error})" if getattr(self, "_last_error", None) else ""))
         return out
 
     def cache_addresses(self, view) -> Tuple[List[int], List[int]]:
@@ -207,9 +235,11 @@ class PeerStoreExchange:
         if not self.emulated:
             ops.peer_wait(self.flags.ptr + 4 * self._index(layer, self.DONE), self.world, epoch, self.timeout_ms, self.status)
 
-    def self_test(self) -> bool:
-        """One ready / push / done round through a small scratch cache, checked on every rank and agreed on over the process group:
-        True only if every rank saw every rank's rows.  Call once after construction (collective); a False means "use the all-gather"."""
+    def self_test(self, rounds: int = 3) -> bool:
+        """Ready / push / done rounds through a small scratch cache, with the CONSUMER in the position the attention kernel has in a
+        layer: a device copy enqueued right behind `wait_done` on the same stream, no host synchronisation in between (a stale
+        cache line of the previous round would show).  Checked on every rank and agreed on over the process group: True only if
+        every rank saw every rank's rows in every round.  Collective; a False means "use the all-gather"."""
         from . import hip_ops as ops
         if self.emulated:
             return True
@@ -221,27 +251,37 @@ class PeerStoreExchange:
             kc = torch.zeros(self.world * rows, H, hd, dtype=torch.bfloat16, device=dev)
             vc = torch.zeros_like(kc)
             view = ops.KvCacheView(kc, vc)
-            kv = torch.full((rows, 2 * d), float(self.rank + 1), dtype=torch.bfloat16, device=dev)
+            addr_ok = True
+            try:
+                ks, vs = self.cache_addresses(view)
+            except RuntimeError:                               # raised on every rank together (see _exchange_addresses)
+                addr_ok = False
+            if not addr_ok:
+                return False
             wk = torch.ones(d, dtype=torch.bfloat16, device=dev)
-            ks, vs = self.cache_addresses(view)
             layer = self.MAX_LAYERS - 1
-            self._epoch[layer] += 1
-            e = self._epoch[layer]
-            ops.peer_signal(self.peer_flags, self._index(layer, self.READY) + self.rank, e)
-            ops.peer_wait(self.flags.ptr + 4 * self._index(layer, self.READY), self.world, e, self.timeout_ms, self.status)
-            ops.rmsnorm_rope_kv_push(kv, wk, 1e-6, None, ks, vs, view, 0, self.world * rows, rows, self.rank * rows, d)
-            ops.peer_signal(self.peer_flags, self._index(layer, self.DONE) + self.rank, e)
-            self.wait_done(layer, e)
+            snaps = []
+            for rnd in range(rounds):
+                kv = torch.full((rows, 2 * d), float(self.rank + 1 + 8 * rnd), dtype=torch.bfloat16, device=dev)
+                self._epoch[layer] += 1
+                e = self._epoch[layer]
+                ops.peer_signal(self.peer_flags, self._index(layer, self.READY) + self.rank, e)
+                ops.peer_wait(self.flags.ptr + 4 * self._index(layer, self.READY), self.world, e, self.timeout_ms, self.status)
+                ops.rmsnorm_rope_kv_push(kv, wk, 1e-6, None, ks, vs, view, 0, self.world * rows, rows, self.rank * rows, d)
+                ops.peer_signal(self.peer_flags, self._index(layer, self.DONE) + self.rank, e)
+                self.wait_done(layer, e)
+                snaps.append(vc.clone())                       # the consumer kernel, stream-ordered behind the wait
             torch.cuda.synchronize()
-            want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(rows)
-            ok = int(self.status.item()) == 0 and torch.equal(vc[:, 0, 0].float(), want) and bool((kc[:, 0, 0].float() > 0).all())
+            ok = int(self.status.item()) == 0
+            for rnd, snap in enumerate(snaps):
+                want = (torch.arange(1, self.world + 1, dtype=torch.float32, device=dev) + 8 * rnd).repeat_interleave(rows)
+                ok = ok and torch.equal(snap[:, 0, 0].float(), want) and torch.equal(snap[:, H - 1, hd - 1].float(), want)
         except Exception:                                      # noqa: BLE001 — any failure here means "do not use this path"
             ok = False
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
         votes: List = [None] * self.world
-        dist.all_gather_object(votes, int(flag.item()), group=self.group)
+        dist.all_gather_object(votes, bool(ok), group=self.group)
         self.status.zero_()
-        return all(v == 1 for v in votes)
+        return all(votes)
 
     def check(self) -> None:
         """Raise if a wait gave up (synchronises: call at a point that synchronises anyway)."""
@@ -256,7 +296,8 @@ class PeerStoreExchange:
             ops.peer_close(base)
         self._opened.clear()
         self._views.clear()
-        self.flags.free()
+        if self.flags is not None:
+            self.flags.free()
 
 
 class HipSequenceParallel:
@@ -301,6 +342,13 @@ class HipSequenceParallel:
             model._evict(mgr, req, name, view, step)
             view = model._kv_view(mgr, req, name)
         have_prefix = step.local_start > 0
+        if self.peer is not None:
+            try:                                            # first use of a cache tensor: handles travel (collective, main stream)
+                self.peer.cache_addresses(view)
+            except RuntimeError as exc:                     # raised on every rank together: all fall back to the collective
+                import warnings
+                warnings.warn(f"peer-store exchange disabled, using the all-gather: {exc}")
+                self.peer = None
         side = self.overlap and dev.type == "cuda"
         st = dict(step=step, view=view, n_local=n_local, side=side, have_prefix=have_prefix, layer=l, epoch=0)
         main = torch.cuda.current_stream(dev) if side else None
