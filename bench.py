@@ -427,8 +427,9 @@ def main():
     ap.add_argument("--sp-exchange", choices=["auto", "allgather", "peer"], default="auto",
                     help="N > 1: K/V exchange per layer — one RCCL all-gather, or direct peer stores through HIP IPC mappings; auto = peer "
                          "stores when their self-test passes on every rank, else the all-gather")
-    ap.add_argument("--sp-fused-qkv", action="store_true", help="N > 1, debug: one fused q/k/v projection before the exchange starts "
-                                                                 "(default: K/V projection first, the exchange runs under the q projection)")
+    ap.add_argument("--sp-qkv", choices=["auto", "fused", "kv-first"], default="auto",
+                    help="N > 1: one fused q/k/v projection before the exchange starts, or the K/V projection first so that the exchange "
+                         "runs under the q projection; auto = kv-first in front of the all-gather, fused in front of the peer stores")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -490,12 +491,12 @@ def main():
             if peer is None and a.sp_exchange == "peer":
                 raise SystemExit("--sp-exchange peer: the peer-store self-test failed")
         exchange_used = "peer_store" if peer is not None else "allgather"
-        attach_sequence_parallel(model, dist.group.WORLD, peer=peer, kv_first=not a.sp_fused_qkv)
+        attach_sequence_parallel(model, dist.group.WORLD, peer=peer, kv_first={'auto': None, 'fused': False, 'kv-first': True}[a.sp_qkv])
     elif a.emulate_sp > 1:
         from inferix_amd.sequence_parallel import LoopbackExchange, PeerStoreExchange, attach_sequence_parallel
         peer = PeerStoreExchange(emulate_world=a.emulate_sp) if a.sp_exchange == "peer" else None
         exchange_used = "peer_store(emulated)" if peer is not None else "allgather(emulated)"
-        attach_sequence_parallel(model, exchange=LoopbackExchange(a.emulate_sp, 0), peer=peer, kv_first=not a.sp_fused_qkv)
+        attach_sequence_parallel(model, exchange=LoopbackExchange(a.emulate_sp, 0), peer=peer, kv_first={'auto': None, 'fused': False, 'kv-first': True}[a.sp_qkv])
     if a.quant != "none":
         from inferix_amd import quant as Qz
         qc = (Qz.get_dynamic_fp8_per_token_act_per_channel_weight_qconfig() if a.quant == "fp8"

@@ -308,10 +308,13 @@ class HipSequenceParallel:
     (default), or direct peer stores (`peer` = a PeerStoreExchange)."""
 
     def __init__(self, group=None, overlap: bool = True, exchange: Optional[SequenceParallelExchange] = None,
-                 peer: Optional[PeerStoreExchange] = None, kv_first: bool = True):
+                 peer: Optional[PeerStoreExchange] = None, kv_first: Optional[bool] = None):
         self.ex = exchange if exchange is not None else SequenceParallelExchange(group)
         self.peer = peer
-        self.kv_first = kv_first
+        # K/V projection first = the exchange starts one GEMM earlier, at the price of two projection launches and a separate
+        # q norm/RoPE kernel (12 us per layer at 585 rows).  Worth it in front of a collective (~100 us of launch + transfer), not in
+        # front of the peer stores (two flag round trips + 3.6 MB per link), which the prefix attention covers from the second block on.
+        self.kv_first = (peer is None) if kv_first is None else kv_first
         self.overlap = overlap
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._buf: Dict[Tuple, torch.Tensor] = {}
@@ -426,7 +429,7 @@ class HipSequenceParallel:
 
 def attach_sequence_parallel(model, group=None, overlap: bool = True,
                              exchange: Optional[SequenceParallelExchange] = None, peer: Optional[PeerStoreExchange] = None,
-                             kv_first: bool = True) -> HipSequenceParallel:
+                             kv_first: Optional[bool] = None) -> HipSequenceParallel:
     """Enable sequence parallelism on a HipCausalWanModel whose ParallelConfig has world_size > 1."""
     sp = HipSequenceParallel(group, overlap, exchange, peer, kv_first)
     pc = model.parallel_config
