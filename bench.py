@@ -352,7 +352,9 @@ def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34, fp8_quant: bool
         ang = torch.rand(s_loc, 64, generator=g, device=device) * 6.0
         rope = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
         qr = torch.tensor([[i * clip, (i + 1) * clip] for i in range(ranges)], dtype=torch.int32)
-        kr = torch.tensor([[0, (2 + i) * clip] for i in range(ranges)], dtype=torch.int32)      # keys = [1 clean chunk | 4 new]
+        # keys = [1 clean chunk | 4 new]: the named config's schedule for four chunks at steps 48 / 32 / 16 / 0 of 64
+        from inferix_amd.magi.kv_ranges import generate_kvrange_for_denoising_video
+        kr = generate_kvrange_for_denoising_video(clip, 1, ranges, [48, 32, 16, 0], 64, [5, 4, 3, 2], 1)
         core = PackedCoreAttnParams(q_range=qr, k_range=kr, np_q_range=qr.numpy(), np_k_range=kr.numpy(), max_seqlen_q=clip,
                                     max_seqlen_k=(ranges + 1) * clip)
         # this rank's tokens all belong to denoising range 0 (6075 < 12150): one cross-attention segment
