@@ -39,7 +39,6 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 // exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
 // inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
 // otherwise unused `gate_slot` field carries 1 for IFX_EPI_GELU_ERF.
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const unsigned short* __restrict__ x, int ldx,

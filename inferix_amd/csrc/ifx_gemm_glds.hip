@@ -63,7 +63,6 @@ __device__ __forceinline__ float gelu_tanh_f2(float x) {
 // exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
 // inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
 // otherwise unused `gate_slot` field carries 1 for IFX_EPI_GELU_ERF.
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;

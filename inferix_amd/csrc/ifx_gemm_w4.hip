@@ -37,7 +37,6 @@ __device__ __forceinline__ float gelu_tanh_w4(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));   // v_rcp_f32 (1 ulp fp32) instead of the IEEE division sequence
 }
-__device__ __forceinline__ float gelu_erf_w4(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 }  // namespace w4
 
 #define W4_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else if (EPI == IFX_EPI_GELU_TANH) {
         if (ea.gate_slot) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_w4(bf2f(vv[e])));
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_w4(bf2f(vv[e])));

@@ -187,6 +187,33 @@ def test_gate_path_and_gelu_erf_epilogue():
                            what="epilogue == gelu(bf16 GEMM output)")
 
 
+def test_gelu_erf_epilogue_every_bf16_input():
+    """The exact-GELU epilogue (erf from the Chebyshev erfc, ifx_common.h) on EVERY finite bf16 value, passed through a GEMM whose
+    weight picks one input column: bit-identical to torch's fp32 `0.5 x (1 + erf(x / sqrt 2))` rounded to bf16 for x >= -3; below
+    that 1 + erf cancels in fp32 and torch's own vectorised erf and libm's differ in the last bits (a handful of inputs, results
+    ~1e-3 and smaller) — there the bound is one ULP, absolute 2e-6 in the deep tail."""
+    from inferix_amd import _hip
+    from inferix_amd import hip_ops as ops
+    bits = torch.arange(65536, dtype=torch.int32)
+    v = (bits << 16).view(torch.float32)
+    v = v[torch.isfinite(v) & (v.abs() < 1e30) & (v.abs() > 1e-30)].to(BF)       # (-0 cannot pass through a GEMM: 0 * w + (-0) = +0)
+    v = torch.cat([torch.zeros(1, dtype=BF), v])
+    M = v.numel()
+    a = torch.zeros(M, 64, dtype=BF)
+    a[:, 0] = v
+    w = torch.zeros(64, 64, dtype=BF)
+    w[0, 0] = 1.0
+    got = ops.linear(a.cuda(), w.cuda(), None, epilogue=_hip.IFX_EPI_GELU_ERF)[:, 0].cpu()
+    ref = torch.nn.functional.gelu(v.float()).to(BF)
+    head = v.float() >= -3.0
+    assert torch.equal(got[head].view(torch.int16), ref[head].view(torch.int16)), \
+        f"{int((got[head].view(torch.int16) != ref[head].view(torch.int16)).sum())} of {int(head.sum())} inputs differ for x >= -3"
+    tail = ~head
+    assert int((got[tail].view(torch.int16) != ref[tail].view(torch.int16)).sum()) <= 64
+    d = (got[tail].float() - ref[tail].float()).abs()
+    assert bool((d <= torch.clamp(ref[tail].float().abs() * 2.0 ** -7, min=2e-6)).all())      # one bf16 ULP, or 2e-6 in the deep tail
+
+
 def test_strided_attention_matches_dense():
     """ifx_attn_fwd_paged_ld: query rows taken from, and output rows written into, column blocks of wider matrices — bit-identical
     to the dense launch; neighbouring columns untouched.  Shapes of one MAGI rank and of a single-GPU layer."""
