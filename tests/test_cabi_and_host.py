@@ -240,3 +240,19 @@ def test_outer_plugin_refuses_to_run_without_a_gpu(tmp_path):
     bidir.write_text(yaml.safe_dump({"model_kwargs": {}}))
     with pytest.raises(NotImplementedError):
         SelfForcingPipeline(str(bidir))
+
+
+def test_no_transcendental_to_valu_hazard_in_the_built_kernels():
+    """A VALU instruction must not read a v_exp / v_rcp / v_log ... result in the very next slot; the compiler pads its own code but
+    not inline asm (found as -inf attention row sums after a recompile).  tools/check_trans_hazard.py disassembles the
+    gfx950 code objects of the built library and looks for such pairs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "inferix_amd", "libinferix_hip.so")
+    if not (os.path.exists(lib) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        import pytest
+        pytest.skip("library or llvm-objdump not present")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_hazard.py"), lib], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-500:]
