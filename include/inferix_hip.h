@@ -50,8 +50,8 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   18 = four-wave 256x256 on the LDS-DMA ring (experiment), 19 = four-wave 256x256x64 register-staged software
  *                   pipeline (ifx_gemm_w4.hip), 20 = auto including its split-K form when a workspace is given
  *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
- *                   4 free-running schedule, 5 software-pipelined schedule (what 0 = auto picks for large launches),
- *                   6 software-pipelined in four-wave workgroups, two per CU
+ *                   4 free-running schedule, 5 software-pipelined schedule, 6 software-pipelined in four-wave workgroups, two per CU,
+ *                   7 software-pipelined and unrolled four times over constant LDS slots (what 0 = auto picks for large launches)
  * Results are identical across variants up to fp32 summation order.  Returns IFX_EINVAL for unknown keys. */
 int ifx_set_option(const char* key, int32_t value);
 

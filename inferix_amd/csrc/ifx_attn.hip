@@ -395,11 +395,12 @@ int launch_attn_merge(const float* workspace, int slot_cap, int slots_used, unsi
 size_t attn_pp_workspace_bytes(int q_rows, int heads, int splits);
 int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots);
 // schedule of the multi-wave kernel for a launch (the `groups` code of launch_attn_pp): 2 phase-locked ping-pong, 3 three groups
-// (384-row tiles), 4 free-running, 5 software-pipelined, 6 software-pipelined in four-wave workgroups (128-row tiles, two per CU).
-// Auto (variant 0): 5, except for launches whose rows fill 128-row tiles markedly better than 256-row tiles — one rank's 585 rows
+// (384-row tiles), 4 free-running, 5 software-pipelined, 6 software-pipelined in four-wave workgroups (128-row tiles, two per CU),
+// 7 software-pipelined, unrolled four times over constant LDS slots (what auto takes for 256-row tiles).
+// Auto (variant 0): 7, except for launches whose rows fill 128-row tiles markedly better than 256-row tiles — one rank's 585 rows
 // of an eight-way sequence-parallel shard: 5 x 128 (91 %) against 3 x 256 (76 %); one rank's clip 348 -> 332 ms
 static int attn_groups(int variant, int q_rows, int heads = 0) {
-  if (variant == 3 || variant == 4 || variant == 2 || variant == 6) return variant;
+  if (variant == 3 || variant == 4 || variant == 2 || variant == 5 || variant == 6 || variant == 7) return variant;
   if (variant == 0 && q_rows > 0) {
     const int t256 = (q_rows + 255) / 256, t128 = (q_rows + 127) / 128;
     const float u256 = (float)q_rows / (256.f * t256), u128 = (float)q_rows / (128.f * t128);
@@ -414,7 +415,7 @@ static int attn_groups(int variant, int q_rows, int heads = 0) {
       if (c6 < 0.95f * c5) return 6;
     }
   }
-  return 5;
+  return 7;
 }
 static int attn_qt(int groups) { return groups == 3 ? 384 : (groups == 6 ? 128 : 256); }
 static int attn_slots(int groups) { return groups == 6 ? 512 : 256; }
@@ -531,7 +532,7 @@ extern "C" int ifx_attn_fwd_ranges(const ifx_bf16* q, int32_t ldq, ifx_bf16* out
     rows += q1 - q0;
   }
   const int groups = attn_groups(attn_variant(), rows / n_ranges, heads * n_ranges);   // every range tiles separately
-  return launch_attn_pp(q, out, nullptr, kv, q_rows, heads, kmin, kmax, scale, 1, nullptr, groups == 5 || groups == 6 ? groups : 5,
+  return launch_attn_pp(q, out, nullptr, kv, q_rows, heads, kmin, kmax, scale, 1, nullptr, groups == 5 || groups == 6 || groups == 7 ? groups : 7,
                         (hipStream_t)stream, 0, 0, nullptr, ldq, ldo, n_ranges, q_ranges, k_ranges);
 }
 

@@ -161,8 +161,15 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   // FR = 3 (attn_variant 6): the software-pipelined loop in FOUR-wave workgroups of 128 queries, TWO of them per CU (80 KiB of
   // LDS each: K ring 2, V ring 3).  The two waves of a SIMD then belong to different workgroups: no barrier couples them, so
   // the older wave no longer waits ~600 cycles per tile for the younger one; the price is that each workgroup streams K/V itself.
-  constexpr bool SWP = FR >= 2, DUAL = FR == 3;
-  constexpr int PD = FR == 2 ? 3 : pp::PD, RK = DUAL ? 2 : (FR == 2 ? 3 : pp::RK), RV = DUAL ? 3 : (FR == 2 ? 5 : pp::RV), V_OFF = RK * 16384;
+  // FR = 5 (attn_variant 7): the software-pipelined loop unrolled FOUR times over rings of 4 K + 4 V tiles, so that every LDS slot is
+  // a compile-time constant: a fragment read is `ds_read v_term offset:imm` with 12 lane terms computed once per kernel, where the
+  // two-times-unrolled loop re-derives its addresses every tile (56 of the 177 non-MFMA VALU instructions of a tile; the loop is
+  // bound by VALU issue).  V ring first (imm offsets reach 64 KiB), K ring behind it; K is requested three tiles ahead,
+  // V two (it is consumed two iterations later), which is what lets four V slots do.
+  constexpr bool SWP = FR >= 2, DUAL = FR == 3, U4 = FR == 5;
+  constexpr int PD = (FR == 2 || U4) ? 3 : pp::PD, RK = DUAL ? 2 : (U4 ? 4 : (FR == 2 ? 3 : pp::RK)),
+                RV = DUAL ? 3 : (U4 ? 4 : (FR == 2 ? 5 : pp::RV));
+  constexpr int K_OFF = U4 ? 65536 : 0, V_OFF = U4 ? 0 : RK * 16384;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = (NG == 2 && PP_GROUP) ? (wave & 1) : (wave >> 2);
@@ -546,7 +553,22 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       return a0 + a1;
     };
     // iteration t: sC = S(t) -> pC = P(t) (softmax), pP = P(t-1) -> O (PV), sN = S(t+1) (QK)
-    auto body = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) -> float {
+    // U4: lane terms of the fragment reads, once per kernel (K_OFF folded into the K terms; V_OFF = 0)
+    int kterm[8], vterm[4];
+    if (U4) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        kterm[ks] = K_OFF + l31 * 256 + (((2 * ks + hi) ^ kswz) << 4);
+        asm volatile("" : "+v"(kterm[ks]));
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        vterm[d] = (4 * hi + v_rowq) * 256 + v_in + ((d ^ v_rowq) << 6);
+        asm volatile("" : "+v"(vterm[d]));
+      }
+    }
+    auto body = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2], auto kslot_c, auto vslot_c) -> float {
+      constexpr int KSLOT = decltype(kslot_c)::value, VSLOT = decltype(vslot_c)::value;     // U4 only (-1 otherwise)
       const unsigned char* kb = smem + K_OFF + ((t + 1) % RK) * 16384;
       const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
 #if PP_SWP_RECOMPUTE
@@ -559,7 +581,21 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       bf16x8 fs[RDs][2];
       auto load = [&](int j) {
         bf16x8(&f)[2] = fs[j % RDs];
-        if (j < 8) {
+        if (U4 && j < 8) {
+          const int bb = j >> 2, sl = (j >> 1) & 1, dh = j & 1;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned char* a0 = smem + vterm[2 * dh + e] + (VSLOT * 16384 + (32 * bb + 16 * sl) * 256);
+            const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+            const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 2048));
+            f[e] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        } else if (U4) {
+          const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            f[e] = *reinterpret_cast<const bf16x8*>(smem + kterm[ks0 + e] + (KSLOT * 16384 + 32 * bb * 256));
+        } else if (j < 8) {
           const int bb = j >> 2, sl = (j >> 1) & 1, dh = j & 1;
           const unsigned char* vr0 = vb + (32 * bb + 16 * sl + 4 * hi + v_rowq) * 256 + v_in;
           const unsigned char* vr1 = vr0 + 8 * 256;
@@ -649,7 +685,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       if (PP_SWP_PACKED) return (accp[0][0] + accp[0][1]) + (accp[1][0] + accp[1][1]);
       return (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     };
-    auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2]) {
+    auto iteration = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2], auto kslot_c, auto vslot_c) {
       long long tr[6] = {0, 0, 0, 0, 0, 0};
       if (PP_TRACE) tr[0] = __builtin_readcyclecounter();
       if (DUAL) {
@@ -679,6 +715,17 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           issue_w(t + 1, wave, 2);
           issue_w(t + 1, wave + 4, 2);
         }
+      } else if (U4) {
+        if (wave < 4) {                                  // K three tiles ahead, V two: four slots each
+          if (t + 3 < NT) {
+            issue_w(t + 3, wave, 1);
+            issue_w(t + 3, wave + 4, 1);
+          }
+          if (t + 2 < NT) {
+            issue_w(t + 2, wave, 2);
+            issue_w(t + 2, wave + 4, 2);
+          }
+        }
       } else if (wave < 4 && t + PD < NT && !(PP_ABLATE & 1)) {
         issue_w(t + PD, wave);
         issue_w(t + PD, wave + 4);
@@ -687,7 +734,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       if (t == NT - 1 && (nkeys & (KT - 1))) mask_ragged(t, sC);
       const float mc0 = m_run * c2;
       v_mcv = pp_f32x2{mc0, mc0};
-      float tile_sum = body(t, sC, sN, pC, pP);
+      float tile_sum = body(t, sC, sN, pC, pP, kslot_c, vslot_c);
       if (PP_TRACE) {
         asm volatile("" ::"v"(tile_sum), "v"(sN[1][15]), "v"(o[3][15]));
         tr[4] = __builtin_readcyclecounter();
@@ -719,13 +766,33 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
+    if (U4) {
+      // V slot 3 is read (times P(-1) = 0) by the PV of iteration 0 before anything was copied there: LDS starts with arbitrary bits
+      *reinterpret_cast<u32x4*>(smem + V_OFF + 3 * 16384 + tid * 32) = u32x4{0, 0, 0, 0};
+      *reinterpret_cast<u32x4*>(smem + V_OFF + 3 * 16384 + tid * 32 + 16) = u32x4{0, 0, 0, 0};
+      if (wave < 4) {                                   // K(0), V(0), K(1), V(1), K(2): everything but K(2) has to land now
+        issue_w(0, wave, 3);
+        issue_w(0, wave + 4, 3);
+        if (NT > 1) {
+          issue_w(1, wave, 3);
+          issue_w(1, wave + 4, 3);
+        }
+        if (NT > 2) {
+          issue_w(2, wave, 1);
+          issue_w(2, wave + 4, 1);
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PD; ++i)
-      if (!DUAL && i < NT && wave < 4) {
+      if (!DUAL && !U4 && i < NT && wave < 4) {
         issue_w(i, wave);
         issue_w(i, wave + 4);
       }
-    if (!DUAL) {
+    if (!DUAL && !U4) {
       const int fl = min(NT, PD) - 1;                  // tiles that may stay in flight behind tile 0 (8 pieces each)
       if (fl <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (fl == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -736,9 +803,19 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     qk_plain(0, s);
     if (NT == 1 && (nkeys & (KT - 1))) mask_ragged(0, s);
     m_run = true_max(s);
-    for (int t = 0; t < NT; t += 2) {
-      iteration(t, s, s2, pb, pb2);
-      if (t + 1 < NT) iteration(t + 1, s2, s, pb2, pb);
+    using ic = std::integral_constant<int, -1>;
+    if (U4) {                                          // iteration t reads K slot (t + 1) % 4 and V slot (t - 1) % 4
+      for (int t = 0; t < NT; t += 4) {
+        iteration(t, s, s2, pb, pb2, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+        if (t + 1 < NT) iteration(t + 1, s2, s, pb2, pb, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        if (t + 2 < NT) iteration(t + 2, s, s2, pb, pb2, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+        if (t + 3 < NT) iteration(t + 3, s2, s, pb2, pb, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+      }
+    } else {
+      for (int t = 0; t < NT; t += 2) {
+        iteration(t, s, s2, pb, pb2, ic{}, ic{});
+        if (t + 1 < NT) iteration(t + 1, s2, s, pb2, pb, ic{}, ic{});
+      }
     }
     if (NT & 1) {                                      // P(NT-1) lives in pb when the last iteration had even parity
     } else {
@@ -1065,7 +1142,7 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
                    hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0,
                    int n_ranges = 0, const int* q_ranges = nullptr, const int* k_ranges = nullptr) {
   using namespace pp;
-  const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : 0));   // attn_variant 4 / 5 / 6
+  const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : (groups == 7 ? 5 : 0)));   // attn_variant 4 / 5 / 6 / 7
   if (fr_mode) groups = fr_mode == 3 ? 1 : 2;
   const int QT = 128 * groups;
   AttnArgsPP a;
@@ -1131,6 +1208,7 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   }
   if (fr_mode == 3) launch_pp_dual(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 2) launch_pp_fr<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else if (fr_mode == 5) launch_pp_fr<5>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 1) launch_pp_fr<1>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (groups == 3) launch_pp_ng<3>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else launch_pp_ng<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);

@@ -250,7 +250,7 @@ def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[tor
 
 
 def set_option(key: str, value: int) -> None:
-    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..20, 'attn_variant' 0..6 (include/inferix_hip.h); 0 = choose by shape."""
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..20, 'attn_variant' 0..7 (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
     _SPLIT_PLAN.clear()          # the split plan depends on the attention schedule
     _GEMM_WS_NEED.clear()        # ... and the workspace a GEMM shape asks for on the tile selection

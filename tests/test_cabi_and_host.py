@@ -42,7 +42,7 @@ def test_cabi_argument_validation_without_gpu():
                                    0, None) == -1                      # row stride of the bytes shorter than the row
     assert lib.ifx_set_option(b"gemm_variant", 20) == 0 and lib.ifx_set_option(b"gemm_variant", 21) != 0
     assert lib.ifx_set_option(b"gemm_variant", 0) == 0
-    assert lib.ifx_set_option(b"attn_variant", 7) != 0 and lib.ifx_set_option(b"no_such_option", 1) != 0
+    assert lib.ifx_set_option(b"attn_variant", 8) != 0 and lib.ifx_set_option(b"no_such_option", 1) != 0
     kv = _hip.KvView(8, 8, None, 1, 100, 12, 64)
     assert lib.ifx_attn_fwd_paged(C.c_void_p(8), C.c_void_p(8), None, C.byref(kv), 4, 12, 0, 10, 0.0, None) == -1
     assert b"head_dim" in lib.ifx_last_error()

@@ -509,7 +509,7 @@ def test_kernels_are_run_to_run_deterministic(ops):
                 return False
         return True
     try:
-        for av in (1, 2, 3, 4, 5, 6):
+        for av in (1, 2, 3, 4, 5, 6, 7):
             ops.set_option("attn_variant", av)
             assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
         ops.set_option("attn_variant", 0)
