@@ -411,7 +411,7 @@ static int attn_groups(int variant, int q_rows, int heads = 0) {
     // (measured 778 -> see profiles/r2_*); the 480p block (228 tiles, one round either way) stays on the 256-row schedule.
     if (heads > 0 && t256 * heads > 256) {
       const float c5 = (float)((t256 * heads + 255) / 256);
-      const float c6 = (float)((t128 * heads + 511) / 512) / 0.934f;
+      const float c6 = (float)((t128 * heads + 511) / 512) / 0.876f;       // 0.934 of schedule 5's rate, which schedule 7 beats by 6.6 %
       if (c6 < 0.95f * c5) return 6;
     }
   }
