@@ -406,12 +406,12 @@ static int attn_groups(int variant, int q_rows, int heads = 0) {
     const float u256 = (float)q_rows / (256.f * t256), u128 = (float)q_rows / (128.f * t128);
     if (u128 > 1.1f * u256) return 6;
     // Launches of more than one round of workgroups: whole rounds are what costs.  256-row tiles run one per CU (256 slots), the
-    // 128-row four-wave tiles two per CU (512 slots) at 0.934 of the rate (1004 vs 1075 TFLOP/s).  CausVid 720p: 10800
+    // 128-row four-wave tiles two per CU (512 slots) at 0.953 of the rate (1061 vs 1113 TFLOP/s).  CausVid 720p: 10800
     // rows x 12 heads = 516 tiles = 2.02 rounds -> THREE rounds of 256-row tiles, but 1020 / 512 = 1.99 -> two of 128-row tiles
     // (measured 778 -> see profiles/r2_*); the 480p block (228 tiles, one round either way) stays on the 256-row schedule.
     if (heads > 0 && t256 * heads > 256) {
       const float c5 = (float)((t256 * heads + 255) / 256);
-      const float c6 = (float)((t128 * heads + 511) / 512) / 0.876f;       // 0.934 of schedule 5's rate, which schedule 7 beats by 6.6 %
+      const float c6 = (float)((t128 * heads + 511) / 512) / 0.953f;       // 1061 vs 1113 TFLOP/s at L = 32760 (both with constant LDS slots)
       if (c6 < 0.95f * c5) return 6;
     }
   }

@@ -166,10 +166,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   // two-times-unrolled loop re-derives its addresses every tile (56 of the 177 non-MFMA VALU instructions of a tile; the loop is
   // bound by VALU issue).  V ring first (imm offsets reach 64 KiB), K ring behind it; K is requested three tiles ahead,
   // V two (it is consumed two iterations later), which is what lets four V slots do.
-  constexpr bool SWP = FR >= 2, DUAL = FR == 3, U4 = FR == 5;
+  // FR = 6: the same treatment for the two-per-CU form (rings of 2 K + 3 V tiles: unrolled six times).
+  constexpr bool SWP = FR >= 2, DUAL = FR == 3 || FR == 6, U4 = FR == 5, U6 = FR == 6, CS = U4 || U6;   // CS: constant LDS slots
   constexpr int PD = (FR == 2 || U4) ? 3 : pp::PD, RK = DUAL ? 2 : (U4 ? 4 : (FR == 2 ? 3 : pp::RK)),
                 RV = DUAL ? 3 : (U4 ? 4 : (FR == 2 ? 5 : pp::RV));
-  constexpr int K_OFF = U4 ? 65536 : 0, V_OFF = U4 ? 0 : RK * 16384;
+  constexpr int K_OFF = CS ? RV * 16384 : 0, V_OFF = CS ? 0 : RK * 16384;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = (NG == 2 && PP_GROUP) ? (wave & 1) : (wave >> 2);
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     // iteration t: sC = S(t) -> pC = P(t) (softmax), pP = P(t-1) -> O (PV), sN = S(t+1) (QK)
     // U4: lane terms of the fragment reads, once per kernel (K_OFF folded into the K terms; V_OFF = 0)
     int kterm[8], vterm[4];
-    if (U4) {
+    if (CS) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         kterm[ks] = K_OFF + l31 * 256 + (((2 * ks + hi) ^ kswz) << 4);
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       }
     }
     auto body = [&](int t, f32x16(&sC)[2], f32x16(&sN)[2], bf16x8(&pC)[2][2], bf16x8(&pP)[2][2], auto kslot_c, auto vslot_c) -> float {
-      constexpr int KSLOT = decltype(kslot_c)::value, VSLOT = decltype(vslot_c)::value;     // U4 only (-1 otherwise)
+      constexpr int KSLOT = decltype(kslot_c)::value, VSLOT = decltype(vslot_c)::value;     // constant-slot forms only (-1 otherwise)
       const unsigned char* kb = smem + K_OFF + ((t + 1) % RK) * 16384;
       const unsigned char* vb = smem + V_OFF + ((t > 0 ? t - 1 : 0) % RV) * 16384;
 #if PP_SWP_RECOMPUTE
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       bf16x8 fs[RDs][2];
       auto load = [&](int j) {
         bf16x8(&f)[2] = fs[j % RDs];
-        if (U4 && j < 8) {
+        if (CS && j < 8) {
           const int bb = j >> 2, sl = (j >> 1) & 1, dh = j & 1;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
             const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 2048));
             f[e] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
           }
-        } else if (U4) {
+        } else if (CS) {
           const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
 #pragma unroll
           for (int e = 0; e < 2; ++e)
@@ -755,6 +756,10 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         for (int i = 0; i < 6; ++i) tp[i] = tr[i];
       }
     };
+    if (U6) {                                          // V slot 2 is read (times P(-1) = 0) by the PV of iteration 0: clear it (256 threads x 64 B)
+#pragma unroll
+      for (int z = 0; z < 4; ++z) *reinterpret_cast<u32x4*>(smem + V_OFF + 2 * 16384 + tid * 64 + z * 16) = u32x4{0, 0, 0, 0};
+    }
     if (DUAL) {                                        // K(0), V(0), K(1); K(0) and V(0) must land before QK(0) / the P = 0 pass over V(0)
       issue_w(0, wave, 3);
       issue_w(0, wave + 4, 3);
@@ -810,6 +815,15 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         if (t + 1 < NT) iteration(t + 1, s2, s, pb2, pb, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
         if (t + 2 < NT) iteration(t + 2, s, s2, pb, pb2, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
         if (t + 3 < NT) iteration(t + 3, s2, s, pb2, pb, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+      }
+    } else if (U6) {                                   // K slot (t + 1) % 2, V slot (t + 2) % 3
+      for (int t = 0; t < NT; t += 6) {
+        iteration(t, s, s2, pb, pb2, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        if (t + 1 < NT) iteration(t + 1, s2, s, pb2, pb, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if (t + 2 < NT) iteration(t + 2, s, s2, pb, pb2, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        if (t + 3 < NT) iteration(t + 3, s2, s, pb2, pb, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        if (t + 4 < NT) iteration(t + 4, s, s2, pb, pb2, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if (t + 5 < NT) iteration(t + 5, s2, s, pb2, pb, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
       }
     } else {
       for (int t = 0; t < NT; t += 2) {
@@ -1071,23 +1085,26 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots)
   return best;
 }
 
+#ifndef PP_DUAL_FR
+#define PP_DUAL_FR 6     // 6: six-times unrolled over constant LDS slots; 3: the two-times unrolled form it replaced
+#endif
 static void launch_pp_dual(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   constexpr int LDS_DUAL = 5 * 16384;                   // 80 KiB: two workgroups per CU
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
     attr_set = true;
   }
   const dim3 block(256);
   if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 1, 3>), grid, block, LDS_DUAL, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 1, 3>), grid, block, LDS_DUAL, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
   } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, 3>), grid, block, LDS_DUAL, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 1, 3>), grid, block, LDS_DUAL, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
   }
 }
 
