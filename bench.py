@@ -519,6 +519,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and getattr(model.cp, "peer", None) is not None:
+        # one validation clip on the peer-store path before anything is timed: a wait that times out raises on every rank together
+        # (PeerStoreExchange.check), and all ranks then continue on the all-gather
+        try:
+            clip()
+            torch.cuda.synchronize()
+        except RuntimeError as exc:
+            print(f"[bench rank {rank}] peer-store exchange failed in the validation clip, using the all-gather: {exc}", file=sys.stderr)
+            model.cp.peer, model.cp.kv_first = None, True
+            exchange_used = "allgather"
+            torch.cuda.synchronize()
+            dist.barrier()
     for _ in range(a.warmup):
         clip()
     timer = ops.KernelTimer(names=("attn_self",))

@@ -284,10 +284,16 @@ class PeerStoreExchange:
         return all(votes)
 
     def check(self) -> None:
-        """Raise if a wait gave up (synchronises: call at a point that synchronises anyway)."""
+        """Raise — on EVERY rank together — if a wait gave up on any rank (one small MAX all-reduce of the status words; synchronises:
+        call at a point that synchronises anyway).  A rank that timed out alone and raised alone would leave its peers in the next
+        collective."""
+        if not self.emulated and dist.is_initialized():
+            dist.all_reduce(self.status, op=dist.ReduceOp.MAX, group=self.group)
         st = int(self.status.item())
         if st:
-            raise RuntimeError(f"peer-store exchange: rank {self.rank} timed out after {self.timeout_ms} ms waiting for rank {st - 1}")
+            self.status.zero_()
+            raise RuntimeError(f"peer-store exchange: a wait timed out after {self.timeout_ms} ms (rank {self.rank} sees status {st}: "
+                               f"waiting for rank {st - 1} somewhere in the group)")
 
     def close(self) -> None:
         from . import hip_ops as ops
