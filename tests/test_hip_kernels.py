@@ -473,10 +473,14 @@ def test_gemm_split_k_tiles_refuse_indivisible_k(ops):
         assert_bf16_parity(ops.linear(gpu(x), gpu(w), gpu(b)), torch.nn.functional.linear(x, w, b), what=f"auto {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
 def test_attention_both_kernels(ops, variant):
     ops.set_option("attn_variant", variant)
     try:
+        if variant in (6, 7):                                  # loops unrolled 6 / 4 times over constant LDS slots: every remainder
+            for tiles in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13):
+                _attn_case(ops, 260, 2, 64 * tiles - 9, cap=64 * tiles)
+                _attn_case(ops, 140, 3, 64 * tiles, cap=64 * tiles + 64, page=64)
         _attn_case(ops, 300, 12, 2048, cap=2100)
         _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
         _attn_case(ops, 1000, 2, 700, cap=777)                 # several query tiles, ragged last key tile
