@@ -48,6 +48,9 @@
 #ifndef PP_SWP_RING
 #define PP_SWP_RING 4
 #endif
+#ifndef PP_SWP_BALANCE
+#define PP_SWP_BALANCE 1
+#endif
 #ifndef PP_SWP_YIELD
 #define PP_SWP_YIELD 0
 #endif
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           sN[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], sN[bb], 0, 0, 0);
         }
       };
-      float p0 = 0.f, p1 = 0.f;
+      float p0 = 0.f, p1 = 0.f, e1 = 0.f;
       float acc4[4] = {0.f, 0.f, 0.f, 0.f};
       pp_f32x2 accp[2] = {pp_f32x2{0.f, 0.f}, pp_f32x2{0.f, 0.f}};
       u32x4 pw[2][2];                                  // P(t) as packed bf16 pairs: pw[b][half][k] = keys 2k, 2k+1 of that half
@@ -651,12 +654,20 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           const pp_f32x2 e2 = pp_f32x2{sC[b][2 * i], sC[b][2 * i + 1]} * c2v - v_mcv;
           p0 = __builtin_amdgcn_exp2f(e2[0]);
           p1 = __builtin_amdgcn_exp2f(e2[1]);
+        } else if (PP_SWP_BALANCE) {
+          // the VALU work of a pair is split evenly around the second MFMA: two scale-FMAs + one exponential (24 cycles) here, the
+          // other exponential + two adds + the pack (28 cycles) behind it — each piece fits under the 32 matrix-pipe cycles of the
+          // OTHER wave's MFMA, where 40 + 12 left a bubble every pair
+          p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i], c2, -mc));
+          e1 = __builtin_fmaf(sC[b][2 * i + 1], c2, -mc);
+          asm volatile("" : "+v"(e1));
         } else {
           p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i], c2, -mc));
           p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sC[b][2 * i + 1], c2, -mc));
         }
         PP_SB();
         if (!(PP_ABLATE & 8)) mma1(j, 1);
+        if (PP_SWP_BALANCE && !PP_SWP_PACKED && !(PP_ABLATE & 16)) p1 = __builtin_amdgcn_exp2f(e1);
         if (!(PP_ABLATE & 64)) {                       // four independent row-sum chains, pinned behind this MFMA
           if (PP_SWP_PACKED) {
             pp_f32x2& a2 = (j & 1) ? accp[1] : accp[0];
