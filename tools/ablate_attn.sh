@@ -5,10 +5,10 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/tools/bin/abl
 if [ "$1" = "build" ]; then
+  make -C $R/inferix_amd/csrc -j8 >/dev/null      # the other objects are linked as built
   for a in ${ABL_LIST:-0 1 2 4 8 3 6 10 12 14 15}; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ${ABL_FLAGS:-} -DPP_ABLATE=$a $R/inferix_amd/csrc/ifx_core.hip $R/inferix_amd/csrc/ifx_norm.hip \
-      $R/inferix_amd/csrc/ifx_gemm.hip $R/inferix_amd/csrc/ifx_gemm_glds.hip $R/inferix_amd/csrc/ifx_attn.hip $R/inferix_amd/csrc/ifx_attn_pp.hip \
-      $R/inferix_amd/csrc/ifx_quant.hip $R/inferix_amd/csrc/ifx_conv.hip $R/inferix_amd/csrc/ifx_t5.hip -o $R/tools/bin/abl/lib${ABL_TAG:-}_$a.so &
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC ${ABL_FLAGS:-} -DPP_ABLATE=$a -c $R/inferix_amd/csrc/ifx_attn_pp.hip -o $R/tools/bin/abl/pp${ABL_TAG:-}_$a.o &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $R/inferix_amd/csrc/build/*.o | grep -v ifx_attn_pp.o) $R/tools/bin/abl/pp${ABL_TAG:-}_$a.o -o $R/tools/bin/abl/lib${ABL_TAG:-}_$a.so ) &
   done; wait; ls $R/tools/bin/abl
 else
   for a in ${ABL_LIST:-0 1 2 4 8 3 6 10 12 14 15}; do
