@@ -24,7 +24,7 @@ for _ in range(2):
     out, lse = ops.attention(q, ops.KvCacheView(k, v), L, return_lse=True, splits=1)
 torch.cuda.synchronize()
 FR = NG == 4
-SWP = NG == 5
+SWP = NG in (5, 7)
 if FR or SWP:
     NG = 2
 W = 4 * NG
