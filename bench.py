@@ -19,6 +19,7 @@ MFMA-bound) and `cpu_baseline` (CPU oracle timed on the host cores, N=1 only).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -89,6 +90,51 @@ def cpu_baseline(layers: int = 30):
                       "generator forwards of the 30-layer Wan2.1-1.3B causal DiT over one 3-frame block (N = L_kv = 4680), "
                       f"NO_DECODE, bf16 CPU oracle (O.inference); {dt:.1f} s wall",
             "seconds": round(dt, 2), "ms_per_generator_forward": round(dt / 2 * 1e3, 1), "host_cpus": os.cpu_count()}
+
+
+class ClockSampler:
+    """Shader clock and socket power of GPU `index` while the timed region runs: a side thread polls `rocm-smi --json` (sysfs reads, no GPU
+    work) every 0.2 s.  Reported beside the roofline because every MFMA-heavy launch of this path sits at the socket power limit and the
+    clock is what gives (profiles/r2_clocks_power.md): `peak` is quoted at 2.4 GHz, `frac_at_clock` scales it to the clock that was sustained.
+    Never fatal: any failure yields nulls."""
+
+    def __init__(self, index: int = 0):
+        import threading
+        self.index, self.samples, self._stop = index, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        smi = "/opt/rocm/bin/rocm-smi"
+        while not self._stop.is_set():
+            try:
+                r = subprocess.run([smi, "-d", str(self.index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=3)
+                card = next(iter(json.loads(r.stdout).values()))
+                clk = next((v for k, v in card.items() if k.startswith("sclk")), None)
+                pw = next((v for k, v in card.items() if "ower" in k and "(W)" in k), None)
+                m = re.search(r"([0-9.]+)", str(clk))
+                self.samples.append((float(m.group(1)) if m else None, float(pw) if pw is not None else None))
+            except Exception:  # noqa: BLE001
+                pass
+            self._stop.wait(0.2)
+
+    def __enter__(self):
+        if os.path.exists("/opt/rocm/bin/rocm-smi"):
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th.is_alive():
+            self._th.join(timeout=5)
+
+    def summary(self):
+        import statistics
+        clk = [c for c, _ in self.samples[1:] if c]          # the first sample may predate the first launch
+        pw = [p for _, p in self.samples[1:] if p]
+        return {"sclk_mhz_median": statistics.median(clk) if clk else None, "socket_power_w_median": statistics.median(pw) if pw else None,
+                "samples": len(clk)}
 
 
 def pmc_traffic(shards):
@@ -536,11 +582,12 @@ def main():
     timer = ops.KernelTimer(names=("attn_self",))
     ops.set_kernel_timer(timer)
     sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = clip()
-    sync()
-    dt = time.perf_counter() - t0
+    with ClockSampler(local_rank if world > 1 else 0) if rank == 0 else contextlib.nullcontext() as clocks:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = clip()
+        sync()
+        dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -622,6 +669,11 @@ def main():
         if a.emulate_sp > 1:
             res["config"]["INVALID"] = f"one rank of sp{a.emulate_sp} emulated on one GPU, collective replaced by a copy"
         res["roofline"].update(pmc_traffic(world if world > 1 else max(a.emulate_sp, 1)))
+        ck = clocks.summary()
+        res["roofline"]["clocks"] = ck
+        if ck["sclk_mhz_median"]:
+            # the dense bf16 peak is 256 CUs x 4 SIMDs x 1024 FLOP/clk at 2.4 GHz; the same pipes at the clock the timed region sustained
+            res["roofline"]["frac_at_clock"] = round(attn_tflops / (PEAK_BF16_TFLOPS * ck["sclk_mhz_median"] / 2400.0), 4)
         if breakdown:
             res["kernel_breakdown"] = breakdown
         if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
