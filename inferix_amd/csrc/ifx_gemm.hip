@@ -210,7 +210,12 @@ static int pick_tile(int M, int N, int K) {
   struct Cand { int tile, bm, bn, slots; float base; };
   // 128x128 runs double-buffered with TWO workgroups per CU (64 KiB of LDS each): the co-resident workgroup hides the operand
   // latency better than the deep rings of the big tiles do — QKV 92 -> 83 us, O 38 -> 35, FFN down 150 -> 137 (tools/bench_gemm_tiles.py)
-  static const Cand cands[] = {{3, 256, 256, 256, 1.00f}, {0, 256, 128, 256, 0.85f}, {1, 128, 128, 512, 0.95f},
+  // 256x192 (tile 19, round 2): 7 % more outputs per round-microsecond than the two-per-CU 128x128 tile, 8 % fewer than 256x256; it wins
+  // where 192-wide columns quantise better — the QKV projection, N = 4608 = 24 x 192: 456 tiles = 1.8 rounds against 1.3 of 256x256
+  // (interleaved A/B, tools/scratch/ab_gemm_tiles.py: 4680x4608x1536 82.4 -> 75.3 us, 2340x4608x1536 47.1 -> 42.1, 2340x8960x1536
+  // 83.7 -> 79.3; not picked, and slower, at 4680x8960 147 vs 142, 9360x4608 154 vs 144, 10800x4608 193 vs 181).  Same K order as the
+  // other single-pass tiles: bit-identical outputs.
+  static const Cand cands[] = {{3, 256, 256, 256, 1.00f}, {19, 256, 192, 256, 0.99f}, {0, 256, 128, 256, 0.85f}, {1, 128, 128, 512, 0.95f},
                                {4, 128, 64, 512, 0.68f},  {2, 64, 64, 512, 0.50f}};
   // Few output tiles (one rank's M = 4680 / P rows of a sequence-parallel shard): the parallelism has to come from K.  Tiles 10-12
   // split K between wave groups of ONE workgroup (no workspace, fixed summation order).  Measured, tools/bench_gemm_tiles.py 585 / 2340:
@@ -257,7 +262,8 @@ static int pick_tile(int M, int N, int K) {
 // kernel selection: 0 = auto (LDS-DMA kernels, tile by shape), 1 = force the register-staged 128x128 kernel,
 // 2 = force 256x128, 3 = force LDS-DMA 128x128, 4 = force LDS-DMA 64x64, 5 = force 256x256x32, 6 = force LDS-DMA 128x64,
 // 7 / 8 = the two-per-CU 256x128x32 and eight-wave 128x128x32 experiments (slower than 3, kept selectable),
-// 12 / 13 / 14 = the split-K-inside-the-workgroup tiles 10 / 11 / 12 (small launches), 15 = 128x64 three per CU, 16 / 17 = 64x128
+// 12 / 13 / 14 = the split-K-inside-the-workgroup tiles 10 / 11 / 12 (small launches), 15 = 128x64 three per CU, 16 / 17 = 64x128,
+// 18 / 19 = the four-wave 256x256 tiles, 20 = split-K over two workgroups (needs a workspace), 21 = 256x192
 }  // namespace ifx
 
 using namespace ifx;

@@ -822,6 +822,10 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   constexpr int RB = WN * 2, CR = RB / 16, RP = 64 / CR;   // row bytes, 16-B chunks per row, rows per instruction
+  // CR a power of two (WN = 32 / 64 / 128): XOR swizzle, all 64 lanes read.  Otherwise (WN = 96 of the 256 x 192 tile: 12 chunks) the
+  // chunk index is rotated by the row and lanes RP * CR .. 63 sit the read-out phase out.
+  constexpr bool P2 = (CR & (CR - 1)) == 0;
+  auto phys = [&](int chunk, int mrow) { return P2 ? (chunk ^ (mrow & (CR - 1))) : (chunk + mrow) % CR; };
   unsigned char* tw = smem + wave * (WM * RB);
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
         u16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        const int chunk = (nl >> 3) ^ (mrow & (CR - 1));
+        const int chunk = phys(nl >> 3, mrow);
         *reinterpret_cast<u16x4*>(tw + mrow * RB + chunk * 16 + (nl & 4) * 2) = o;
       }
   }
@@ -849,11 +853,12 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128) ? (NST <= 2 ? 3 : 2) : 
   {
     const int rr = lane / CR, cc = lane % CR;
 #pragma unroll
-    for (int p = 0; p < WM / RP; ++p) {
+    for (int p = 0; p < (WM + RP - 1) / RP; ++p) {
       const int mrow = p * RP + rr;
+      if (!P2 && (rr >= RP || mrow >= WM)) continue;
       const int m = m_base + wm * WM + mrow;
       const int n = n_base + wn * WN + cc * 8;
-      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * RB + ((cc ^ (mrow & (CR - 1))) << 4));
+      const u16x8 vv = *reinterpret_cast<const u16x8*>(tw + mrow * RB + (phys(cc, mrow) << 4));
       if (m >= M || n >= N) continue;
       u16x8 o;
       if (EPI == IFX_EPI_BIAS) {
@@ -1051,6 +1056,8 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   // tiles read (128 + 64) fragment rows per 8192 outputs from LDS = ~96 B/clk/CU of a 128 B/clk LDS next to 32 B/clk of DMA
   // writes; 128 x 128 wave tiles read a third less per FLOP
   if (tile == 16) return launch_small<256, 256, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
+  // 256 x 192: the QKV projection's 4608 columns are 24 x 192 -> 456 tiles = 1.8 rounds where 256 x 256 has 1.3 (two rounds, a third idle)
+  if (tile == 19) return launch_big<256, 192, 4, 2, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   if (tile == 17) return launch_gemm_w4(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, s, 1, nullptr);   // ifx_gemm_w4.hip
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }

@@ -396,6 +396,11 @@ _GEMM_CASES += [(v, M, N, K) for v in (18, 19) for M, N, K in [(585, 1536, 1536)
                                                                 (2000, 2312, 3072)]]
 
 
+# the 256x192 tile: 96-column wave tiles (a 12-chunk epilogue transpose); ragged M and N edges, N not a multiple of 192
+_GEMM_CASES += [(21, M, N, K) for M, N, K in [(585, 1536, 1536), (300, 640, 64), (77, 64, 192), (1170, 4608, 1536), (2000, 2312, 3072),
+                                              (4680, 4608, 1536)]]
+
+
 @pytest.mark.parametrize("variant,M,N,K", _GEMM_CASES)
 def test_gemm_every_tile_variant(ops, variant, M, N, K):
     """Each GEMM kernel (register-staged 128x128, LDS-DMA 256x128 / 128x128 / 64x64) on shard shapes with ragged
@@ -518,7 +523,7 @@ def test_kernels_are_run_to_run_deterministic(ops):
             assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=1)), f"attention variant {av}"
         ops.set_option("attn_variant", 0)
         assert stable(lambda: ops.attention(q, ops.KvCacheView(k, v), L, splits=4)), "split-KV attention"
-        for gv in (1, 2, 3, 4, 5, 6, 12, 13, 14):
+        for gv in (1, 2, 3, 4, 5, 6, 12, 13, 14, 21):
             ops.set_option("gemm_variant", gv)
             assert stable(lambda: ops.linear(x, w, b, epilogue=_hip.IFX_EPI_GELU_TANH), reps=15), f"gemm variant {gv}"
     finally:
