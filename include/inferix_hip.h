@@ -194,6 +194,11 @@ typedef struct {
   int32_t height, width; /* patch grid of one frame */
   int32_t hw_offset;     /* rank * hw_local */
   int32_t hw_local;      /* height*width / world_size */
+  float q_scale;         /* ifx_rmsnorm_rope_kv_append only: the rotated q is multiplied by this in fp32 before its single rounding
+                            to bf16 (0 = 1 = the reference's q).  With q_scale = softmax_scale * log2(e) and the attention entry
+                            points called with scale = ln 2 the attention is the same function of the unrounded q — q·k·scale —
+                            and the self-attention kernel takes its exponent fast path (scores are exp2 arguments; no scale-FMA
+                            per score).  K / V and the cache are untouched. */
 } ifx_rope_grid;
 
 int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t qkv_row_stride, ifx_bf16* q_out,

@@ -41,7 +41,7 @@ class RopeGrid(C.Structure):
     """ifx_rope_grid"""
     _fields_ = [("freqs", C.c_void_p), ("max_pos", C.c_int32), ("start_frame", C.c_int32),
                 ("height", C.c_int32), ("width", C.c_int32), ("hw_offset", C.c_int32),
-                ("hw_local", C.c_int32)]
+                ("hw_local", C.c_int32), ("q_scale", C.c_float)]
 
 
 class Conv3dDesc(C.Structure):

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   // bound by VALU issue).  V ring first (imm offsets reach 64 KiB), K ring behind it; K is requested three tiles ahead,
   // V two (it is consumed two iterations later), which is what lets four V slots do.
   // FR = 6: the same treatment for the two-per-CU form (rings of 2 K + 3 V tiles: unrolled six times).
-  constexpr bool SWP = FR >= 2, DUAL = FR == 3 || FR == 6, U4 = FR == 5, U6 = FR == 6, CS = U4 || U6;   // CS: constant LDS slots
+  constexpr bool SWP = FR >= 2, DUAL = FR == 3 || FR == 6, U4 = FR == 5 || FR == 7, U6 = FR == 6, CS = U4 || U6;   // CS: constant LDS slots
+  // PRE (FR = 7): the caller's scale * log2(e) is exactly 1 (q was scaled where it was produced): scores ARE exponents, and the softmax
+  // reference -m enters as the C operand of a score block's first MFMA, so exp2 is applied straight to the accumulator
+  constexpr bool PRE = FR == 7;
   constexpr int PD = (FR == 2 || U4) ? 3 : pp::PD, RK = DUAL ? 2 : (U4 ? 4 : (FR == 2 ? 3 : pp::RK)),
                 RV = DUAL ? 3 : (U4 ? 4 : (FR == 2 ? 5 : pp::RV));
   constexpr int K_OFF = CS ? RV * 16384 : 0, V_OFF = CS ? 0 : RK * 16384;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float c2 = A.scale_log2;
+  const float c2 = FR == 7 ? 1.0f : A.scale_log2;     // FR = 7 is only launched when the product is 1 to rounding
   const int kswz = l31 & 15;
   const int vi = lane & 15, vg1 = (lane >> 4) & 1;
   const int v_rowq = vi >> 2;
@@ -535,8 +538,8 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         for (int r = 0; r < 16; ++r)
           if (kidx + 32 * b + (r & 3) + 8 * (r >> 2) >= nkeys) sx[b][r] = -INFINITY;
     };
-    auto true_max = [&](f32x16(&sx)[2]) -> float {
-      float mx = pp_max3(__builtin_fmaxf(sx[0][0], sx[1][0]), m_run, m_run);
+    auto true_max = [&](f32x16(&sx)[2], float floor_v) -> float {
+      float mx = pp_max3(__builtin_fmaxf(sx[0][0], sx[1][0]), floor_v, floor_v);
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = pp_max3(mx, sx[0][r], sx[1][r]);
       return pp_half_max(mx);
@@ -558,6 +561,13 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     };
     // iteration t: sC = S(t) -> pC = P(t) (softmax), pP = P(t-1) -> O (PV), sN = S(t+1) (QK)
     // U4: lane terms of the fragment reads, once per kernel (K_OFF folded into the K terms; V_OFF = 0)
+    f32x16 negm;                                       // PRE: -m in every element (MFMA C operand)
+    auto set_negm = [&](float m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m;
+      asm volatile("" : "+v"(negm));
+    };
+    if (PRE) set_negm(0.f);
     int kterm[8], vterm[4];
     if (CS) {
 #pragma unroll
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       const int hi = ln >> 5, l31 = ln & 31, kswz = ln & 15, v_rowq = (ln >> 2) & 3;
       const int v_in = (((ln >> 4) & 1) << 5) | ((ln & 3) << 3);
 #endif
-      constexpr int RDs = PP_SWP_RING, LAs = RDs - 1;  // fragment ring of this schedule (registers are tight)
+      constexpr int RDs = PRE ? 2 : PP_SWP_RING, LAs = RDs - 1;  // fragment ring of this schedule (registers are tight; PRE spends 16 on negm)
       bf16x8 fs[RDs][2];
       auto load = [&](int j) {
         bf16x8(&f)[2] = fs[j % RDs];
@@ -624,11 +634,15 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           o[2 * dh + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], pP[bb][sl], o[2 * dh + e], 0, 0, 0);
         } else {
           const int q = j - 8, bb = q >> 2, ks0 = 2 * (q & 3);
-          if ((q & 3) == 0 && e == 0) {
+          if (PRE && (q & 3) == 0 && e == 0) {
+            sN[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], negm, 0, 0, 0);     // S - m
+          } else {
+            if ((q & 3) == 0 && e == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sN[bb][r] = 0.f;
+              for (int r = 0; r < 16; ++r) sN[bb][r] = 0.f;
+            }
+            sN[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], sN[bb], 0, 0, 0);
           }
-          sN[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[e], qf[ks0 + e], sN[bb], 0, 0, 0);
         }
       };
       float p0 = 0.f, p1 = 0.f, e1 = 0.f;
@@ -654,6 +668,9 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           const pp_f32x2 e2 = pp_f32x2{sC[b][2 * i], sC[b][2 * i + 1]} * c2v - v_mcv;
           p0 = __builtin_amdgcn_exp2f(e2[0]);
           p1 = __builtin_amdgcn_exp2f(e2[1]);
+        } else if (PRE) {                              // the score is the exponent
+          p0 = __builtin_amdgcn_exp2f(sC[b][2 * i]);
+          e1 = sC[b][2 * i + 1];
         } else if (PP_SWP_BALANCE) {
           // the VALU work of a pair is split evenly around the second MFMA: two scale-FMAs + one exponential (24 cycles) here, the
           // other exponential + two adds + the pack (28 cycles) behind it — each piece fits under the 32 matrix-pipe cycles of the
@@ -667,7 +684,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         }
         PP_SB();
         if (!(PP_ABLATE & 8)) mma1(j, 1);
-        if (PP_SWP_BALANCE && !PP_SWP_PACKED && !(PP_ABLATE & 16)) p1 = __builtin_amdgcn_exp2f(e1);
+        if ((PRE || PP_SWP_BALANCE) && !PP_SWP_PACKED && !(PP_ABLATE & 16)) p1 = __builtin_amdgcn_exp2f(e1);
         if (!(PP_ABLATE & 64)) {                       // four independent row-sum chains, pinned behind this MFMA
           if (PP_SWP_PACKED) {
             pp_f32x2& a2 = (j & 1) ? accp[1] : accp[0];
@@ -751,8 +768,22 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         asm volatile("" ::"v"(tile_sum), "v"(sN[1][15]), "v"(o[3][15]));
         tr[4] = __builtin_readcyclecounter();
       }
-      if (__any(!(tile_sum < kLazyLimit))) {           // rare: this tile outgrew the reference maximum
-        const float m_new = true_max(sC);
+      if (PRE) {
+        if (__any(!(tile_sum < kLazyLimit))) {         // rare: sC holds S(t) - m_run, sN already holds S(t+1) - m_run
+          const float d = true_max(sC, 0.f);           // >= 0: how far this tile's maximum lies above the reference
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          tile_sum = exp_plain(sC, pC, d);
+          m_run += d;
+          l_run *= alpha;
+          rescale_o(alpha);
+          set_negm(m_run);
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sN[b][r] -= d;
+        }
+      } else if (__any(!(tile_sum < kLazyLimit))) {    // rare: this tile outgrew the reference maximum
+        const float m_new = true_max(sC, m_run);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
         m_run = m_new;
         tile_sum = exp_plain(sC, pC, m_new * c2);
@@ -818,7 +849,14 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     __builtin_amdgcn_s_barrier();
     qk_plain(0, s);
     if (NT == 1 && (nkeys & (KT - 1))) mask_ragged(0, s);
-    m_run = true_max(s);
+    m_run = true_max(s, m_run);
+    if (PRE) {                                         // the loop's scores come out of the MFMA as S - m: bring S(0) to the same form
+      set_negm(m_run);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[b][r] -= m_run;
+    }
     using ic = std::integral_constant<int, -1>;
     if (U4) {                                          // iteration t reads K slot (t + 1) % 4 and V slot (t - 1) % 4
       for (int t = 0; t < NT; t += 4) {
@@ -1236,6 +1274,8 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   }
   if (fr_mode == 3) launch_pp_dual(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 2) launch_pp_fr<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else if (fr_mode == 5 && fabsf(a.scale_log2 - 1.0f) <= 2.5e-7f)   // q carries scale * log2(e) already (ifx_rope_grid.q_scale): scores are exponents
+    launch_pp_fr<7>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 5) launch_pp_fr<5>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 1) launch_pp_fr<1>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (groups == 3) launch_pp_ng<3>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
 struct RopeArgs {
   const double* freqs;
   int max_pos, start_frame, height, width, hw_offset, hw_local;
+  float q_scale = 1.0f;   // applied to the rotated q in fp32 before its ONE rounding to bf16 (ifx_rope_grid.q_scale)
 };
 
 // rotate the 4 adjacent-channel pairs held in t[0..7]; pair index jp0..jp0+3 within the head
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
       else if (has_rope) rope4(t, (col % head_dim) >> 1, ra, half, n_t, n_h, pos_t, pos_h, pos_w);
       u16x8 o;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i]);
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(t[i] * ra.q_scale);
       *reinterpret_cast<u16x8*>(q_out + (size_t)r * dim + col) = o;
     }
   }
@@ -486,6 +487,8 @@ extern "C" int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t ld, ifx_b
                 "ifx_rmsnorm_rope_kv_append: positions exceed rope table (%d)", rope->max_pos);
     ra = RopeArgs{rope->freqs, rope->max_pos, rope->start_frame, rope->height,
                   rope->width, rope->hw_offset, rope->hw_local};
+    IFX_REQUIRE(rope->q_scale >= 0.f && rope->q_scale == rope->q_scale, "ifx_rmsnorm_rope_kv_append: q_scale must be >= 0 (0 = 1)");
+    ra.q_scale = rope->q_scale > 0.f ? rope->q_scale : 1.0f;
   }
   if (rows == 0) return IFX_OK;
   return dispatch_nch(dim, [&](auto nch) {

@@ -163,11 +163,20 @@ class RopeGridSpec:
     width: int
     hw_offset: int = 0
     hw_local: Optional[int] = None
+    q_scale: float = 0.0         # rmsnorm_rope_kv_append: q is multiplied by this before its rounding to bf16 (0 = 1); see ATTN_Q_PRESCALE
 
     def struct(self) -> _hip.RopeGrid:
         hl = self.hw_local if self.hw_local is not None else self.height * self.width
         return _hip.RopeGrid(_dev(self.freqs, "rope.freqs", torch.float64), self.freqs.shape[0],
-                             int(self.start_frame), int(self.height), int(self.width), int(self.hw_offset), int(hl))
+                             int(self.start_frame), int(self.height), int(self.width), int(self.hw_offset), int(hl),
+                             float(self.q_scale))
+
+
+def attn_q_prescale(head_dim: int) -> Tuple[float, float]:
+    """(q_scale, attention scale) of the exponent fast path: q carries softmax_scale * log2(e) from the kernel that produces it
+    (`RopeGridSpec.q_scale`) and the attention is called with scale = ln 2 — softmax(q k^T / sqrt(d)) as before, with ONE rounding
+    of q to bf16 either way, and no scale-FMA per score in the attention loop (ifx_attn_pp.hip, FR = 7)."""
+    return (head_dim ** -0.5) * 1.4426950408889634, 0.6931471805599453
 
 
 def layernorm(x: torch.Tensor, eps: float, *, gamma=None, beta=None, mod=None, shift_slot=0, scale_slot=1,

@@ -134,6 +134,7 @@ class HipCausalWanModel(torch.nn.Module):
         self._cross_dedup: Dict[str, Tuple[int, int]] = {}
         self._roll_scratch: Optional[torch.Tensor] = None
         self.cp = None                                # set by inferix_amd.sequence_parallel when world_size > 1
+        self.q_prescale = self.head_dim == 128        # exponent fast path of the self-attention kernel (hip_ops.attn_q_prescale)
 
     # ------------------------------------------------------------------ weights
     def parameters(self, recurse: bool = True):       # `next(generator.parameters())` is used by the pipeline
@@ -350,7 +351,7 @@ class HipCausalWanModel(torch.nn.Module):
                 view = self._kv_view(kv_cache_manager, req, name)
             ops.rmsnorm_rope_kv_append(qkv[b * N:(b + 1) * N], w["nq"], w["nk"], self.eps, rope, view,
                                        step.local_start, d, q_out=qb[b * N:(b + 1) * N])
-            ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end,
+            ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end, scale=st.get("attn_scale", 0.0),
                           out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_self")
         if explicit is None:
             self._meta_set(meta, "global_end_index", step.global_end)
@@ -460,11 +461,14 @@ class HipCausalWanModel(torch.nn.Module):
         # ---- scratch ---------------------------------------------------------------------
         h = self._buf("h", B * N, d)
         start_frame = current_start // fs
-        rope = ops.RopeGridSpec(self.freqs, start_frame, grid[1], grid[2], cp_rank * hw_local, hw_local)
+        # single-GPU path: q leaves the norm / RoPE kernel already multiplied by scale * log2(e) (one rounding to bf16 either way) and the
+        # attention is called with scale = ln 2 — the same softmax(q k^T / sqrt(d)), without a scale-FMA per score in the attention loop
+        q_scale, attn_scale = ops.attn_q_prescale(self.head_dim) if (self.q_prescale and self.cp is None) else (0.0, 0.0)
+        rope = ops.RopeGridSpec(self.freqs, start_frame, grid[1], grid[2], cp_rank * hw_local, hw_local, q_scale)
         sink_tokens = self.sink_size * fs
 
         st = dict(B=B, N=N, F_=F_, fs=fs, rows_per_group=rows_per_group, rope=rope, sink_tokens=sink_tokens,
-                  current_start=current_start, ctx=ctx, explicit_slots=explicit)
+                  current_start=current_start, ctx=ctx, explicit_slots=explicit, attn_scale=attn_scale)
         for l in range(L):
             self._run_block(l, xact, E[l], st, kv_cache_meta[l], crossattn_cache_meta[l], kv_cache_manager,
                             kv_cache_requests)

@@ -122,10 +122,16 @@ def test_rope_golden(ops):
             assert_bf16_parity(qo.view(72, 2, 128), ref[0], floor=1.0, what="rope golden path")
 
 
-def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None, splits=None):
+def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None, splits=None, prescaled=False):
     g = torch.Generator().manual_seed(seed + rows + kv_len)
     hd = 128
     q = rnd(g, rows, heads, hd)
+    q_call, scale = q, 0.0
+    if prescaled:
+        # the exponent fast path: q carries softmax_scale * log2(e) (rounded to bf16 ONCE, as the norm / RoPE kernel does with
+        # ifx_rope_grid.q_scale) and the call says scale = ln 2; the fp64 reference below is evaluated on exactly that q
+        q_scale, scale = ops.attn_q_prescale(hd)
+        q_call = (q.float() * q_scale).to(BF)
     k = rnd(g, kv_len, heads, hd)
     v = rnd(g, kv_len, heads, hd)
     cap = cap or kv_len
@@ -144,9 +150,10 @@ def _attn_case(ops, rows, heads, kv_len, cap=None, seed=0, page=None, splits=Non
         slot = perm[t // ps] * ps + t % ps
         kc[slot], vc[slot] = k, v
         view = ops.KvCacheView(gpu(kc), gpu(vc), gpu(perm.to(torch.int32)), ps)
-    out, lse = ops.attention(gpu(q), view, kv_len, return_lse=True, splits=splits)
+    out, lse = ops.attention(gpu(q_call), view, kv_len, scale=scale, return_lse=True, splits=splits)
     torch.cuda.synchronize()
-    ref64, lse64 = O.attention_with_lse(q[None], k[None], v[None])
+    q64 = q_call.double() * (scale * math.sqrt(hd)) if prescaled else q
+    ref64, lse64 = O.attention_with_lse(q64[None], k[None], v[None])
     ref_bf = O.attention(q[None], k[None], v[None])            # the reference's CPU path (SDPA bf16)
     err_gpu = (out.cpu().double() - ref64[0]).abs().max().item()
     err_ref = (ref_bf[0].double() - ref64[0]).abs().max().item()
@@ -496,6 +503,63 @@ def test_attention_both_kernels(ops, variant):
         _attn_case(ops, 500, 2, 1111, cap=1200, splits=3)
     finally:
         ops.set_option("attn_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [0, 7])
+def test_attention_prescaled_q_exponent_fast_path(ops, variant):
+    """scale * log2(e) == 1: `attn_fwd_pp_kernel<.., 7>` applies exp2 straight to the MFMA accumulators (the reference maximum enters as the
+    C operand).  Every remainder of the four-times unrolled loop, ragged / paged / split launches, the kernels without the fast path
+    (short prefixes, small launches: same call, generic arithmetic), and the redo path of the lazy maximum."""
+    ops.set_option("attn_variant", variant)
+    try:
+        for tiles in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13):
+            _attn_case(ops, 260, 2, 64 * tiles - 9, cap=64 * tiles, prescaled=True)
+            _attn_case(ops, 140, 3, 64 * tiles, cap=64 * tiles + 64, page=64, prescaled=True)
+        _attn_case(ops, 300, 12, 2048, cap=2100, prescaled=True)
+        _attn_case(ops, 130, 12, 1000, cap=1560, page=120, prescaled=True)
+        _attn_case(ops, 1000, 2, 700, cap=777, prescaled=True)
+        _attn_case(ops, 70, 2, 40, cap=64, prescaled=True)
+        _attn_case(ops, 500, 2, 1111, cap=1200, splits=3, prescaled=True)
+        _attn_case(ops, 1200, 12, 4680, prescaled=True)
+        # one key dominates late in the sequence: the tile outgrows the reference maximum (redo + rescale + the next tile's scores corrected)
+        g = torch.Generator().manual_seed(3)
+        rows, heads, kv_len, hd = 300, 2, 900, 128
+        q, k, v = rnd(g, rows, heads, hd), rnd(g, kv_len, heads, hd), rnd(g, kv_len, heads, hd)
+        k[500] = (q[5] * 4).to(BF)
+        k[10] = (q[40] * 6).to(BF)
+        k[700] = (q[290] * 5).to(BF)
+        q_scale, scale = ops.attn_q_prescale(hd)
+        qs = (q.float() * q_scale).to(BF)
+        out = ops.attention(gpu(qs), ops.KvCacheView(gpu(k), gpu(v)), kv_len, scale=scale, splits=1)
+        ref64, _ = O.attention_with_lse((qs.double() * (scale * math.sqrt(hd)))[None], k[None], v[None])
+        assert (out.cpu().double() - ref64[0]).abs().max().item() < 3e-2
+        assert rel_l2(out.cpu(), ref64[0]) < 5e-3
+    finally:
+        ops.set_option("attn_variant", 0)
+
+
+def test_rope_q_scale_is_one_rounding(ops):
+    """ifx_rope_grid.q_scale: q_out == bf16(q_fp32 * q_scale) — checked against the unscaled kernel output, whose bf16 values bracket
+    the fp32 q: |q_scaled - bf16(q_out * q_scale)| stays within one bf16 ulp, K and V written to the cache do not change."""
+    from inferix_amd.wan import components as C
+    g = torch.Generator().manual_seed(11)
+    rows, H, hd = 3 * 24, 2, 128
+    d = H * hd
+    qkv = rnd(g, rows, 3 * d)
+    wq, wk = rnd(g, d, scale=0.3) + 1.0, rnd(g, d, scale=0.3) + 1.0
+    freqs = C.rope_table(hd).cuda()
+    q_scale, _ = ops.attn_q_prescale(hd)
+    outs = []
+    for qs in (0.0, q_scale):
+        kc, vc = torch.zeros(rows, H, hd, dtype=BF, device="cuda"), torch.zeros(rows, H, hd, dtype=BF, device="cuda")
+        rope = ops.RopeGridSpec(freqs, 2, 4, 6, q_scale=qs)
+        qo = ops.rmsnorm_rope_kv_append(gpu(qkv), gpu(wq), gpu(wk), 1e-6, rope, ops.KvCacheView(kc, vc), 0, d)
+        outs.append((qo.cpu(), kc.cpu(), vc.cpu()))
+    (q0, k0, v0), (q1, k1, v1) = outs
+    assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    want = q0.float() * q_scale
+    ulp = torch.maximum(want.abs(), torch.tensor(1e-30)) * 2.0 ** -7      # one bf16 ulp of the value's binade, generously
+    assert ((q1.float() - want).abs() <= ulp).all()
 
 
 def test_kernels_are_run_to_run_deterministic(ops):

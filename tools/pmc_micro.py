@@ -18,9 +18,11 @@ g = torch.Generator(device=dev).manual_seed(0)
 N, H, D, d, f = 4680, 12, 128, 1536, 8960
 rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
 if "attn" in which:
-    q, k, v = rnd(N, H, D), rnd(L, H, D), rnd(L, H, D)
+    # as the model calls it: q carries scale * log2(e), the call says scale = ln 2 (the exponent fast path, `attn_fwd_pp_kernel<.., 2, 7>`)
+    q_scale, a_scale = ops.attn_q_prescale(D)
+    q, k, v = (torch.randn(N, H, D, generator=g, device=dev) * q_scale).to(torch.bfloat16), rnd(L, H, D), rnd(L, H, D)
     for _ in range(reps):
-        ops.attention(q, ops.KvCacheView(k, v), L)
+        ops.attention(q, ops.KvCacheView(k, v), L, scale=a_scale)
 if "gemm" in which:
     x = rnd(N, d)
     wqkv, wo, w1, w2 = rnd(3 * d, d), rnd(d, d), rnd(f, d), rnd(d, f)
