@@ -170,10 +170,10 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   // bound by VALU issue).  V ring first (imm offsets reach 64 KiB), K ring behind it; K is requested three tiles ahead,
   // V two (it is consumed two iterations later), which is what lets four V slots do.
   // FR = 6: the same treatment for the two-per-CU form (rings of 2 K + 3 V tiles: unrolled six times).
-  constexpr bool SWP = FR >= 2, DUAL = FR == 3 || FR == 6, U4 = FR == 5 || FR == 7, U6 = FR == 6, CS = U4 || U6;   // CS: constant LDS slots
+  constexpr bool SWP = FR >= 2, DUAL = FR == 3 || FR == 6 || FR == 8, U4 = FR == 5 || FR == 7, U6 = FR == 6 || FR == 8, CS = U4 || U6;   // CS: constant LDS slots
   // PRE (FR = 7): the caller's scale * log2(e) is exactly 1 (q was scaled where it was produced): scores ARE exponents, and the softmax
   // reference -m enters as the C operand of a score block's first MFMA, so exp2 is applied straight to the accumulator
-  constexpr bool PRE = FR == 7;
+  constexpr bool PRE = FR == 7 || FR == 8;           // 8: the two-per-CU form (FR = 6) in its exponent form
   constexpr int PD = (FR == 2 || U4) ? 3 : pp::PD, RK = DUAL ? 2 : (U4 ? 4 : (FR == 2 ? 3 : pp::RK)),
                 RV = DUAL ? 3 : (U4 ? 4 : (FR == 2 ? 5 : pp::RV));
   constexpr int K_OFF = CS ? RV * 16384 : 0, V_OFF = CS ? 0 : RK * 16384;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float c2 = FR == 7 ? 1.0f : A.scale_log2;     // FR = 7 is only launched when the product is 1 to rounding
+  const float c2 = (FR == 7 || FR == 8) ? 1.0f : A.scale_log2;     // FR = 7 / 8 are only launched when the product is 1 to rounding
   const int kswz = l31 & 15;
   const int vi = lane & 15, vg1 = (lane >> 4) & 1;
   const int v_rowq = vi >> 2;
@@ -1137,23 +1137,24 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots)
 #ifndef PP_DUAL_FR
 #define PP_DUAL_FR 6     // 6: six-times unrolled over constant LDS slots; 3: the two-times unrolled form it replaced
 #endif
+template <int DFR>
 static void launch_pp_dual(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   constexpr int LDS_DUAL = 5 * 16384;                   // 80 KiB: two workgroups per CU
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 1, PP_DUAL_FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
     attr_set = true;
   }
   const dim3 block(256);
   if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 1, DFR>), grid, block, LDS_DUAL, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 1, DFR>), grid, block, LDS_DUAL, stream, a);
   } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 1, PP_DUAL_FR>), grid, block, LDS_DUAL, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, DFR>), grid, block, LDS_DUAL, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 1, DFR>), grid, block, LDS_DUAL, stream, a);
   }
 }
 
@@ -1272,9 +1273,11 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
     set_error("ifx_attn_fwd_paged_split: split / partial launches need a workspace");
     return IFX_EINVAL;
   }
-  if (fr_mode == 3) launch_pp_dual(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  const bool pre = fabsf(a.scale_log2 - 1.0f) <= 2.5e-7f;   // q carries scale * log2(e) already (ifx_rope_grid.q_scale): scores are exponents
+  if (fr_mode == 3 && pre && PP_DUAL_FR == 6) launch_pp_dual<8>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  else if (fr_mode == 3) launch_pp_dual<PP_DUAL_FR>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 2) launch_pp_fr<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (fr_mode == 5 && fabsf(a.scale_log2 - 1.0f) <= 2.5e-7f)   // q carries scale * log2(e) already (ifx_rope_grid.q_scale): scores are exponents
+  else if (fr_mode == 5 && pre)
     launch_pp_fr<7>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 5) launch_pp_fr<5>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
   else if (fr_mode == 1) launch_pp_fr<1>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);

@@ -396,6 +396,7 @@ class HipSequenceParallel:
         qv = q_out.view(n_local, H, hd)
         av = a_out.view(n_local, H, hd)
         dev = q_out.device
+        scale = getattr(model, "_attn_scale", 0.0)    # ln 2 when q carries scale * log2(e) (hip_ops.attn_q_prescale), else the default
 
         def arrived():
             if st["side"]:
@@ -408,13 +409,13 @@ class HipSequenceParallel:
             s2 = ops.attention_split_plan(n_local, H, step.local_end - step.local_start)
             cap = s1 + s2
             ws = ops.attention_workspace(qv, cap)
-            u1 = ops.attention_partial(qv, view, step.local_start, 0, s1, ws, 0, cap, tag="attn_self")
+            u1 = ops.attention_partial(qv, view, step.local_start, 0, s1, ws, 0, cap, scale=scale, tag="attn_self")
             arrived()
-            u2 = ops.attention_partial(qv, view, step.local_end, step.local_start, s2, ws, u1, cap, tag="attn_self")
+            u2 = ops.attention_partial(qv, view, step.local_end, step.local_start, s2, ws, u1, cap, scale=scale, tag="attn_self")
             ops.attention_merge(ws, cap, u1 + u2, av)
         else:
             arrived()
-            ops.attention(qv, view, step.local_end, out=av, tag="attn_self")
+            ops.attention(qv, view, step.local_end, scale=scale, out=av, tag="attn_self")
         return step
 
     def self_attention(self, model, l, b, view, qkv_b, q_out, a_out, w, rope, current_start, g_end, l_end,

@@ -461,9 +461,10 @@ class HipCausalWanModel(torch.nn.Module):
         # ---- scratch ---------------------------------------------------------------------
         h = self._buf("h", B * N, d)
         start_frame = current_start // fs
-        # single-GPU path: q leaves the norm / RoPE kernel already multiplied by scale * log2(e) (one rounding to bf16 either way) and the
+        # q leaves the norm / RoPE kernel already multiplied by scale * log2(e) (one rounding to bf16 either way) and the
         # attention is called with scale = ln 2 — the same softmax(q k^T / sqrt(d)), without a scale-FMA per score in the attention loop
-        q_scale, attn_scale = ops.attn_q_prescale(self.head_dim) if (self.q_prescale and self.cp is None) else (0.0, 0.0)
+        q_scale, attn_scale = ops.attn_q_prescale(self.head_dim) if self.q_prescale else (0.0, 0.0)
+        self._attn_scale = attn_scale                 # the sequence-parallel attention calls (sequence_parallel.finish) read it here
         rope = ops.RopeGridSpec(self.freqs, start_frame, grid[1], grid[2], cp_rank * hw_local, hw_local, q_scale)
         sink_tokens = self.sink_size * fs
 

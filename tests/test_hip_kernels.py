@@ -505,9 +505,9 @@ def test_attention_both_kernels(ops, variant):
         ops.set_option("attn_variant", 0)
 
 
-@pytest.mark.parametrize("variant", [0, 7])
+@pytest.mark.parametrize("variant", [0, 6, 7])
 def test_attention_prescaled_q_exponent_fast_path(ops, variant):
-    """scale * log2(e) == 1: `attn_fwd_pp_kernel<.., 7>` applies exp2 straight to the MFMA accumulators (the reference maximum enters as the
+    """scale * log2(e) == 1: `attn_fwd_pp_kernel<.., 7>` (and `<.., 8>`, the two-per-CU form) applies exp2 straight to the MFMA accumulators (the reference maximum enters as the
     C operand).  Every remainder of the four-times unrolled loop, ragged / paged / split launches, the kernels without the fast path
     (short prefixes, small launches: same call, generic arithmetic), and the redo path of the lazy maximum."""
     ops.set_option("attn_variant", variant)
