@@ -468,6 +468,9 @@ typedef struct {
   ifx_bf16* v_out;
   int32_t ld_kv, kv_head_stride;
   int32_t row0, split, row1;
+  float q_scale;                              /* q (self-attention queries only) is multiplied by this in fp32 before its one rounding to bf16;
+                                                 0 = 1.  softmax_scale * log2(e) here + attention scale = ln 2 = the same attention on the
+                                                 exponent fast path (see ifx_rope_grid.q_scale) */
 } ifx_magi_head_prep_desc;
 int ifx_magi_head_prep(const ifx_magi_head_prep_desc* desc, void* stream);
 

@@ -42,6 +42,7 @@ struct HeadPrepArgs {
   unsigned short* v_out;
   int ld_kv, kv_head_stride;
   int row0, split, row1;         // dest(r) = r < split ? row0 + r : row1 + (r - split)
+  float q_scale;                 // self-attention q only: applied in fp32 before the rounding to bf16 (1 = the reference's q)
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void magi_head_prep_kernel(HeadPrepArgs A) {
     const float sn = i < 4 ? s0[i] : s1[i - 4], cs = i < 4 ? c0[i] : c1[i - 4];
     // out1 = x1 * cos - x2 * sin ; out2 = x1 * sin + x2 * cos   (products rounded separately, as the elementwise torch ops do)
     const float out = lo ? __fmul_rn(y[i], cs) - __fmul_rn(p, sn) : __fmul_rn(p, sn) + __fmul_rn(y[i], cs);
-    o[i] = f2bf(out);
+    o[i] = f2bf(type == HT_Q ? out * A.q_scale : out);
   }
   if (type == HT_Q) *reinterpret_cast<u16x8*>(A.q_out + (size_t)r * A.ld_q + hidx * 128 + e0) = o;
   else *reinterpret_cast<u16x8*>(A.k_out + (size_t)dest * A.ld_kv + hidx * A.kv_head_stride + e0) = o;
@@ -348,6 +349,8 @@ extern "C" int ifx_magi_head_prep(const ifx_magi_head_prep_desc* d, void* stream
   a.eps = d->eps;
   a.one_p = d->layernorm_1p ? 1 : 0;
   a.q_out = d->q_out, a.ld_q = d->ld_q, a.qx_out = d->qx_out, a.ld_qx = d->ld_qx;
+  IFX_REQUIRE(d->q_scale >= 0.f && d->q_scale == d->q_scale, "ifx_magi_head_prep: q_scale must be >= 0 (0 = 1)");
+  a.q_scale = d->q_scale > 0.f ? d->q_scale : 1.0f;
   a.k_out = d->k_out, a.v_out = d->v_out, a.ld_kv = d->ld_kv, a.kv_head_stride = d->kv_head_stride;
   a.row0 = d->row0, a.split = d->split, a.row1 = d->row1;
   if (d->rows == 0) return IFX_OK;

@@ -669,7 +669,7 @@ F32 = torch.float32
 def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: int, eps: float, layernorm_1p: bool,
                    k_out: torch.Tensor, v_out: torch.Tensor, kv_head_stride: int, ld_kv: int, row0: int = 0,
                    split: Optional[int] = None, row1: int = 0, rope: Optional[torch.Tensor] = None, qn=None, kn=None, xn=None,
-                   q_out: Optional[torch.Tensor] = None, qx_out: Optional[torch.Tensor] = None) -> None:
+                   q_out: Optional[torch.Tensor] = None, qx_out: Optional[torch.Tensor] = None, q_scale: float = 0.0) -> None:
     """ifx_magi_head_prep: per-head LayerNorm (+ rotary) of the fused projection row and the k / v scatter (include/inferix_hip.h).
     `qn` / `kn` = (weight, bias) fp32 `[128]`; `xn` = (weight, bias) bf16 `[128]`; `k_out` / `v_out` are base tensors of the
     destination (cache planes or a staging buffer), addressed dest(r) * ld_kv + head * kv_head_stride."""
@@ -690,6 +690,7 @@ def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: 
     d.xn_w, d.xn_b = _dev(xn[0], "layernorm_xattn.weight"), _dev(xn[1], "layernorm_xattn.bias")
     d.k_out, d.v_out, d.ld_kv, d.kv_head_stride = _dev(k_out, "k_out"), _dev(v_out, "v_out"), int(ld_kv), int(kv_head_stride)
     d.row0, d.split, d.row1 = int(row0), int(rows if split is None else split), int(row1)
+    d.q_scale = float(q_scale)                  # self-attention q pre-multiplied (attn_q_prescale); 0 = 1
     n_heads = (2 * q_heads + 2 * kv_heads) if layout == 0 else 2 * kv_heads
     with _timed("magi_head_prep", 0.0, 4.0 * rows * n_heads * 128):
         _hip.check(_hip.load().ifx_magi_head_prep(C.byref(d), _stream()), "ifx_magi_head_prep")

@@ -25,6 +25,7 @@ Batch 1 only (as `core_attention`'s cached path upstream: 3-cfg folds ranges int
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -38,6 +39,10 @@ from .attention import MagiKVCacheManager
 from .types import InferenceParams, ModelMetaArgs
 
 BF16 = torch.bfloat16
+# self-attention queries leave ifx_magi_head_prep multiplied by softmax_scale * log2(e) (one rounding to bf16 either way) and the core
+# attention is called with scale = ln 2: the same softmax(q k^T / sqrt(128)), on the exponent fast path of the attention kernel.  The
+# cross-attention queries (qx) keep the reference's form.
+Q_SCALE, ATTN_SCALE = ops.attn_q_prescale(128) if os.environ.get("IFX_MAGI_Q_PRESCALE", "1") != "0" else (0.0, 0.0)
 FP32_PARAMS = ("self_attention.q_layernorm.", "self_attention.k_layernorm.", "self_attn_post_norm.", "mlp_post_norm.",
                "final_layernorm.")
 
@@ -138,7 +143,7 @@ class HipFullyParallelAttention:
             ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
                                k_out=handle.view.k, v_out=handle.view.v, kv_head_stride=self.hd, ld_kv=self.hk * self.hd,
                                row0=row0, split=split, row1=row1, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
-                               xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
+                               xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf, q_scale=Q_SCALE)
             _range_attention(q_buf, handle, cq, ck, meta_args.denoising_range_num, attn_cat, self.hq)
         elif strategy == "cp_shuffle_overlap":
             self._cso(mixed, rope, q_buf, qx_buf, attn_cat, inference_params, meta_args, cp, eps, one_p)
@@ -167,7 +172,7 @@ class HipFullyParallelAttention:
         ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
                            k_out=kv_stage, v_out=kv_stage.view(-1)[self.hd:], kv_head_stride=2 * self.hd,
                            ld_kv=self.hk * 2 * self.hd, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
-                           xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
+                           xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf, q_scale=Q_SCALE)
         cq = meta_args.core_attn_params.np_q_range
         ck = meta_args.core_attn_params.np_k_range
 
@@ -195,7 +200,7 @@ class HipFullyParallelAttention:
         ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
                            k_out=kv_stage, v_out=kv_stage.view(-1)[self.hd:], kv_head_stride=2 * self.hd,
                            ld_kv=self.hk * 2 * self.hd, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
-                           xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf)
+                           xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf, q_scale=Q_SCALE)
         kv, handle_kv = cpl.cso_communication(kv_stage, cp, sizes, "kv")               # [(cp dn m), hk_local, 2 hd]
         helper = cpl.CSOHelper(dn, cp, sizes)
         qs, handle_q = helper.split_query_for_overlap(q_buf.view(s_len, self.hq, self.hd))
@@ -215,7 +220,7 @@ class HipFullyParallelAttention:
             ks, ke = int(ck[i, 0]), int(ck[i, 1])
             if ke > handle.kv_len:
                 raise ValueError(f"k_range[{i}] = [{ks}, {ke}) exceeds the {handle.kv_len} available keys")
-            ops.attention_ld(q.view(rows, -1), handle.view, ke, out.view(rows, -1), heads, kv_start=ks, tag="attn_magi")
+            ops.attention_ld(q.view(rows, -1), handle.view, ke, out.view(rows, -1), heads, kv_start=ks, scale=ATTN_SCALE, tag="attn_magi")
             return out
         outs, handle_attn = helper.overlap(fattn, qs, handle, handle)
         handle_attn.wait()
@@ -238,7 +243,7 @@ def _range_attention(q2d: torch.Tensor, handle, q_range, k_range, n: int, out2d:
     #  different ranges stream different key windows out of phase, so the L2 sharing between the query tiles of one launch is lost.
     #  The entry point stays for callers with many short ranges, where launch count is what costs.)
     for (qs, qe), (ks, ke) in zip(qr, kr):
-        ops.attention_ld(q2d[qs:qe], handle.view, ke, out2d[qs:qe], heads, kv_start=ks, tag="attn_magi")
+        ops.attention_ld(q2d[qs:qe], handle.view, ke, out2d[qs:qe], heads, kv_start=ks, scale=ATTN_SCALE, tag="attn_magi")
 
 
 def _cross_segments(xp):
