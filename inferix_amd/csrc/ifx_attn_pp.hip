@@ -1033,8 +1033,8 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   }
   if (PP_TRACE && wi == 0 && A.lse != nullptr) {
     __syncthreads();
-    const long long* tp = reinterpret_cast<const long long*>(smem + (FR == 2 ? LDS_SWP : LDS_BYTES));
-    for (int i = tid; i < (FR == 2 ? 48 : 64) * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
+    const long long* tp = reinterpret_cast<const long long*>(smem + (FR >= 2 ? LDS_SWP : LDS_BYTES));
+    for (int i = tid; i < (FR >= 2 ? 48 : 64) * 4 * NG * 8; i += 256 * NG) reinterpret_cast<long long*>(A.lse)[i] = tp[i];
   }
   // ---- drain: PV of the last tile
   if (FR == 0) {
