@@ -266,14 +266,22 @@ def test_attention_480p_block_shapes(ops):
 
 @pytest.mark.parametrize("kv_len", [14040, 23400, 32760])
 @pytest.mark.parametrize("paged", [False, True])
-def test_attention_480p_long_prefixes_vs_fp64_oracle(ops, kv_len, paged):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_480p_long_prefixes_vs_fp64_oracle(ops, kv_len, paged, prescaled):
     """The prefix lengths of blocks 2 / 4 / 6 of the BASELINE clip (where 70 % of the attention time is): 4680 queries x 12 heads
     over 14040 / 23400 / 32760 cached keys, default schedule, contiguous and through a page table (pages of one frame, shuffled).
     192 query rows (the first, a middle and the last ragged tile) against the CPU fp64 oracle, with the reference's own bf16 SDPA
-    measured on the same rows as the yardstick: the kernel may be at most twice as far from exact attention as the reference is."""
+    measured on the same rows as the yardstick: the kernel may be at most twice as far from exact attention as the reference is.
+    `prescaled`: the form the model uses — q multiplied by scale * log2(e) before its rounding to bf16, the call with scale = ln 2 (the
+    exponent fast path); the fp64 reference is evaluated on that q."""
     g = torch.Generator().manual_seed(kv_len + int(paged))
     rows, heads, hd, fsz = 4680, 12, 128, 1560
     q, k, v = rnd(g, rows, heads, hd), rnd(g, kv_len, heads, hd), rnd(g, kv_len, heads, hd)
+    q_call, scale, q64 = q, 0.0, q
+    if prescaled:
+        q_scale, scale = ops.attn_q_prescale(hd)
+        q_call = (q.float() * q_scale).to(BF)
+        q64 = q_call.double() * (scale * math.sqrt(hd))
     if paged:
         pages = kv_len // fsz
         perm = torch.randperm(pages, generator=g)
@@ -283,14 +291,14 @@ def test_attention_480p_long_prefixes_vs_fp64_oracle(ops, kv_len, paged):
         view = ops.KvCacheView(gpu(kp), gpu(vp), perm.to(torch.int32).cuda(), fsz)
     else:
         view = ops.KvCacheView(gpu(k), gpu(v))
-    out, lse = ops.attention(gpu(q), view, kv_len, return_lse=True)
+    out, lse = ops.attention(gpu(q_call), view, kv_len, scale=scale, return_lse=True)
     sel = torch.cat([torch.arange(0, 64), torch.arange(2300, 2364), torch.arange(4616, 4680)])
-    ref64, lse64 = O.attention_with_lse(q[sel][None], k[None], v[None])
+    ref64, lse64 = O.attention_with_lse(q64[sel][None], k[None], v[None])
     ref_bf = O.attention(q[sel][None], k[None], v[None])[0]
     got = out[sel.cuda()].cpu().double()
     e_gpu, e_ref = (got - ref64[0]).abs().max().item(), (ref_bf.double() - ref64[0]).abs().max().item()
     r_gpu, r_ref = rel_l2(got, ref64[0]), rel_l2(ref_bf, ref64[0])
-    print(f"L={kv_len} paged={paged}: max|err| hip {e_gpu:.3e} / reference bf16 SDPA {e_ref:.3e}; rel-L2 hip {r_gpu:.3e} / reference {r_ref:.3e}")
+    print(f"L={kv_len} paged={paged} prescaled={prescaled}: max|err| hip {e_gpu:.3e} / reference bf16 SDPA {e_ref:.3e}; rel-L2 hip {r_gpu:.3e} / reference {r_ref:.3e}")
     assert e_gpu <= 2 * e_ref + 1e-3, (kv_len, e_gpu, e_ref)
     assert r_gpu <= 2 * r_ref + 1e-3, (kv_len, r_gpu, r_ref)
     assert (lse[:, sel.cuda()].cpu().double() - lse64[0]).abs().max().item() < 2e-3
