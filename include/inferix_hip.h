@@ -37,6 +37,11 @@ extern "C" {
 typedef uint16_t ifx_bf16;
 
 /* library identity ------------------------------------------------------- */
+/* The MINOR number is the ABI generation: it changes whenever an argument struct gains a field or an entry point changes its
+ * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: this round).  Callers built against another minor
+ * must not call in: zero-initialise every struct (new fields default to 0 = off) and compare IFX_ABI_MINOR with
+ * (ifx_version() >> 8) & 255 at load time, as inferix_amd/_hip.py does. */
+#define IFX_ABI_MINOR 3
 int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */

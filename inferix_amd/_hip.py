@@ -138,6 +138,7 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
+ABI_MINOR = 3      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
 
 
 def load() -> C.CDLL:
@@ -154,6 +155,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    got = (lib.ifx_version() >> 8) & 255
+    if got != ABI_MINOR:       # a stale .so next to newer bindings (or the reverse): the argument structs would not line up
+        raise HipLibraryMissing(f"{LIB_PATH} has ABI minor {got}, these bindings are for {ABI_MINOR} (include/inferix_hip.h "
+                                "IFX_ABI_MINOR): rebuild with __graft_entry__.build()")
     _lib = lib
     return lib
 

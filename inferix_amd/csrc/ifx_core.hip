@@ -37,7 +37,7 @@ int check_launch(const char* what) {
 }
 }  // namespace ifx
 
-extern "C" int ifx_version(void) { return (0 << 16) | (1 << 8) | 0; }
+extern "C" int ifx_version(void) { return (0 << 16) | (IFX_ABI_MINOR << 8) | 0; }
 extern "C" const char* ifx_last_error(void) { return ifx::g_err; }
 extern "C" const char* ifx_arch(void) { return "gfx950"; }
 extern "C" int ifx_set_option(const char* key, int32_t value) {

@@ -89,6 +89,7 @@ class KVCacheManager:
         self.device = torch.device(device)
         self.offload_device = torch.device("cpu")
         self.request_to_kv_caches: Dict[str, KVCaches] = {}
+        self._generation: Dict[tuple, int] = {}      # (request id, layer) -> how many times that layer has been allocated
 
     # ---- allocation -------------------------------------------------------
     def allocate_slots(self, req: KVCacheRequest, spec: KVCacheRequestSpec) -> KVCaches:
@@ -103,6 +104,7 @@ class KVCacheManager:
             caches.specs[name] = KVCacheTensorSpec(
                 size=coef * tokens * s.num_kv_heads * s.head_size * get_dtype_size(s.dtype),
                 num_tokens=tokens, num_blocks=num_blocks, block_size=spec.block_size, spec=s)
+            self._generation[(req.request_id, name)] = self._generation.get((req.request_id, name), 0) + 1
             caches.tensors[name] = torch.empty(
                 (coef, num_blocks, spec.block_size, s.num_kv_heads, s.head_size), dtype=s.dtype,
                 device=self.offload_device if s.kv_offload else self.device,
@@ -118,6 +120,14 @@ class KVCacheManager:
         del c.specs[layer_name]
         c.page_tables.pop(layer_name, None)
         c.views.pop(layer_name, None)
+
+    def allocation_id(self, req: KVCacheRequest, layer_name: str) -> tuple:
+        """(request id, layer, generation): names ONE allocation of a layer's cache.  A data pointer does not — the caching
+        allocator hands a freed address out again — and the generation is a pure function of the call sequence, so the ranks of an
+        SPMD run agree on it (what inferix_amd.sequence_parallel keys its peer mappings by)."""
+        if layer_name not in self.request_to_kv_caches[req.request_id].tensors:
+            raise KeyError(layer_name)
+        return (req.request_id, layer_name, self._generation[(req.request_id, layer_name)])
 
     # ---- lookup -----------------------------------------------------------
     def layers(self, req: KVCacheRequest) -> Union[KeysView[str], Sequence[str]]:

@@ -129,6 +129,11 @@ class MagiKVCacheManager:
         # logical keys [0, start + stored) are in place, the n - stored unstored rows sit in the scratch tail at [capacity, ...):
         # a two-segment map (no per-token table: the attention kernel's paged address path does one dependent load per key row)
         unstored = n - stored
+        if unstored and start + stored == 0:
+            # nothing in place in front of the unstored rows (forward_3cfg's first pass: update_kv_cache=False with
+            # slice_point = chunk_start - 1 = 0): seg_split == 0 means "no map" to every reader, so the view is simply BASED at the
+            # scratch tail — logical key j == row j of the tail, rows written at (row0, split, row1) = (0, 0, 0) of that view
+            return MagiKvHandle(ops.KvCacheView(kc[capacity:], vc[capacity:]), n, hn), (0, 0, 0)
         view = ops.KvCacheView(kc, vc, None, 1, start + stored if unstored else 0, capacity - (start + stored) if unstored else 0)
         return MagiKvHandle(view, start + n, hn), (start, stored, capacity)
 

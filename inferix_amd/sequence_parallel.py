@@ -136,7 +136,7 @@ class PeerStoreExchange:
             raise ValueError(f"peer-store exchange is built for up to {_hip.IFX_MAX_PEERS} ranks, got {self.world}")
         self.timeout_ms = timeout_ms
         self._opened: Dict[bytes, int] = {}                 # IPC handle -> base address mapped into this process
-        self._views: Dict[Tuple[int, int], Tuple[List[int], List[int]]] = {}
+        self._views: Dict[Tuple, Tuple[List[int], List[int]]] = {}
         self._epoch = [0] * self.MAX_LAYERS
         self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
         try:
@@ -189,18 +189,43 @@ class PeerStoreExchange:
                                + (f" ({self._last_error})" if getattr(self, "_last_error", None) else ""))
         return out
 
-    def cache_addresses(self, view) -> Tuple[List[int], List[int]]:
-        """(K base, V base) of this (request, layer) cache on every rank; exchanged the first time a cache tensor is seen (a
-        collective: every rank reaches it at the same call)."""
-        key = (view.k.data_ptr(), view.v.data_ptr())
-        got = self._views.get(key)
+    @staticmethod
+    def view_geometry(view) -> Tuple:
+        """What `push` assumes is IDENTICAL on every rank, because it addresses the peers' slots through this rank's own view:
+        slot count, heads, head size, page size and the page table's contents (crc of the host copy)."""
+        import zlib
+        pt = getattr(view, "page_table", None)
+        crc = 0 if pt is None else zlib.crc32(pt.detach().cpu().numpy().tobytes())
+        return (int(view.k.shape[0]), int(view.k.shape[1]), int(view.k.shape[2]), int(getattr(view, "page_size", 1)), crc)
+
+    def cache_addresses(self, view, ident: Optional[Tuple] = None) -> Tuple[List[int], List[int]]:
+        """(K base, V base) of this (request, layer) cache on every rank; exchanged the first time an ALLOCATION is seen (a
+        collective: every rank reaches it at the same call).  `ident` = `KVCacheManager.allocation_id(req, layer)` — (request, layer,
+        generation), on which the ranks of an SPMD run agree.  Keying by data pointers (round 2) was wrong twice over: a freed cache's
+        address can come back on one rank and not on its peers (stale mapping -> stores into freed peer memory), and ranks that
+        disagree on hit / miss deadlock in the exchange.  Without an `ident` (the self test's scratch cache) nothing is remembered.
+        Raises — on every rank together — if the ranks' cache geometries or page tables differ."""
+        got = self._views.get(ident) if ident is not None else None
         if got is None:
+            kp, vp = view.k.data_ptr(), view.v.data_ptr()
             if self.emulated:
-                got = ([key[0]], [key[1]])
+                got = ([kp], [vp])
             else:
-                got = (self._exchange_addresses(key[0]), self._exchange_addresses(key[1]))
-            self._views[key] = got
+                geo: List = [None] * self.world
+                dist.all_gather_object(geo, self.view_geometry(view), group=self.group)
+                if any(g != geo[0] for g in geo):
+                    raise RuntimeError(f"peer-store exchange: ranks disagree on the cache geometry / page table of {ident}: {geo}")
+                got = (self._exchange_addresses(kp), self._exchange_addresses(vp))
+            if ident is not None:
+                for old in [k for k in self._views if k[:2] == ident[:2]]:      # earlier allocations of this (request, layer)
+                    del self._views[old]
+                self._views[ident] = got
         return got
+
+    def forget(self, request_id: str) -> None:
+        """Drop the mappings of a freed request (the manager's `free`); harmless if there are none."""
+        for k in [k for k in self._views if k[0] == request_id]:
+            del self._views[k]
 
     # ---- per layer ----
     def _index(self, layer: int, kind: int) -> int:
@@ -208,12 +233,12 @@ class PeerStoreExchange:
         return (layer * 2 + kind) * _hip.IFX_MAX_PEERS
 
     def push(self, layer: int, kv_rows: torch.Tensor, wk: torch.Tensor, eps: float, rope, view, local_start: int, frame_tokens: int,
-             dim: int) -> int:
+             dim: int, ident: Optional[Tuple] = None) -> int:
         """On the current stream: ready -> wait for every peer's ready -> store the rows everywhere -> done.  Returns the epoch."""
         from . import hip_ops as ops
         if layer >= self.MAX_LAYERS:
             raise ValueError(f"layer {layer}: the flag block holds {self.MAX_LAYERS} layers")
-        ks, vs = self.cache_addresses(view)
+        ks, vs = self.cache_addresses(view, ident)
         self._epoch[layer] += 1
         e = self._epoch[layer]
         hw_local = rope.hw_local
@@ -287,13 +312,17 @@ class PeerStoreExchange:
         """Raise — on EVERY rank together — if a wait gave up on any rank (one small MAX all-reduce of the status words; synchronises:
         call at a point that synchronises anyway).  A rank that timed out alone and raised alone would leave its peers in the next
         collective."""
+        words = [int(self.status.item())]
         if not self.emulated and dist.is_initialized():
-            dist.all_reduce(self.status, op=dist.ReduceOp.MAX, group=self.group)
-        st = int(self.status.item())
-        if st:
+            # every rank's own status word (1 + index of the peer it gave up on, 0 = fine): a MAX all-reduce would name the highest
+            # awaited index seen ANYWHERE, not who waited for whom
+            everyone = [torch.zeros_like(self.status) for _ in range(self.world)]
+            dist.all_gather(everyone, self.status, group=self.group)
+            words = [int(t.item()) for t in everyone]
+        if any(words):
             self.status.zero_()
-            raise RuntimeError(f"peer-store exchange: a wait timed out after {self.timeout_ms} ms (rank {self.rank} sees status {st}: "
-                               f"waiting for rank {st - 1} somewhere in the group)")
+            pairs = ", ".join(f"rank {r} gave up waiting for rank {w - 1}" for r, w in enumerate(words) if w)
+            raise RuntimeError(f"peer-store exchange: a wait timed out after {self.timeout_ms} ms ({pairs})")
 
     def close(self) -> None:
         from . import hip_ops as ops
@@ -351,9 +380,10 @@ class HipSequenceParallel:
             model._evict(mgr, req, name, view, step)
             view = model._kv_view(mgr, req, name)
         have_prefix = step.local_start > 0
+        ident = mgr.allocation_id(req, name) if hasattr(mgr, "allocation_id") else None
         if self.peer is not None:
-            try:                                            # first use of a cache tensor: handles travel (collective, main stream)
-                self.peer.cache_addresses(view)
+            try:                                            # first use of an allocation: handles travel (collective, main stream)
+                self.peer.cache_addresses(view, ident)
             except RuntimeError as exc:                     # raised on every rank together: all fall back to the collective
                 import warnings
                 warnings.warn(f"peer-store exchange disabled, using the all-gather: {exc}")
@@ -368,7 +398,7 @@ class HipSequenceParallel:
 
         def exchange():
             if self.peer is not None:
-                st["epoch"] = self.peer.push(l, kv_rows, w["nk"], model.eps, rope, view, step.local_start, fs, d)
+                st["epoch"] = self.peer.push(l, kv_rows, w["nk"], model.eps, rope, view, step.local_start, fs, d, ident)
                 return
             # this rank's K / V -> staging (a dense 1-shard cache), one collective [2, n_local, H, D] -> [P, 2, n_local, H, D], one
             # kernel scatters K and V rows to their cache slots (through the page table when there is one)

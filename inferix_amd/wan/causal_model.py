@@ -44,6 +44,13 @@ class ParallelConfig:
     def __init__(self, ulysses_size=1, ring_size=1, local_rank=0, rank=0, world_size=1,
                  ring_strategy="pass-kv", attn_backend=None):
         from ..attention import collect_supported_attn
+        if ulysses_size != 1 or ring_size != 1:
+            # the reference sizes each rank's cache 32760 / ring x heads / ulysses (self_forcing_kv_cache_manager.py:45-57) and runs
+            # CoreAttention's all-to-all + ring (attention/distributed.py:53-281).  This build shards the SEQUENCE only
+            # (inferix_amd/sequence_parallel.py: hw-slice per frame, K/V all-gather, replicated cache; 12 heads do not divide by 8)
+            # and takes its degree from world_size: a caller asking for a Ulysses / ring degree must hear that, not be ignored.
+            raise ValueError(f"ulysses_size={ulysses_size} / ring_size={ring_size}: this build has no Ulysses or ring attention; "
+                             "sequence parallelism is selected by world_size (see inferix_amd/sequence_parallel.py)")
         self.ulysses_size, self.ring_size = ulysses_size, ring_size
         self.local_rank, self.rank, self.world_size = local_rank, rank, world_size
         self.ring_strategy = ring_strategy
@@ -120,6 +127,9 @@ class HipCausalWanModel(torch.nn.Module):
         self.qk_norm, self.cross_attn_norm = qk_norm, cross_attn_norm
         self.enable_kv_offload = enable_kv_offload
         self.parallel_config = parallel_config if parallel_config is not None else ParallelConfig()
+        if getattr(self.parallel_config, "ulysses_size", 1) != 1 or getattr(self.parallel_config, "ring_size", 1) != 1:
+            raise ValueError("CausalWanModel: ulysses_size / ring_size != 1 are not supported by this build (sequence parallelism "
+                             "follows world_size; see ParallelConfig)")      # also catches duck-typed configs (SimpleNamespace)
         self.num_frame_per_block = 1
         self.independent_first_frame = False
         self.device_ = torch.device(device)
@@ -312,7 +322,9 @@ class HipCausalWanModel(torch.nn.Module):
         else:
             g_end = l_end = 0
         step = None
-        kv_first = self.cp is not None and self.cp.kv_first and "qkv_w" in w
+        # 8-bit linears stay on the fused (norm + quantise -> one qkv GEMM) path: quantize_dynamic keeps the bf16 "qkv_w" next to
+        # "qkv_q" / "qkv_s", so the test is for the QUANTISED entry — a split projection on the bf16 weights would silently bypass it
+        kv_first = self.cp is not None and self.cp.kv_first and "qkv_q" not in w
         if kv_first:
             # sequence parallel: the K/V projection first, so that the exchange of the new block's K/V (side stream) runs under the
             # q projection, its norm/RoPE and the attention over the old prefix (same GEMM rows as the fused projection)
@@ -451,6 +463,10 @@ class HipCausalWanModel(torch.nn.Module):
                 same = (padded == padded[:, -1:]).all(-1)                        # [B, text_len]
                 idx = torch.arange(self.text_len, device=dev).expand(B, -1)
                 first = (torch.where(same, -1, idx).amax(1) + 1).tolist()         # first row of the trailing identical run
+                live = getattr(kv_cache_manager, "request_to_kv_caches", None)
+                if live is not None:                                             # entries of requests the manager has freed since
+                    for rid in [r for r in self._cross_dedup if r not in live]:
+                        del self._cross_dedup[rid]
                 for b, req in enumerate(kv_cache_requests or []):
                     j0 = min(int(first[b]), self.text_len - 1)
                     self._cross_dedup[req.request_id] = (j0 + 1, self.text_len - j0)

@@ -242,3 +242,50 @@ def test_product_context_shuffle_overlap_gloo_world4_matches_reference_golden():
         assert len(ret) == world
         for r in range(world):
             assert ret[r] == [], f"rank {r}: mismatching entries {ret[r]}"
+
+
+def test_kv_adapter_host_logic_matches_oracle_for_every_flag_combination():
+    """The product adapter's placement rule (in-place rows / scratch tail / two-segment map) against the cache oracle on CPU, for
+    every (slice_point, update_kv_cache, fwd_extra_1st_chunk, nearly_clean) the reference can reach — including forward_3cfg's first
+    pass (slice_point = 0, update_kv_cache = False), where NOTHING is in place in front of the unstored rows and a map with
+    seg_split == 0 would read as "no map" (round-2 advisor finding)."""
+    from inferix_amd.magi.attention import MagiKVCacheManager
+    from inferix_amd.magi.types import InferenceParams, ModelMetaArgs
+    hn, hd, clip, cap = 2, 8, 4, 32
+    g = torch.Generator().manual_seed(11)
+    for sp in (0, 1, 2):
+        for upd in (False, True):
+            for fe in (False, True):
+                for di in (False, True):
+                    if sp == 0 and not fe:
+                        continue                      # no cache involvement: fresh planes, nothing to place
+                    mgr = MagiKVCacheManager(0, hn, hd, None)
+                    ip = InferenceParams(1, cap, device="cpu")
+                    oracle = M.MagiCacheOracle(cap, hn, hd)
+                    if sp:                            # a clean prefix first
+                        pre = torch.randn(sp * clip, hn, 2 * hd, generator=g).to(torch.bfloat16)
+                        ip.update_kv_cache = True
+                        m0 = ModelMetaArgs(H=1, W=1, cp_pad_size=0, cp_split_sizes=None, slice_point=0, denoising_range_num=1,
+                                           range_num=1, extract_prefix_video_feature=False, fwd_extra_1st_chunk=True,
+                                           distill_nearly_clean_chunk=False, clip_token_nums=clip, enable_cuda_graph=False,
+                                           core_attn_params=None, cross_attn_params=None)
+                        mgr.adjust_key_and_value_for_inference(pre, ip, m0)
+                        oracle.adjust(pre, slice_point=0, clip_token_nums=clip, update_kv_cache=True, fwd_extra_1st_chunk=True)
+                    kv = torch.randn(2 * clip, hn, 2 * hd, generator=g).to(torch.bfloat16)
+                    ip.update_kv_cache = upd
+                    meta = ModelMetaArgs(H=1, W=1, cp_pad_size=0, cp_split_sizes=None, slice_point=sp, denoising_range_num=1,
+                                         range_num=1, extract_prefix_video_feature=False, fwd_extra_1st_chunk=fe,
+                                         distill_nearly_clean_chunk=di, clip_token_nums=clip, enable_cuda_graph=False,
+                                         core_attn_params=None, cross_attn_params=None)
+                    handle = mgr.adjust_key_and_value_for_inference(kv, ip, meta)
+                    kr, vr = oracle.adjust(kv, slice_point=sp, clip_token_nums=clip, update_kv_cache=upd,
+                                           fwd_extra_1st_chunk=fe, distill_nearly_clean_chunk=di)
+                    k, v = handle.materialize()
+                    tag = (sp, upd, fe, di)
+                    assert handle.kv_len == kr.shape[0], tag
+                    assert torch.equal(k, kr) and torch.equal(v, vr), tag
+                    # a view never carries a map that readers would take for "no map"
+                    assert not (handle.view.seg_delta and not handle.view.seg_split), tag
+                    raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_0")
+                    rows = sp * clip + ((2 * clip - (clip if di else 0)) if upd else 0)      # what the rule has stored so far
+                    assert torch.equal(raw[:, :rows, 0], oracle.mem.reshape(2, cap, hn, hd)[:, :rows]), tag
