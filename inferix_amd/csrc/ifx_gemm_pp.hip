@@ -1,0 +1,541 @@
+// bf16 linear layer, PERSISTENT PING-PONG tile (gfx950): one 8-wave workgroup per CU walks its list of 64*TJ (tokens) x 256 (channels)
+// output tiles; the two waves of every SIMD alternate roles every half K-step, so the matrix pipe always has a wave issuing MFMAs
+// out of registers while its partner issues the LDS-DMA of later K-steps and reads its own fragments of the next one.
+//
+//   y[M,N] = epilogue( x[M,K] @ W[N,K]^T + bias[N] )            (same contract and epilogues as ifx_gemm_glds.hip)
+//
+// Why (round 3; profiles/r3_gemm_pp.md).  The eight-wave 256 x 256 x 64 tile of ifx_gemm_glds.hip runs its two waves per SIMD in LOCK
+// STEP: after the one barrier per K-step both issue their 8 LDS-DMA pieces (~60 cycles each, serialised per SIMD: ~1000 cycles with
+// nothing on the matrix pipe), then both read fragments and wait for LDS (four times per K-step), then both want the matrix pipe.
+// ISA of that loop: vmcnt(0) / barrier / 8 x DMA / 4 x (6 ds_read_b128, lgkmcnt(0), 8 MFMA) = ~3660 cycles per K-step for 2048 cycles
+// of MFMA (SQ_VALU_MFMA_BUSY 0.45-0.57).  Here, per SIMD and per K-step g (two phases, one barrier each):
+//
+//   phase 2g   : group 0 (waves 0-3)  32 MFMAs of K-step g from registers      | group 1 (waves 4-7)  DMA issue, fragment reads of g
+//   phase 2g+1 : group 0  DMA issue, fragment reads of K-step g+1              | group 1  32 MFMAs of K-step g
+//
+//   * wave tile 32*TJ (tokens) x 64 (channels); group 0 owns the upper token half of the tile, group 1 the lower one, the four waves
+//     of a group the four channel quarters.  ALL fragments of a K-step (16 x + 8 W ds_read_b128 = 96 VGPRs) are read in the wave's
+//     loader phase: the MFMA phase contains nothing but MFMAs and an LDS slot is free one phase after its last reader.
+//   * LDS = two K-step stages of four 16 KiB slots (x-upper, W-lo, W-hi, x-lower) + 2 x 16 KiB of transpose scratch for the epilogues.
+//     Group 0 requests W (lo, hi of K-step g+1 in phase 2g-1), group 1 requests x (x-lower of g+1 and x-upper of g+2 in phase 2g): eight
+//     1 KiB pieces per wave and phase, every piece two to three phases (>= 2 x 1024 matrix-pipe cycles) ahead of its first reader,
+//     64-96 KiB in flight per CU; waits are COUNTED on the requesting wave (vmcnt(2 TJ) / vmcnt(TJ) / vmcnt(0) = "my pieces of the
+//     slot the next phase reads").  DMA from inline asm (hipcc would fence every later ds_read with vmcnt(0), see ifx_attn_pp.hip).
+//   * persistent: the request stream runs across output tiles (the first K-steps of the next tile are in flight while the last ones
+//     of this tile are multiplied).  BOTH groups run the epilogue of a tile in the phase of group 1's last MFMAs (group 0 under those
+//     MFMAs, group 1 right behind them), each through its own scratch; bias / residual / gate are fetched by asm loads with counted
+//     waits, so the only compiler-visible vector-memory operations in the kernel are the output stores (hipcc's own vmcnt waits
+//     would otherwise drain the request stream: 6000 cycles per epilogue in the first version, profiles/r3_gemm_pp.md).
+//   * layout, swizzle (16-byte chunk XOR ((row >> 1) & 7)), transposed MFMA tile (A = W rows, B = x rows: a lane owns 4 consecutive
+//     channels of one token), K order and the LDS-transposed epilogue are those of the other tiles: outputs are bit-identical.
+#include <stdlib.h>
+
+#include "ifx_common.h"
+
+#ifndef IFX_PP_TRACE
+#define IFX_PP_TRACE 0      // 1: s_memtime segment sums of workgroup 0 (tools/gemm_lab.cpp -t reads them back)
+#endif
+
+namespace ifx {
+
+struct EpiArgsP {
+  const unsigned short* bias;
+  const unsigned short* residual;
+  int ld_res;
+  const unsigned short* mod;
+  int mod_slots, gate_slot, rows_per_group;
+};
+
+namespace gpp {
+constexpr int BN = 256, BK = 64;
+constexpr int SLOT = 16384, STAGE = 4 * SLOT, SCRATCH = 2 * STAGE;      // two 64 KiB stages + 2 x 16 KiB epilogue scratch = 160 KiB
+constexpr int LDS_BYTES = SCRATCH + 32768;
+constexpr int X_UP = 0, W_LO = SLOT, W_HI = 2 * SLOT, X_DN = 3 * SLOT;  // slots of a stage
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ v4i make_rsrc(const void* base, unsigned num_bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xffffu);      // stride 0: raw buffer, byte offsets, reads past num_bytes return 0
+  r[2] = (int)num_bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ float gelu_tanh_p(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// lgkmcnt(0) through the builtin (simm16: vmcnt 63, expcnt 7, lgkmcnt 0), so that hipcc's own scoreboard knows the fragment reads have
+// returned: after an asm wait it keeps protecting their registers with lgkmcnt(14 .. 0) in the middle of the next batch of reads
+__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+// one request cursor: K-step kt of tile i (the g-th K-step of this workgroup's stream), descriptor of that tile's operand rows
+struct Cursor {
+  int i, kt, g, rot;
+  v4i rs;
+};
+}  // namespace gpp
+
+template <int EPI, int TJ>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                         const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
+                                                         int ldy, int M, int N, int K, int tiles_m, int total, int per_xcd,
+                                                         int wg_per_xcd, EpiArgsP ea, unsigned long long* __restrict__ trace, int dbg) {
+  using namespace gpp;
+  constexpr int BM = 64 * TJ;               // tokens per tile: two groups x TJ blocks of 32
+  constexpr int GM = 4;                     // row tiles per rasterisation group (see ifx_gemm_glds.hip)
+  constexpr bool RES = EPI == IFX_EPI_RESIDUAL || EPI == IFX_EPI_GATE_RES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int KT = K / BK;
+  const int tiles_n = total / tiles_m;
+
+  // ---- this workgroup's tiles: XCD (bid & 7) owns ids [xcd * per_xcd, ...); its wg_per_xcd workgroups take them round-robin, so the
+  //      workgroups resident on one XCD always work on consecutive ids = a GM x (32 / GM) block of tiles sharing operand panels in L2
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  const int id_first = xcd * per_xcd + slot_i;
+  const int id_end = min(xcd * per_xcd + per_xcd, total);
+  if (id_first >= id_end) return;
+  const int n_my = (id_end - id_first + wg_per_xcd - 1) / wg_per_xcd;
+  const int G = n_my * KT;                  // K-steps of the whole request stream
+  auto tile_base = [&](int i, int& m_base, int& n_base) __attribute__((always_inline)) {
+    const int t_id = id_first + i * wg_per_xcd;
+    const int grp_sz = GM * tiles_n;
+    const int first_m = (t_id / grp_sz) * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int rem = t_id % grp_sz;
+    m_base = (first_m + rem % gm) * BM;
+    n_base = (rem / gm) * BN;
+  };
+
+  // ---- loader side.  A piece = one wave instruction = 8 rows x 128 B, lane -> row lane >> 3, PHYSICAL 16-byte chunk lane & 7, which
+  //      holds LOGICAL chunk (lane & 7) ^ ((row >> 1) & 7).  Wave w4 of the loading group moves pieces q * 4 + w4 of a slot: rows
+  //      (q * 4 + w4) * 8 + (lane >> 3) — the swizzle phase does not depend on q, so ONE voffset per wave; the piece, the K-step and
+  //      the tile half are scalar offsets.  Rows past M / N read zeros through the descriptor's bound.
+  const int r8 = lane >> 3, pc = lane & 7;
+  const int prow = w4 * 8 + r8;
+  const int ld_op = grp == 0 ? K : ldx;              // row pitch of the operand this group requests (W / x)
+  const int voff = prow * ld_op * 2 + ((pc ^ ((prow >> 1) & 7)) << 4);
+  const unsigned lds_piece0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + w4 * 1024;
+  auto cur_desc = [&](Cursor& c) __attribute__((always_inline)) {                   // descriptor (and lab rotation) of tile c.i
+    int mb, nb;
+    tile_base(c.i, mb, nb);
+    if (dbg & 1) mb = nb = 0;                        // lab: every workgroup streams tile 0's operands (L2-hot), timing only
+    c.rot = (dbg & 4) ? ((nb / BN) * 3) % KT : 0;    // lab: K rotation by column tile
+    if (grp == 0) c.rs = make_rsrc(w + (size_t)nb * K, (unsigned)min(((long)N - nb) * (long)K * 2L, 0xffffffffL));
+    else c.rs = make_rsrc(x + (size_t)mb * ldx, (unsigned)min(((long)M - mb - 1) * (long)ldx * 2L + (long)K * 2L, 0xffffffffL));
+  };
+  auto cur_init = [&](Cursor& c) __attribute__((always_inline)) {
+    c.i = 0, c.kt = 0, c.g = 0;
+    cur_desc(c);
+  };
+  auto cur_next = [&](Cursor& c) __attribute__((always_inline)) {
+    ++c.g;
+    if (++c.kt == KT) {
+      c.kt = 0;
+      if (++c.i < n_my) cur_desc(c);
+    }
+  };
+  // `pieces` 1 KiB pieces of the cursor's K-step: rows row0 + (q * 4 + w4) * 8 ... of the tile's operand -> slot `slot` of its stage
+  auto issue = [&](const Cursor& c, int slot, int row0, int pieces) __attribute__((always_inline)) {
+    const int kk = c.kt + c.rot;
+    const int kb = (kk >= KT ? kk - KT : kk) * 128;
+    const unsigned p = lds_piece0 + (c.g & 1) * STAGE + slot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < pieces) dma16(c.rs, p + q * 4096, voff, kb + (row0 + q * 32) * ld_op * 2);
+  };
+  Cursor ca, cb;                                     // group 0: ca = W.  group 1: ca = x-lower, cb = x-upper (one K-step ahead of ca)
+  cur_init(ca);
+  cur_init(cb);
+
+  // ---- reader side: fragment row = block base + (lane & 31), logical chunk 2 ks + (lane >> 5)
+  const int l31 = lane & 31, hi = lane >> 5;
+  int lane_ks[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) lane_ks[ks] = l31 * 128 + (((2 * ks + hi) ^ ((l31 >> 1) & 7)) << 4);
+  const int w_frag_off = (w4 >> 1) * SLOT + (w4 & 1) * 8192 + W_LO;     // this wave's 64 W rows: W-lo (waves 0, 1) / W-hi (waves 2, 3)
+  const int x_frag_off = grp == 0 ? X_UP : X_DN;
+  bf16x8 fx[4][TJ], fw[4][2];
+  int rg = 0;                                        // K-step the next read_frags reads
+  auto read_frags = [&]() __attribute__((always_inline)) {
+    const unsigned char* st = smem + (rg & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fw[ks][i] = *reinterpret_cast<const bf16x8*>(st + w_frag_off + lane_ks[ks] + i * 4096);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fx[ks][j] = *reinterpret_cast<const bf16x8*>(st + x_frag_off + lane_ks[ks] + j * 4096);
+    }
+    ++rg;
+  };
+
+  f32x16 acc[2][TJ];
+  auto mfma_first = [&]() __attribute__((always_inline)) {                          // first K-step of a tile: the accumulators start from zero
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0][i], fx[0][j], z, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
+  };
+  auto mfma_next = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- epilogue of tile i_tile for THIS wave.  `between` = what the caller wants ahead of the epilogue's own memory operations in the
+  //      in-order queue (this phase's DMA and the counted wait for the slot the NEXT phase reads).  Then bias (8 x 8 B per lane),
+  //      residual (4 TJ x 16 B) and the gate rows (2 x 16 B) are fetched with ordinary loads — hipcc counts its waits over its own
+  //      operations only, and everything older (the DMA just issued) returns first: one memory latency per epilogue, nothing drained
+  //      that was requested later.  (Asm loads with hand-counted waits were tried: hipcc is free to spill or recycle the destination
+  //      registers of an asm statement at once — the data of a load still in flight then lands in whatever lives there next: wild
+  //      addresses in the following loads.)  32-token blocks go one at a time through the wave's 4 KiB of scratch: v = bf16(acc + bias)
+  //      transposed to token-major rows of 128 B, then row-contiguous 16-byte accesses for the activation / residual / gate and the store.
+  // Lane-derived addressing is re-derived from an opaque lane id: hoisted out of the K loop it would stay live across it (the loop runs
+  // at ~232 VGPRs: 128 accumulators + 96 fragment registers).
+  unsigned char* const tw = smem + SCRATCH + wave * 4096;
+  auto epilogue = [&](int i_tile, auto between) __attribute__((always_inline)) {
+    between();
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
+    const int l31 = ln & 31, hi = ln >> 5, rr = ln >> 3, cc = ln & 7;
+    int m_base, n_base;
+    tile_base(i_tile, m_base, n_base);
+    const int e_n0 = min(n_base + w4 * 64, N - 64);   // a wave whose 64 channels lie past N (N % 64 == 0) fetches valid addresses, stores nothing
+    const bool n_ok = n_base + w4 * 64 < N;
+    const int e_m0 = m_base + grp * (32 * TJ);
+    const bool has_bias = ea.bias != nullptr;
+    const unsigned short* const bias_p = has_bias ? ea.bias : y;      // any valid address: the values are not used without a bias
+    u32x2 e_bias[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_bias[i][g] = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + i * 32 + g * 8 + hi * 4);
+    u32x4 e_res[2][4], e_gate[2];                     // residual rows of two 32-token blocks: the next block's are in flight under this one's work
+    int e_split = 0;                                  // first token of the wave's second gate group
+    auto fetch_res = [&](int j) __attribute__((always_inline)) {
+      if constexpr (RES) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = min(e_m0 + j * 32 + p * 8 + rr, M - 1);      // rows past M: any valid address, the store is masked
+          e_res[j & 1][p] = *reinterpret_cast<const u32x4*>(ea.residual + (size_t)m * ea.ld_res + e_n0 + cc * 8);
+        }
+      }
+    };
+    if constexpr (RES) {
+      fetch_res(0);
+      if constexpr (EPI == IFX_EPI_GATE_RES) {
+        // the wave's 32 TJ tokens lie in at most two gate groups (rows_per_group >= 32 TJ, checked by the launcher)
+        const int m_hi = min(e_m0 + 32 * TJ - 1, M - 1);
+        const int g_lo = min(e_m0, M - 1) / ea.rows_per_group, g_hi = m_hi / ea.rows_per_group;
+        e_split = (g_lo + 1) * ea.rows_per_group;
+        e_gate[0] = *reinterpret_cast<const u32x4*>(ea.mod + ((size_t)g_lo * ea.mod_slots + ea.gate_slot) * N + e_n0 + cc * 8);
+        e_gate[1] = *reinterpret_cast<const u32x4*>(ea.mod + ((size_t)g_hi * ea.mod_slots + ea.gate_slot) * N + e_n0 + cc * 8);
+      }
+    }
+    unsigned char* const wr = tw + l31 * 128 + hi * 8;
+    const unsigned char* const rd = tw + rr * 128;
+    unsigned short* const yrow = y + (size_t)(e_m0 + rr) * ldy + e_n0 + cc * 8;
+    // Every loaded register is TOUCHED (an empty asm that reads it) on every path: hipcc waits for a load where its value is used, and a
+    // use that it sinks into a branch (the masked store of a ragged tile) leaves the load "maybe pending" at the loop back-edge — it then
+    // protects the registers with vmcnt(3 .. 0) in the middle of the NEXT K-step's fragment reads, which drains the whole DMA queue
+    // (measured: the loader phase 1100 -> 1900 cycles in the residual / gate instantiations).
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_bias[i][g]));
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      if (j + 1 < TJ) fetch_res(j + 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (has_bias) {
+            const u32x2 b = e_bias[i][g];
+            v[0] += __builtin_bit_cast(float, b[0] << 16);
+            v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
+            v[2] += __builtin_bit_cast(float, b[1] << 16);
+            v[3] += __builtin_bit_cast(float, b[1] & 0xffff0000u);
+          }
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          // channel nl = i * 32 + g * 8 + hi * 4 of token l31: 16-byte chunk (i * 4 + g) XOR (l31 & 7), half hi
+          *reinterpret_cast<u16x4*>(wr + (((i * 4 + g) ^ (l31 & 7)) << 4)) = o;
+        }
+      wait_lds();                                            // wave-private region: no barrier
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int mrow = p * 8 + rr;
+        const int m = e_m0 + j * 32 + mrow;
+        const u16x8 vv = *reinterpret_cast<const u16x8*>(rd + p * 1024 + ((cc ^ (mrow & 7)) << 4));
+        if constexpr (RES) asm volatile("" : "+v"(e_res[j & 1][p]));
+        if constexpr (EPI == IFX_EPI_GATE_RES) {
+          if (j == 0 && p == 0) asm volatile("" : "+v"(e_gate[0]), "+v"(e_gate[1]));
+        }
+        u16x8 o;
+        if constexpr (EPI == IFX_EPI_BIAS) {
+          o = vv;
+        } else if constexpr (EPI == IFX_EPI_GELU_TANH) {
+          if (ea.gate_slot) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_p(bf2f(vv[e])));
+          }
+        } else {
+          const u16x8 rv = __builtin_bit_cast(u16x8, e_res[j & 1][p]);
+          if constexpr (EPI == IFX_EPI_RESIDUAL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + bf2f(vv[e]));
+          } else {
+            const u16x8 gv = __builtin_bit_cast(u16x8, m >= e_split ? e_gate[1] : e_gate[0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+          }
+        }
+        if (m < M && n_ok) *reinterpret_cast<u16x8*>(yrow + (size_t)(j * 32 + p * 8) * ldy) = o;
+      }
+      // (no wait here: the LDS operations of one wave execute in order, the next block's writes cannot overtake these reads)
+    }
+  };
+
+#if IFX_PP_TRACE
+  // six segment sums per group (cycles), kept in scalar registers and written once: per-stamp stores would queue behind the DMA
+  // stream and perturb exactly what is measured
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  int seg_i = 0;
+#define PP_STAMP()                                                 \
+  do {                                                             \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    seg[seg_i] += t_now - t_last;                                  \
+    t_last = t_now;                                                \
+    seg_i = seg_i == 5 ? 0 : seg_i + 1;                            \
+  } while (0)
+#else
+#define PP_STAMP() \
+  do {             \
+  } while (0)
+#endif
+  // lab: loader waves 1 and 3 of a group read their fragments BEFORE they issue their DMA (the LDS serves two waves at a time instead of
+  // four while the other two sit in their DMA issue stalls)
+#ifndef IFX_PP_STAGGER
+#define IFX_PP_STAGGER 0
+#endif
+  const bool reads_first = IFX_PP_STAGGER && (w4 & 1);     // (a run-time switch here costs 400 spilled registers: two definitions of the fragment set)
+
+  // ---- the two role sequences.  Both execute 2 G + 1 barriers.  Segments of the trace: 0 barrier behind the MFMA phase, 1 DMA issue
+  //      (+ fragment reads of the staggered waves), 2 epilogue, 3 fragment reads + waits, 4 barrier behind the loader phase, 5 MFMAs
+  int kt = 0, it = 0;                                // K-step within the tile / tile index of the K-step g being multiplied
+  if (grp == 0) {
+    issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);          // W(0)
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                    // -> phase -1: group 1 has x-upper(0)
+    for (int g = 0; g < G; ++g) {
+      // ---------------- phase 2g - 1: loader (W of K-step g + 1), epilogue of the tile that ended with K-step g - 1 ----------------
+      PP_STAMP();
+      const bool epi = g > 0 && kt == 0;
+      const bool issued = ca.g < G;
+      const bool early_reads = reads_first && !epi;
+      if (epi) {
+        epilogue(it - 1, [&]() __attribute__((always_inline)) {
+          if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
+          PP_STAMP();                                // 1: DMA issue
+        });
+        PP_STAMP();                                  // 2: the epilogue proper
+        read_frags();                                // x-upper(g), W(g)
+      } else if (early_reads) {
+        read_frags();
+        if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
+        PP_STAMP();
+        PP_STAMP();
+      } else {
+        if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
+        PP_STAMP();
+        PP_STAMP();
+        read_frags();
+      }
+      wait_lds();
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 2g: MFMA ----------------
+      PP_STAMP();
+      if (!(dbg & 2)) {
+        if (kt == 0) mfma_first();
+        else mfma_next();
+      }
+      if (++kt == KT) kt = 0, ++it;
+      wait_vm<0>();                                  // W(g+1) (requested one phase ago) landed for the next phase's readers
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // phase 2G - 1: the last tile, under group 1's last MFMAs
+    epilogue(it - 1, [&]() __attribute__((always_inline)) {});
+  } else {
+    // x-upper(0); x-lower(0), x-upper(1): the x-upper cursor runs one K-step ahead of the x-lower cursor
+    issue(cb, X_UP, 0, TJ), cur_next(cb);
+    issue(ca, X_DN, 32 * TJ, TJ), cur_next(ca);
+    if (cb.g < G) issue(cb, X_UP, 0, TJ), cur_next(cb);
+    if (G > 1) wait_vm<2 * TJ>();                    // x-upper(0) landed
+    else wait_vm<TJ>();
+    __builtin_amdgcn_s_barrier();                    // -> phase -1 (group 0 reads K-step 0)
+    if (G > 1) wait_vm<TJ>();                        // x-lower(0) landed
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                    // -> phase 0
+    for (int g = 0; g < G; ++g) {
+      // ---------------- phase 2g: loader (x-lower of K-step g + 1, x-upper of g + 2) ----------------
+      PP_STAMP();
+      const bool lower = ca.g < G, upper = cb.g < G;
+      if (reads_first) {
+        read_frags();
+        if (lower) issue(ca, X_DN, 32 * TJ, TJ), cur_next(ca);
+        if (upper) issue(cb, X_UP, 0, TJ), cur_next(cb);
+        PP_STAMP();
+        PP_STAMP();
+      } else {
+        if (lower) issue(ca, X_DN, 32 * TJ, TJ), cur_next(ca);
+        if (upper) issue(cb, X_UP, 0, TJ), cur_next(cb);
+        PP_STAMP();
+        PP_STAMP();
+        read_frags();                                // x-lower(g), W(g)
+      }
+      wait_lds();
+      // x-upper(g+1) (requested two phases ago) has to have landed before group 0's phase: everything but this phase's requests
+      if (upper) wait_vm<2 * TJ>();
+      else if (lower) wait_vm<TJ>();
+      else wait_vm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 2g + 1: MFMA, then the epilogue if the tile is complete ----------------
+      PP_STAMP();
+      if (!(dbg & 2)) {
+        if (kt == 0) mfma_first();
+        else mfma_next();
+      }
+      if (++kt == KT) kt = 0, ++it;
+      // x-lower(g+1) landed for this group's next phase: all but the x-upper(g+2) pieces behind it
+      if (upper) wait_vm<TJ>();
+      else wait_vm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP();
+      if (kt == 0) epilogue(it - 1, [&]() __attribute__((always_inline)) {});      // K-step g closed tile it - 1
+      if (g + 1 < G) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#if IFX_PP_TRACE
+  if (trace != nullptr && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) trace[grp * 8 + k] = seg[k];
+    trace[grp * 8 + 6] = (unsigned long long)G;
+  }
+#endif
+}
+
+int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
+                   int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj) {
+  using namespace gpp;
+  EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
+  if (N % 64 != 0 || K % 64 != 0) {
+    set_error("ifx_gemm_bf16: the ping-pong tile needs N and K to be multiples of 64 (N = %d, K = %d)", N, K);
+    return IFX_EINVAL;
+  }
+  if (mode == IFX_EPI_GATE_RES && rows_per_group < 32 * tj) {
+    set_error("ifx_gemm_bf16: the ping-pong tile needs gate groups of at least %d rows (rows_per_group = %d)", 32 * tj, rows_per_group);
+    return IFX_EINVAL;
+  }
+  const bool res = mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES;
+  if (((uintptr_t)bias & 7) || (res && (((uintptr_t)residual & 15) || ld_res % 8 != 0)) ||
+      (mode == IFX_EPI_GATE_RES && ((uintptr_t)mod & 15))) {
+    set_error("ifx_gemm_bf16: the ping-pong tile needs 8-byte aligned bias and 16-byte aligned residual / gate rows");
+    return IFX_EINVAL;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int BM = 64 * tj;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
+  const dim3 grid(wg_per_xcd * 8), block(512);
+  static unsigned long long* trace = nullptr;
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char* e = getenv("IFX_PP_DEBUG");       // lab only: 1 all workgroups stream tile 0, 2 no MFMAs, 4 K rotation by column tile, 16 staggered loaders
+    dbg = e ? atoi(e) : 0;
+  }
+#if IFX_PP_TRACE
+  if (!trace) {
+    const char* e = getenv("IFX_PP_TRACE_PTR");
+    if (e) trace = (unsigned long long*)strtoull(e, nullptr, 0);
+  }
+#endif
+#define IFX_LAUNCH_PP(E, T)                                                                                                       \
+  do {                                                                                                                            \
+    static bool attr_set = false;                                                                                                 \
+    if (!attr_set) {                                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<E, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);   \
+      attr_set = true;                                                                                                            \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((gemm_pp_kernel<E, T>), grid, block, LDS_BYTES, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd,    \
+                       wg_per_xcd, ea, trace, dbg);                                                                               \
+  } while (0)
+#define IFX_SWITCH_PP(T)                                              \
+  switch (mode) {                                                     \
+    case IFX_EPI_BIAS: IFX_LAUNCH_PP(IFX_EPI_BIAS, T); break;         \
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_PP(IFX_EPI_GELU_TANH, T); break; \
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_PP(IFX_EPI_RESIDUAL, T); break; \
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T); break; \
+    default: return IFX_EINVAL;                                       \
+  }
+  if (tj == 4) { IFX_SWITCH_PP(4) }
+  else if (tj == 3) { IFX_SWITCH_PP(3) }
+  else if (tj == 2) { IFX_SWITCH_PP(2) }
+  else return IFX_EINVAL;
+#undef IFX_SWITCH_PP
+#undef IFX_LAUNCH_PP
+  return check_launch("ifx_gemm_bf16(pp)");
+}
+
+}  // namespace ifx
