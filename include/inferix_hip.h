@@ -55,7 +55,9 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   18 = four-wave 256x256 on the LDS-DMA ring (experiment), 19 = four-wave 256x256x64 register-staged software
  *                   pipeline (ifx_gemm_w4.hip), 20 = auto including its split-K form when a workspace is given,
  *                   21 = 256x192x64 (what 0 = auto picks where 192-wide columns fill the rounds better: the QKV projection),
- *                   22 / 23 / 24 = the persistent ping-pong tiles of ifx_gemm_pp.hip: 256 / 192 / 128 tokens x 256 channels
+ *                   22 / 23 / 24 = the persistent ping-pong tiles of ifx_gemm_pp.hip: 256 / 192 / 128 tokens x 256 channels (what 0 =
+ *                   auto picks for launches of at least 2048 rows); 22 splits K over two workgroups per tile where N <= 2048 and
+ *                   K >= 4096 when the caller gives a workspace (ifx_gemm_bf16_ws), 25 = 22 without that split
  *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
  *                   4 free-running schedule, 5 software-pipelined schedule, 6 software-pipelined in four-wave workgroups, two per CU,
  *                   7 software-pipelined and unrolled four times over constant LDS slots (what 0 = auto picks for large launches)

@@ -187,6 +187,32 @@ int launch_gemm_w4(const unsigned short* x, int ldx, const unsigned short* w, un
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int splits, void* workspace);
 size_t gemm_w4_workspace_bytes(int M, int N, int splits);
+// persistent ping-pong tiles (ifx_gemm_pp.hip): 64 tj tokens x 256 channels, K split in two when gemm_pp_split(N, K) and a workspace is given
+int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
+                   int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace);
+bool gemm_pp_split(int N, int K);
+size_t gemm_pp_workspace_bytes(int M, int N, int K);
+
+// Which ping-pong tile (tokens = 64 tj) for a launch, 0 = none.  Model fitted to tools/gemm_lab.cpp on the block's shapes (1 x MI355X,
+// profiles/r3_gemm_pp.md): a workgroup needs ~1.6 / 1.4 / 1.2 us per 64-deep K-step on the 256 / 192 / 128-token tile (the smaller
+// tiles are bound by their loader phase, not by the matrix pipe) plus ~3 us per tile (8 with a GELU epilogue); the launch takes
+// ceil(tiles / CUs) of those.  With K split in two (gemm_pp_split) there are twice the work items of half the length, 256-token tile only.
+static int pick_pp(int M, int N, int K, int mode, bool have_ws) {
+  if (M < 2048 || N % 64 != 0 || K % 64 != 0) return 0;
+  if (have_ws && gemm_pp_split(N, K) && ((M + 255) / 256) * ((N + 255) / 256) <= 1024) return 4;
+  static const float step_us[5] = {0.f, 0.f, 1.2f, 1.4f, 1.6f};
+  const float tile_us = (mode == IFX_EPI_GELU_TANH ? 8.f : 3.f);
+  int best = 0;
+  float best_t = 1e30f;
+  for (int tj = 4; tj >= 2; --tj) {
+    const int tiles = ((M + 64 * tj - 1) / (64 * tj)) * ((N + 255) / 256);
+    const int rounds = (tiles + 255) / 256;
+    const float t = rounds * ((K / 64) * step_us[tj] + tile_us);
+    if (t < best_t) best_t = t, best = tj;
+  }
+  return best;
+}
 
 // Split-K over two workgroups on the four-wave 256 x 256 tile (ifx_gemm_w4.hip): long-K launches whose 256 x 256 tiles fill less
 // than half of the chip — the FFN down-projection, 4680 x 1536 x 8960: 114 tiles, 228 workgroups with the split.  Needs a caller
@@ -302,6 +328,18 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
       workspace_bytes >= (int64_t)gemm_w4_workspace_bytes(M, N, 2))
     return launch_gemm_w4(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
                           ea.rows_per_group, (hipStream_t)stream, 2, workspace);
+  // persistent ping-pong tiles: 22 / 23 / 24 force the 256 / 192 / 128-token tile (25 = 256 without the K split), 0 = auto picks one for
+  // launches of at least 2048 rows; the gate epilogue needs groups of at least a wave's token rows, the operands 16-byte rows
+  if (wide_ok && (variant == 0 || (variant >= 22 && variant <= 25))) {
+    const bool ws_ok = workspace != nullptr && workspace_bytes >= (int64_t)gemm_pp_workspace_bytes(M, N, K) && variant != 25;
+    int tj = variant == 0 ? pick_pp(M, N, K, mode, ws_ok) : (variant == 22 || variant == 25 ? 4 : variant == 23 ? 3 : 2);
+    const bool res = mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES;
+    const bool fits = N % 64 == 0 && !((uintptr_t)bias & 7) && (!res || (!((uintptr_t)ea.residual & 15) && ea.ld_res % 8 == 0)) &&
+                      (mode != IFX_EPI_GATE_RES || (!((uintptr_t)ea.mod & 15) && ea.rows_per_group >= 32 * tj));
+    if (tj && (fits || variant != 0))
+      return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                            ea.rows_per_group, (hipStream_t)stream, tj, ws_ok ? workspace : nullptr);
+  }
   if (wide_ok && variant != 1) {
     const int tile = (variant >= 2 && variant != 20) ? variant - 2 : pick_tile(M, N, K);
     return launch_gemm_lds_dma(tile, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod,
@@ -338,7 +376,11 @@ extern "C" int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, 
 }
 
 extern "C" int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
-  return (M > 0 && N > 0 && K > 0 && gemm_variant() == 20 && want_w4_splitk(M, N, K)) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int v = gemm_variant();
+  if (v == 20) return want_w4_splitk(M, N, K) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
+  if ((v == 0 && M >= 2048 && N % 64 == 0 && K % 64 == 0) || v == 22) return (int64_t)gemm_pp_workspace_bytes(M, N, K);
+  return 0;
 }
 
 extern "C" int ifx_gemm_bf16_ws(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,

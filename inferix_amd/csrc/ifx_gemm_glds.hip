@@ -993,9 +993,6 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
 int launch_gemm_w4(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int splits, void* workspace);
-int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
-                   int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
-                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj);
 
 // host launcher used by ifx_gemm_bf16 (ifx_gemm.hip) for large shapes
 int launch_gemm_glds(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M,
@@ -1061,10 +1058,6 @@ int launch_gemm_lds_dma(int tile, const unsigned short* x, int ldx, const unsign
   if (tile == 16) return launch_small<256, 256, 2>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
   // 256 x 192: the QKV projection's 4608 columns are 24 x 192 -> 456 tiles = 1.8 rounds where 256 x 256 has 1.3 (two rounds, a third idle)
   if (tile == 19) return launch_big<256, 192, 4, 2, 64>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
-  // persistent ping-pong tiles (ifx_gemm_pp.hip): 256 / 192 / 128 tokens x 256 channels
-  if (tile == 20) return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, s, 4);
-  if (tile == 21) return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, s, 3);
-  if (tile == 22) return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, s, 2);
   if (tile == 17) return launch_gemm_w4(x, ldx, w, y, ldy, M, N, K, mode, bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, s, 1, nullptr);   // ifx_gemm_w4.hip
   return launch_small<64, 64, 4>(x, ldx, w, y, ldy, M, N, K, mode, ea, s);
 }

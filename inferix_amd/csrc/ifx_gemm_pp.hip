@@ -83,16 +83,17 @@ __device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F);
 
 // one request cursor: K-step kt of tile i (the g-th K-step of this workgroup's stream), descriptor of that tile's operand rows
 struct Cursor {
-  int i, kt, g, rot;
+  int i, kt, g, rot, k0;     // k0: first K-step of the item inside the tile's K range (split-K)
   v4i rs;
 };
 }  // namespace gpp
 
-template <int EPI, int TJ>
+template <int EPI, int TJ, int KS>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* __restrict__ x, int ldx,
                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
                                                          int ldy, int M, int N, int K, int tiles_m, int total, int per_xcd,
-                                                         int wg_per_xcd, EpiArgsP ea, unsigned long long* __restrict__ trace, int dbg) {
+                                                         int wg_per_xcd, EpiArgsP ea, unsigned long long* __restrict__ trace, int dbg,
+                                                         float* __restrict__ ws_part, unsigned* __restrict__ ws_flag) {
   using namespace gpp;
   constexpr int BM = 64 * TJ;               // tokens per tile: two groups x TJ blocks of 32
   constexpr int GM = 4;                     // row tiles per rasterisation group (see ifx_gemm_glds.hip)
@@ -101,8 +102,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, w4 = wave & 3;
-  const int KT = K / BK;
-  const int tiles_n = total / tiles_m;
+  // KS = 2: every tile is TWO work items, the K halves, on two workgroups (neighbouring ids: same XCD, same position of their lists).
+  // The second half's workgroup leaves its fp32 accumulators in the workspace (write-through stores) and raises the tile's flag; the
+  // first half's workgroup adds them to its own — always first + second — and runs the epilogue.  `total` counts ITEMS.
+  const int KT = K / BK / KS;               // K-steps of one work item
+  const int tiles_n = total / KS / tiles_m;
 
   // ---- this workgroup's tiles: XCD (bid & 7) owns ids [xcd * per_xcd, ...); its wg_per_xcd workgroups take them round-robin, so the
   //      workgroups resident on one XCD always work on consecutive ids = a GM x (32 / GM) block of tiles sharing operand panels in L2
@@ -112,8 +116,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   if (id_first >= id_end) return;
   const int n_my = (id_end - id_first + wg_per_xcd - 1) / wg_per_xcd;
   const int G = n_my * KT;                  // K-steps of the whole request stream
+  auto item_split = [&](int i) __attribute__((always_inline)) { return KS > 1 ? (id_first + i * wg_per_xcd) % KS : 0; };
+  auto item_tile = [&](int i) __attribute__((always_inline)) { return (id_first + i * wg_per_xcd) / KS; };
   auto tile_base = [&](int i, int& m_base, int& n_base) __attribute__((always_inline)) {
-    const int t_id = id_first + i * wg_per_xcd;
+    const int t_id = (id_first + i * wg_per_xcd) / KS;
     const int grp_sz = GM * tiles_n;
     const int first_m = (t_id / grp_sz) * GM;
     const int gm = min(GM, tiles_m - first_m);
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     tile_base(c.i, mb, nb);
     if (dbg & 1) mb = nb = 0;                        // lab: every workgroup streams tile 0's operands (L2-hot), timing only
     c.rot = (dbg & 4) ? ((nb / BN) * 3) % KT : 0;    // lab: K rotation by column tile
+    c.k0 = item_split(c.i) * KT;
     if (grp == 0) c.rs = make_rsrc(w + (size_t)nb * K, (unsigned)min(((long)N - nb) * (long)K * 2L, 0xffffffffL));
     else c.rs = make_rsrc(x + (size_t)mb * ldx, (unsigned)min(((long)M - mb - 1) * (long)ldx * 2L + (long)K * 2L, 0xffffffffL));
   };
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   // `pieces` 1 KiB pieces of the cursor's K-step: rows row0 + (q * 4 + w4) * 8 ... of the tile's operand -> slot `slot` of its stage
   auto issue = [&](const Cursor& c, int slot, int row0, int pieces) __attribute__((always_inline)) {
     const int kk = c.kt + c.rot;
-    const int kb = (kk >= KT ? kk - KT : kk) * 128;
+    const int kb = ((kk >= KT ? kk - KT : kk) + c.k0) * 128;
     const unsigned p = lds_piece0 + (c.g & 1) * STAGE + slot;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -218,6 +225,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   // Lane-derived addressing is re-derived from an opaque lane id: hoisted out of the K loop it would stay live across it (the loop runs
   // at ~232 VGPRs: 128 accumulators + 96 fragment registers).
   unsigned char* const tw = smem + SCRATCH + wave * 4096;
+  // ---- split-K hand-off (KS = 2): a wave's accumulators as a register image, 16 B per lane and register quad, in the tile's 256 KiB of
+  //      the workspace.  Write-through (sc1) stores on the producing side, sc1 loads on the consuming side, one flag per tile in between
+  //      (raised once every wave of the producer has waited for its stores: vmcnt(0) + the workgroup barrier).
+  const __amdgpu_buffer_rsrc_t rs_ws =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ws_part, 0, KS > 1 ? (int)min((long)(total / KS) * BM * BN * 4L, 0x7fffffffL) : 0, 0x00020000);
+  auto part_soff = [&](int i) __attribute__((always_inline)) { return item_tile(i) * (BM * BN * 4) + wave * (TJ * 8192); };
+  auto dump_partial = [&](int i) __attribute__((always_inline)) {
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
+    const int so = part_soff(i);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[ii][j][4 * q], acc[ii][j][4 * q + 1], acc[ii][j][4 * q + 2], acc[ii][j][4 * q + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_ws, ln * 16 + ((ii * TJ + j) * 4 + q) * 1024, so, 16);
+        }
+  };
+  int flag_pending = 0;                              // 1 + tile whose partial this workgroup has dumped and not yet announced
+  auto consumer_sync = [&](int i) __attribute__((always_inline)) {              // all eight waves: the partner's partial is complete and visible
+    if (wave == 0) {
+      while (__hip_atomic_load(ws_flag + item_tile(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0) __hip_atomic_store(ws_flag + item_tile(i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as found: zero
+  };
   auto epilogue = [&](int i_tile, auto between) __attribute__((always_inline)) {
     between();
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -225,16 +260,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     const int l31 = ln & 31, hi = ln >> 5, rr = ln >> 3, cc = ln & 7;
     int m_base, n_base;
     tile_base(i_tile, m_base, n_base);
+    const int part_so = KS > 1 ? part_soff(i_tile) : 0;
     const int e_n0 = min(n_base + w4 * 64, N - 64);   // a wave whose 64 channels lie past N (N % 64 == 0) fetches valid addresses, stores nothing
     const bool n_ok = n_base + w4 * 64 < N;
     const int e_m0 = m_base + grp * (32 * TJ);
     const bool has_bias = ea.bias != nullptr;
     const unsigned short* const bias_p = has_bias ? ea.bias : y;      // any valid address: the values are not used without a bias
+    const unsigned bias_mask = has_bias ? 0xffffffffu : 0u;
     u32x2 e_bias[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) e_bias[i][g] = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + i * 32 + g * 8 + hi * 4);
+      for (int g = 0; g < 4; ++g) {
+        // no bias: the loaded bits are masked to +0.0 and added all the same (a branch per register quad costs more than 16 v_and)
+        const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + i * 32 + g * 8 + hi * 4);
+        e_bias[i][g] = u32x2{b[0] & bias_mask, b[1] & bias_mask};
+      }
     u32x4 e_res[2][4], e_gate[2];                     // residual rows of two 32-token blocks: the next block's are in flight under this one's work
     int e_split = 0;                                  // first token of the wave's second gate group
     auto fetch_res = [&](int j) __attribute__((always_inline)) {
@@ -276,13 +317,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (has_bias) {
-            const u32x2 b = e_bias[i][g];
-            v[0] += __builtin_bit_cast(float, b[0] << 16);
-            v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
-            v[2] += __builtin_bit_cast(float, b[1] << 16);
-            v[3] += __builtin_bit_cast(float, b[1] & 0xffff0000u);
+          if constexpr (KS > 1) {
+            // + the partner's partial sums of the second K half, read where the accumulators are consumed (writing them back into
+            // the accumulator vectors first costs hipcc ~300 spilled registers): first half + second half, then the bias
+            const f32x4 pq = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024, part_so, 16));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += pq[e];
           }
+          const u32x2 b = e_bias[i][g];
+          v[0] += __builtin_bit_cast(float, b[0] << 16);
+          v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, b[1] << 16);
+          v[3] += __builtin_bit_cast(float, b[1] & 0xffff0000u);
           u16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
@@ -365,7 +412,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       const bool epi = g > 0 && kt == 0;
       const bool issued = ca.g < G;
       const bool early_reads = reads_first && !epi;
-      if (epi) {
+      if (epi && KS > 1 && item_split(it - 1) == 1) {
+        // second K half: the accumulators go to the workspace, the partner finishes the tile
+        if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
+        PP_STAMP();
+        dump_partial(it - 1);
+        wait_vm<0>();
+        flag_pending = item_tile(it - 1) + 1;
+        PP_STAMP();
+        read_frags();
+      } else if (epi) {
+        if (KS > 1) consumer_sync(it - 1);
         epilogue(it - 1, [&]() __attribute__((always_inline)) {
           if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
           PP_STAMP();                                // 1: DMA issue
@@ -390,6 +447,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- phase 2g: MFMA ----------------
       PP_STAMP();
+      if (KS > 1 && flag_pending) {                  // every wave waited for its dump before the barrier above
+        if (wave == 0) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_pending = 0;
+      }
       if (!(dbg & 2)) {
         if (kt == 0) mfma_first();
         else mfma_next();
@@ -401,8 +462,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
-    // phase 2G - 1: the last tile, under group 1's last MFMAs
-    epilogue(it - 1, [&]() __attribute__((always_inline)) {});
+    // phase 2G - 1: the last item, under group 1's last MFMAs
+    if (KS > 1 && item_split(it - 1) == 1) {
+      dump_partial(it - 1);
+      wait_vm<0>();
+      flag_pending = item_tile(it - 1) + 1;
+    } else {
+      if (KS > 1) consumer_sync(it - 1);
+      epilogue(it - 1, [&]() __attribute__((always_inline)) {});
+    }
+    if (KS > 1) {
+      __builtin_amdgcn_s_barrier();                  // group 1's dump of the last item is complete as well
+      if (flag_pending && wave == 0) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {
     // x-upper(0); x-lower(0), x-upper(1): the x-upper cursor runs one K-step ahead of the x-lower cursor
     issue(cb, X_UP, 0, TJ), cur_next(cb);
@@ -452,8 +524,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       else wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       PP_STAMP();
-      if (kt == 0) epilogue(it - 1, [&]() __attribute__((always_inline)) {});      // K-step g closed tile it - 1
-      if (g + 1 < G) {
+      if (kt == 0) {                                 // K-step g closed item it - 1
+        if (KS > 1 && item_split(it - 1) == 1) {
+          dump_partial(it - 1);
+          wait_vm<0>();
+        } else {
+          if (KS > 1) consumer_sync(it - 1);
+          epilogue(it - 1, [&]() __attribute__((always_inline)) {});
+        }
+      }
+      if (g + 1 < G || KS > 1) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -468,9 +548,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 #endif
 }
 
+// Split K in two for long-K launches with few column tiles (the block's FFN down-projection, 1536 x 8960: 114 tiles of 256 x 256 for
+// 256 CUs).  Depends on (N, K) ONLY: a row's summation order must not change with the number of rows in the launch.
+bool gemm_pp_split(int N, int K) { return K >= 4096 && N <= 2048 && (K / 64) % 2 == 0; }
+size_t gemm_pp_workspace_bytes(int M, int N, int K) {
+  if (!gemm_pp_split(N, K)) return 0;
+  const size_t tiles = (size_t)((M + 255) / 256) * ((N + 255) / 256);
+  return tiles <= 1024 ? 4096 + tiles * 256 * 256 * 4 : 0;
+}
+
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
-                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj) {
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace) {
   using namespace gpp;
   EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
   if (N % 64 != 0 || K % 64 != 0) {
@@ -496,9 +585,14 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
   }
   const int BM = 64 * tj;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  // split K between two workgroups per tile when a workspace is given and the shape asks for it (gemm_pp_split: a function of N and K
+  // only, so that a row's bits do not depend on how many rows the launch has)
+  const int ks = (workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
+  const int total = tiles_m * tiles_n * ks, per_xcd = (total + 7) / 8;
   const int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
   const dim3 grid(wg_per_xcd * 8), block(512);
+  unsigned* ws_flag = (unsigned*)workspace;          // the first 4096 bytes: zero on entry, zero on exit
+  float* ws_part = workspace ? (float*)((char*)workspace + 4096) : nullptr;
   static unsigned long long* trace = nullptr;
   static int dbg = -1;
   if (dbg < 0) {
@@ -511,27 +605,30 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     if (e) trace = (unsigned long long*)strtoull(e, nullptr, 0);
   }
 #endif
-#define IFX_LAUNCH_PP(E, T)                                                                                                       \
-  do {                                                                                                                            \
-    static bool attr_set = false;                                                                                                 \
-    if (!attr_set) {                                                                                                              \
-      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<E, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);   \
-      attr_set = true;                                                                                                            \
-    }                                                                                                                             \
-    hipLaunchKernelGGL((gemm_pp_kernel<E, T>), grid, block, LDS_BYTES, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd,    \
-                       wg_per_xcd, ea, trace, dbg);                                                                               \
+#define IFX_LAUNCH_PP(E, T, S)                                                                                                       \
+  do {                                                                                                                               \
+    static bool attr_set = false;                                                                                                    \
+    if (!attr_set) {                                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<E, T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);   \
+      attr_set = true;                                                                                                               \
+    }                                                                                                                                \
+    hipLaunchKernelGGL((gemm_pp_kernel<E, T, S>), grid, block, LDS_BYTES, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd,    \
+                       wg_per_xcd, ea, trace, dbg, ws_part, ws_flag);                                                                \
   } while (0)
-#define IFX_SWITCH_PP(T)                                              \
-  switch (mode) {                                                     \
-    case IFX_EPI_BIAS: IFX_LAUNCH_PP(IFX_EPI_BIAS, T); break;         \
-    case IFX_EPI_GELU_TANH: IFX_LAUNCH_PP(IFX_EPI_GELU_TANH, T); break; \
-    case IFX_EPI_RESIDUAL: IFX_LAUNCH_PP(IFX_EPI_RESIDUAL, T); break; \
-    case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T); break; \
-    default: return IFX_EINVAL;                                       \
+#define IFX_SWITCH_PP(T, S)                                              \
+  switch (mode) {                                                        \
+    case IFX_EPI_BIAS: IFX_LAUNCH_PP(IFX_EPI_BIAS, T, S); break;         \
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_PP(IFX_EPI_GELU_TANH, T, S); break; \
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_PP(IFX_EPI_RESIDUAL, T, S); break; \
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T, S); break; \
+    default: return IFX_EINVAL;                                          \
   }
-  if (tj == 4) { IFX_SWITCH_PP(4) }
-  else if (tj == 3) { IFX_SWITCH_PP(3) }
-  else if (tj == 2) { IFX_SWITCH_PP(2) }
+  if (ks == 2) {                                     // split K: the 256-token tile only (what long-K, narrow-N shapes want)
+    if (tj != 4) return IFX_EINVAL;
+    IFX_SWITCH_PP(4, 2)
+  } else if (tj == 4) { IFX_SWITCH_PP(4, 1) }
+  else if (tj == 3) { IFX_SWITCH_PP(3, 1) }
+  else if (tj == 2) { IFX_SWITCH_PP(2, 1) }
   else return IFX_EINVAL;
 #undef IFX_SWITCH_PP
 #undef IFX_LAUNCH_PP

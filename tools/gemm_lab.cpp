@@ -31,6 +31,9 @@
 
 typedef int (*gemm_fn)(const ifx_bf16*, int32_t, const ifx_bf16*, const ifx_bf16*, ifx_bf16*, int32_t, int32_t, int32_t, int32_t,
                        const ifx_epilogue*, void*);
+typedef int (*gemm_ws_fn)(const ifx_bf16*, int32_t, const ifx_bf16*, const ifx_bf16*, ifx_bf16*, int32_t, int32_t, int32_t, int32_t,
+                          const ifx_epilogue*, void*, int64_t, void*);
+typedef int64_t (*ws_bytes_fn)(int32_t, int32_t, int32_t);
 typedef int (*opt_fn)(const char*, int32_t);
 typedef const char* (*err_fn)(void);
 
@@ -120,7 +123,14 @@ int main(int argc, char** argv) {
   gemm_fn gemm = (gemm_fn)dlsym(lib, "ifx_gemm_bf16");
   opt_fn set_opt = (opt_fn)dlsym(lib, "ifx_set_option");
   err_fn last_err = (err_fn)dlsym(lib, "ifx_last_error");
-  if (!gemm || !set_opt || !last_err) return 2;
+  gemm_ws_fn gemm_ws = (gemm_ws_fn)dlsym(lib, "ifx_gemm_bf16_ws");
+  ws_bytes_fn ws_bytes = (ws_bytes_fn)dlsym(lib, "ifx_gemm_workspace_bytes");
+  if (!gemm || !set_opt || !last_err || !gemm_ws || !ws_bytes) return 2;
+  // one zero-initialised workspace for every launch (as inferix_amd.hip_ops.linear keeps one per stream): 64 MiB covers the block
+  const int64_t ws_cap = 64ll << 20;
+  void* ws = nullptr;
+  CK(hipMalloc(&ws, ws_cap));
+  CK(hipMemset(ws, 0, ws_cap));
 
   unsigned long long* trace = nullptr;
   if (want_trace) {
@@ -158,7 +168,9 @@ int main(int argc, char** argv) {
     epi.rows_per_group = 1560;
     auto run = [&](int vi) {
       set_opt("gemm_variant", variants[vi]);
-      const int rc = gemm(dx, K, dw, db, dy[vi], N, M, N, K, &epi, nullptr);
+      const int64_t need = ws_bytes(M, N, K);        // what the library asks for under this variant (0: the plain entry point)
+      const int rc = (need > 0 && need <= ws_cap) ? gemm_ws(dx, K, dw, db, dy[vi], N, M, N, K, &epi, ws, ws_cap, nullptr)
+                                                  : gemm(dx, K, dw, db, dy[vi], N, M, N, K, &epi, nullptr);
       if (rc != 0) {
         fprintf(stderr, "variant %d on %s: rc %d: %s\n", variants[vi], sh.name.c_str(), rc, last_err());
         exit(3);
