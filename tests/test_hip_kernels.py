@@ -416,6 +416,14 @@ _GEMM_CASES += [(21, M, N, K) for M, N, K in [(585, 1536, 1536), (300, 640, 64),
                                               (4680, 4608, 1536)]]
 
 
+# 22 / 23 / 24 = the persistent ping-pong tiles (256 / 192 / 128 tokens x 256 channels, ifx_gemm_pp.hip), 25 = 22 without the K split:
+# one K step, odd step counts, ragged token edges, N a multiple of 64 but not of 256, fewer tiles than XCDs, several tiles per workgroup,
+# and the split shape (N <= 2048, K >= 4096: variant 22 splits through the workspace hip_ops.linear hands over, 25 does not)
+_GEMM_CASES += [(v, M, N, K) for v in (22, 23, 24, 25) for M, N, K in [(585, 1536, 1536), (700, 640, 64), (600, 64, 192),
+                                                                       (1170, 4608, 1536), (2000, 2304, 3072), (4680, 1536, 8960),
+                                                                       (9000, 8960, 128)]]
+
+
 @pytest.mark.parametrize("variant,M,N,K", _GEMM_CASES)
 def test_gemm_every_tile_variant(ops, variant, M, N, K):
     """Each GEMM kernel (register-staged 128x128, LDS-DMA 256x128 / 128x128 / 64x64) on shard shapes with ragged
@@ -471,7 +479,40 @@ def test_gemm_four_wave_tile_auto_choice_and_split_k(ops):
     assert all(torch.equal(o, outs[0]) for o in outs), "split-K result must not depend on which workgroup finishes last"
     # two K halves summed once in fp32 instead of one running sum: a flipped bf16 rounding of y moves bf16(res + bf16(y * gate))
     assert_bf16_parity(outs[0], base, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what="split-K vs single pass")
-    assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) == 0          # opt-in only
+
+
+def test_gemm_ping_pong_split_k_is_deterministic_and_row_invariant(ops):
+    """Round 3: the auto choice gives launches of >= 2048 rows to the persistent ping-pong tiles, and splits K over two workgroups per
+    tile where N <= 2048 and K >= 4096 (the FFN down-projection) — a rule on (N, K) ONLY.  So: the library asks for a workspace for that
+    shape under auto, the result is the same run to run (first half + second half, whoever finishes last), agrees with the unsplit
+    tile (variant 25) to fp32 summation order, leaves the flags zero, and a ROW's bits do not depend on how many rows the launch
+    has (4680 rows alone == the first 4680 of 9360) — for the split shape and for an unsplit one."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(78)
+    lib = _hip.load()
+    for (N, K, kw_name) in ((1536, 8960, "gate"), (4608, 1536, "bias")):
+        M = 4680
+        x, w, b = gpu(rnd(g, 2 * M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))
+        res, mod = gpu(rnd(g, 2 * M, N)), gpu(rnd(g, 6, 6, N, scale=0.5))
+        kw = dict(epilogue=_hip.IFX_EPI_GATE_RES, residual=res[:M], mod=mod, gate_slot=5, rows_per_group=1560) if kw_name == "gate" else {}
+        kw2 = dict(kw, residual=res) if kw else {}
+        assert (lib.ifx_gemm_workspace_bytes(M, N, K) > 0) == (N == 1536)
+        outs = [ops.linear(x[:M], w, b, **kw) for _ in range(4)]
+        assert all(torch.equal(o, outs[0]) for o in outs)
+        both = ops.linear(x, w, b, **kw2)
+        assert torch.equal(both[:M], outs[0]), f"N={N} K={K}: a row's bits changed with the number of rows in the launch"
+        ops.set_option("gemm_variant", 25)
+        try:
+            single = ops.linear(x[:M], w, b, **kw)
+        finally:
+            ops.set_option("gemm_variant", 0)
+        if N == 1536:
+            assert_bf16_parity(outs[0], single, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what="ping-pong split-K vs single pass")
+        else:
+            assert torch.equal(outs[0], single)
+    ws = next(iter(ops._GEMM_WS.values()))
+    torch.cuda.synchronize()
+    assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-tile flags must be left zero"
 
 
 def test_gemm_split_k_tiles_refuse_indivisible_k(ops):
