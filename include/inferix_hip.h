@@ -58,6 +58,11 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   22 / 23 / 24 = the persistent ping-pong tiles of ifx_gemm_pp.hip: 256 / 192 / 128 tokens x 256 channels (what 0 =
  *                   auto picks for launches of at least 2048 rows); 22 splits K over two workgroups per tile where N <= 2048 and
  *                   K >= 4096 when the caller gives a workspace (ifx_gemm_bf16_ws), 25 = 22 without that split
+ *   "gemm_small_split": 1 lets the auto choice split K between the wave groups of one workgroup for launches of at most one workgroup
+ *                   per CU (a sequence-parallel rank's 585 .. 2340 rows).  Off by default: those tiles sum K in a different order and
+ *                   which launches get them depends on the row count, while the default auto choice keeps a row's bits independent
+ *                   of the number of rows in the launch (its only K split, two workgroups per tile for N <= 2048 and K >= 4096
+ *                   through ifx_gemm_bf16_ws, is a function of N and K).
  *   "attn_variant": 1 four-wave kernel, 2 eight-wave ping-pong schedule, 3 twelve-wave three-phase schedule,
  *                   4 free-running schedule, 5 software-pipelined schedule, 6 software-pipelined in four-wave workgroups, two per CU,
  *                   7 software-pipelined and unrolled four times over constant LDS slots (what 0 = auto picks for large launches)

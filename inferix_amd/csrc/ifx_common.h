@@ -91,6 +91,7 @@ struct KvAddr {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 int gemm_variant();   // 0 auto, 1 register-staged 128x128, 2..8 LDS-DMA tiles (see include/inferix_hip.h)
+int gemm_small_split();   // 1: launches of at most one workgroup per CU may split K between the wave groups of a workgroup (row-count dependent bits)
 int attn_variant();   // 0 auto (= 7 for large launches), 1 four-wave kernel, 2 ping-pong, 3 three groups, 4 free-running, 5 software-pipelined, 6 its two-per-CU form, 7 its four-times-unrolled form
 
 }  // namespace ifx

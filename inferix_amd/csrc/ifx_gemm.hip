@@ -199,8 +199,11 @@ size_t gemm_pp_workspace_bytes(int M, int N, int K);
 // tiles are bound by their loader phase, not by the matrix pipe) plus ~3 us per tile (8 with a GELU epilogue); the launch takes
 // ceil(tiles / CUs) of those.  With K split in two (gemm_pp_split) there are twice the work items of half the length, 256-token tile only.
 static int pick_pp(int M, int N, int K, int mode, bool have_ws) {
-  if (M < 2048 || N % 64 != 0 || K % 64 != 0) return 0;
-  if (have_ws && gemm_pp_split(N, K) && ((M + 255) / 256) * ((N + 255) / 256) <= 1024) return 4;
+  if (N % 64 != 0 || K % 64 != 0) return 0;
+  // the split shapes at ANY row count (a row's summation order must not depend on it) unless the caller opted into the row-count
+  // dependent in-workgroup splits for small launches
+  if (have_ws && gemm_pp_split(N, K) && ((M + 255) / 256) * ((N + 255) / 256) <= 1024 && !(gemm_small_split() && M < 2048)) return 4;
+  if (M < 2048) return 0;
   static const float step_us[5] = {0.f, 0.f, 1.2f, 1.4f, 1.6f};
   const float tile_us = (mode == IFX_EPI_GELU_TANH ? 8.f : 3.f);
   int best = 0;
@@ -246,22 +249,23 @@ static int pick_tile(int M, int N, int K) {
   // Few output tiles (one rank's M = 4680 / P rows of a sequence-parallel shard): the parallelism has to come from K.  Tiles 10-12
   // split K between wave groups of ONE workgroup (no workspace, fixed summation order).  Measured, tools/bench_gemm_tiles.py 585 / 2340:
   //   585x1536x1536 12.3 -> 9.8 us (tile 10), 585x1536x8960 43.2 -> 33.8 (tile 11)
+  // They add the K halves / quarters in an order that is NOT the single-pass order, and whether a launch gets them depends on its ROW
+  // count — so they are opt-in (ifx_set_option("gemm_small_split", 1); inferix_amd.sequence_parallel turns it on for its ranks, whose
+  // row count is fixed by the rank count).  Without it the auto choice's summation order is a function of (N, K) alone: single pass
+  // everywhere except the two-workgroup K split of ifx_gemm_pp.hip (gemm_pp_split(N, K), any row count, needs the workspace of
+  // ifx_gemm_bf16_ws) — a row's bits do not change with the number of rows in the launch (tests/test_hip_kernels.py).
   const int kt = K / 64;
   const int wgs64 = ((M + 63) / 64) * ((N + 63) / 64);
-  if (wgs64 <= 256 && kt >= 64 && kt % 2 == 0) return 11;
-  if (wgs64 <= 256 && kt >= 16 && kt % 4 == 0) return 10;
+  if (gemm_small_split()) {
+    if (wgs64 <= 256 && kt >= 64 && kt % 2 == 0) return 11;
+    if (wgs64 <= 256 && kt >= 16 && kt % 4 == 0) return 10;
+  }
   // one round of 128x64 workgroups at THREE per CU (two stages, 48 KiB) instead of 1.4 rounds at two per CU:
   //   585x8960x1536 31.8 -> 29.2 us, 585x4608x1536 19.2 -> 17.7, 1170x4608x1536 28.6 -> 27.2
   const int wgs12864 = ((M + 127) / 128) * ((N + 63) / 64);
   if (wgs12864 > 256 && wgs12864 <= 768) return 13;
   // (tile 12 on 128 < wgs128 <= 256 launches is worth 10 % on 2340x1536x8960; it stays opt-in because it would flip the umT5
   //  encoder's M = 512 x batch launches between summation orders.)
-  // NOTE on batch invariance: the split-K tiles above add the K-halves / K-quarters in a fixed order, which is NOT the order of the
-  // single-pass tiles, and the choice depends on M.  A launch's bits are therefore a function of (M, N, K) — deterministic run to run,
-  // but a row's low bits may differ between two launch sizes that land on either side of the wgs64 <= 256 rule (e.g. the Wan
-  // text_embedding linear, N = 1536, K = 4096: split at one 512-token prompt, single-pass at two).  The umT5 encoder's shapes
-  // (N >= 4096) never take a split tile, which is what tests/test_hip_t5.py's batch-invariance test relies on; callers that need
-  // invariance elsewhere pin the tile with ifx_set_option("gemm_variant", ...).
   // Long K and at least ~1.5 rounds of 256 x 256 tiles: the four-wave register-staged tile (ifx_gemm_w4.hip, tile 17), whose K loop
   // needs a third less LDS bandwidth than the eight-wave tiles; its fixed cost per tile (one wave per SIMD: nothing overlaps the
   // prologue and the epilogue) is only amortised by K >= 2048.  MAGI-4.5B shapes, tools/bench_gemm_shapes.py: 6075 x 8192 x 3072
@@ -379,7 +383,7 @@ extern "C" int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int v = gemm_variant();
   if (v == 20) return want_w4_splitk(M, N, K) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
-  if ((v == 0 && M >= 2048 && N % 64 == 0 && K % 64 == 0) || v == 22) return (int64_t)gemm_pp_workspace_bytes(M, N, K);
+  if ((v == 0 && N % 64 == 0 && K % 64 == 0 && !(gemm_small_split() && M < 2048)) || v == 22) return (int64_t)gemm_pp_workspace_bytes(M, N, K);
   return 0;
 }
 

@@ -469,6 +469,10 @@ def attach_sequence_parallel(model, group=None, overlap: bool = True,
                              kv_first: Optional[bool] = None) -> HipSequenceParallel:
     """Enable sequence parallelism on a HipCausalWanModel whose ParallelConfig has world_size > 1."""
     sp = HipSequenceParallel(group, overlap, exchange, peer, kv_first)
+    # a rank's launches have 4680 / P rows: let the GEMM tile choice split K inside a workgroup for them (row-count dependent bits,
+    # which the default choice avoids; the row count of a rank is fixed by P)
+    from . import hip_ops as ops
+    ops.set_option("gemm_small_split", 1)
     pc = model.parallel_config
     if pc.world_size != sp.ex.world or pc.rank != sp.ex.rank:
         raise ValueError(f"ParallelConfig (rank {pc.rank}/{pc.world_size}) does not match the process group "

@@ -42,8 +42,10 @@ def test_cabi_argument_validation_without_gpu():
     assert b"unknown format" in lib.ifx_last_error()
     assert lib.ifx_layernorm_quant(C.c_void_p(8), C.c_void_p(8), 64, C.c_void_p(8), 4, 128, 1e-6, 0, None, None, None, 0, 0, 0, 1,
                                    0, None) == -1                      # row stride of the bytes shorter than the row
-    assert lib.ifx_set_option(b"gemm_variant", 21) == 0 and lib.ifx_set_option(b"gemm_variant", 22) != 0
+    assert lib.ifx_set_option(b"gemm_variant", 25) == 0 and lib.ifx_set_option(b"gemm_variant", 26) != 0
     assert lib.ifx_set_option(b"gemm_variant", 0) == 0
+    assert lib.ifx_set_option(b"gemm_small_split", 1) == 0 and lib.ifx_set_option(b"gemm_small_split", 2) != 0
+    assert lib.ifx_set_option(b"gemm_small_split", 0) == 0
     assert lib.ifx_set_option(b"attn_variant", 8) != 0 and lib.ifx_set_option(b"no_such_option", 1) != 0
     kv = _hip.KvView(8, 8, None, 1, 100, 12, 64)
     assert lib.ifx_attn_fwd_paged(C.c_void_p(8), C.c_void_p(8), None, C.byref(kv), 4, 12, 0, 10, 0.0, None) == -1

@@ -490,6 +490,12 @@ def test_gemm_ping_pong_split_k_is_deterministic_and_row_invariant(ops):
     from inferix_amd import _hip
     g = torch.Generator().manual_seed(78)
     lib = _hip.load()
+    ops.set_option("gemm_small_split", 0)            # the default; a sequence-parallel attach in this process may have turned it on
+    # small launches as well (round-2 verdict: the text-embedding linear, 1536 x 4096, split at one 512-token prompt and not at two)
+    for M, N, K in ((512, 1536, 4096), (585, 1536, 8960), (585, 1536, 1536), (300, 4608, 1536)):
+        x, w, b = gpu(rnd(g, 2 * M + 2048, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))
+        one, more = ops.linear(x[:M], w, b), ops.linear(x, w, b)
+        assert torch.equal(one, more[:M]), f"{M} x {N} x {K}: a row's bits changed with the number of rows in the launch"
     for (N, K, kw_name) in ((1536, 8960, "gate"), (4608, 1536, "bias")):
         M = 4680
         x, w, b = gpu(rnd(g, 2 * M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))

@@ -197,6 +197,32 @@ def test_attention_registry_contract():
         fn(q, k, v, causal=True)
 
 
+def test_attention_varlen_arguments():
+    """The seam's `q_lens` / `k_lens` (flash_attention.py:42-150, round-2 verdict missing #3): sample b attends its first k_lens[b]
+    keys — equal to dense attention over the truncated keys, for a batch whose samples have different lengths; a sample without keys
+    gives zeros as flash-attn's varlen kernels do; `q_lens` other than Lq is refused (the reference's unflatten raises there)."""
+    from inferix_amd.attention import attention
+    g = torch.Generator().manual_seed(3)
+    B, Lq, Lk, H, D = 3, 70, 200, 4, 128
+    q = torch.randn(B, Lq, H, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, Lk, H, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, Lk, H, D, generator=g).to(torch.bfloat16)
+    k_lens = torch.tensor([200, 37, 0])
+    out = attention(q.cuda(), k.cuda(), v.cuda(), k_lens=k_lens, q_lens=torch.tensor([Lq] * B))
+    assert out.shape == q.shape and out.dtype == torch.bfloat16
+    for b, n in enumerate(k_lens.tolist()):
+        if n == 0:
+            assert not out[b].any()
+            continue
+        ref = O.attention_with_lse(q[b:b + 1], k[b:b + 1, :n], v[b:b + 1, :n])[0]
+        assert (out[b:b + 1].cpu().double() - ref).abs().max() < 2e-2, b
+        assert torch.equal(out[b:b + 1], attention(q[b:b + 1].cuda(), k[b:b + 1, :n].cuda(), v[b:b + 1, :n].cuda()))
+    with pytest.raises(ValueError):
+        attention(q.cuda(), k.cuda(), v.cuda(), q_lens=torch.tensor([Lq, 5, Lq]))
+    with pytest.raises(ValueError):
+        attention(q.cuda(), k.cuda(), v.cuda(), k_lens=torch.tensor([1, 2]))
+
+
 def test_causvid_rollover_vs_reference_golden():
     """CausVid (BASELINE config 3 mechanics): explicit slot addressing, dropped last step, start_latents prefill and
     the per-segment request swap, against latents/caches generated by the reference's own CausVid pipeline."""
