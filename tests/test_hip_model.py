@@ -78,7 +78,7 @@ def _pipeline(cfg, W, steps, shift, **model_kw):
     return m, gen, args
 
 
-def _run_rollout(name, cfg, paging=None, tol_rel=1e-2):
+def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4):
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     from inferix_amd.pipeline import CausalInferencePipeline
@@ -118,9 +118,15 @@ def _run_rollout(name, cfg, paging=None, tol_rel=1e-2):
     torch.cuda.synchronize()
     # (1) KV index state: bit-exact against the reference trace
     assert trace == [tuple(r) for r in fx["trace"].tolist()], "integer KV index trace differs from the reference"
-    # (2) latents: chained bf16 forwards (15 for the tiny rollout) -> stated tolerance rel-L2
-    r = rel_l2(out.cpu(), fx["out"])
-    assert r < tol_rel, f"{name}: rollout rel-L2 {r:.3e}"
+    # (2) latents: chained bf16 forwards (15 for the tiny rollout).  Yardstick = the SAME rollout with exact (fp64) attention, generated
+    # next to the reference's in oracle/gen_golden.py: the reference's bf16-SDPA result is `floor` away from it, and the HIP rollout has
+    # to be as close to the exact one — and to the reference — as floor x 1.25 (+ eps), the rule of the block tests (round-2 verdict:
+    # no fixed 1e-2).  A 1.5x regression of either distance fails.
+    floor = rel_l2(fx["out"], fx["out_exact"])
+    r_ref, r_exact = rel_l2(out.cpu(), fx["out"]), rel_l2(out.cpu(), fx["out_exact"])
+    print(f"{name}: floor (reference vs exact attention) {floor:.3e}; HIP vs exact {r_exact:.3e}; HIP vs reference {r_ref:.3e}")
+    assert r_exact <= slack * floor + eps, f"{name}: HIP vs exact-attention rollout {r_exact:.3e} > {slack} x floor {floor:.3e} + {eps}"
+    assert r_ref <= slack * floor + eps, f"{name}: HIP vs reference rollout {r_ref:.3e} > {slack} x floor {floor:.3e} + {eps}"
     # (3) cache contents (logical view through the page table)
     le = int(fx["trace"][-1, 2])
     raw = kvm.get_raw(reqs[0], "layer_0")
@@ -130,8 +136,13 @@ def _run_rollout(name, cfg, paging=None, tol_rel=1e-2):
         t = torch.arange(le)
         slot = (pt.host[t // pt.page_size].long() * pt.page_size + t % pt.page_size).cuda()
         k_log, v_log = k_log[slot], v_log[slot]
-    assert rel_l2(k_log[:le].cpu(), fx["cache_k_layer0"]) < tol_rel
-    assert rel_l2(v_log[:le].cpu(), fx["cache_v_layer0"]) < tol_rel
+    # layer 0's cache rows are projections of the clean-context latents: their own floor (reference vs exact-attention rollout) is a
+    # multiple of the latents'; same rule, against both
+    for nm, got in (("K", k_log[:le].cpu()), ("V", v_log[:le].cpu())):
+        ref_c, ex_c = fx[f"cache_{nm.lower()}_layer0"], fx[f"cache_{nm.lower()}_layer0_exact"]
+        fl, r1, r2 = rel_l2(ref_c, ex_c), rel_l2(got, ref_c), rel_l2(got, ex_c)
+        print(f"{name}: layer-0 cache {nm} after the rollout: floor {fl:.3e}; HIP vs exact {r2:.3e}; HIP vs reference {r1:.3e}")
+        assert r1 <= slack * fl + eps and r2 <= slack * fl + eps, (nm, fl, r1, r2)
     return out, fx
 
 

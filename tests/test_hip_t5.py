@@ -59,6 +59,9 @@ def test_t5_gated_gelu_is_the_reference_op_chain(ops):
     assert_bf16_parity(got.cpu(), ref, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what="gated gelu")
 
 
+T5_MINE, T5_REF = 9.974e-2, 2.201e-2       # rel-L2 of the tiny golden encoder measured on MI355X in round 3 (gpurun_out/r3_par.log): HIP vs fp32, HIP vs reference
+
+
 @pytest.fixture(scope="module")
 def tiny():
     g = golden("t5_encoder.npz")
@@ -84,7 +87,11 @@ def test_encoder_matches_reference_golden(tiny):
     exact = T.text_encoder_forward(cfg, W32, g["ids"], g["mask"])
     floor, mine, r = rel_l2(ref, exact), rel_l2(got, exact), rel_l2(got, ref)
     print(f"t5: bf16 noise floor (reference vs fp32) {floor:.3e}; HIP vs fp32 {mine:.3e}; HIP vs reference {r:.3e}")
-    assert mine <= 1.25 * floor and r <= 2.0 * floor
+    # `floor` is large here (0.099: every bf16 activation rounding of a random-weight encoder shows up against the fp32 evaluation) and
+    # the HIP encoder sits AT it (0.0997) — but only 0.022 from the reference, whose roundings it mostly shares.  floor x 2 for that
+    # second distance would let a 5x regression through (round-2 verdict), so both distances are also held to 1.5 x what this build
+    # measured on MI355X in round 3 (T5_MINE, T5_REF above).
+    assert mine <= min(1.25 * floor, 1.5 * T5_MINE) and r <= min(2.0 * floor, 1.5 * T5_REF), (floor, mine, r)
 
 
 def test_encoder_is_deterministic_and_batch_invariant(tiny):
