@@ -512,7 +512,7 @@ def main():
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     model, gen, pipe = build_pipeline(device, pc, a.layers or None)
-    exchange_used, rccl_ranks = None, None
+    exchange_used, rccl_ranks, sp_preflight = None, None, None
     if world > 1:
         from inferix_amd.sequence_parallel import PeerStoreExchange
         # a real collective first: the rank count the line reports is what an all-gather over the group saw
@@ -538,8 +538,14 @@ def main():
                 peer = None
             if peer is None and a.sp_exchange == "peer":
                 raise SystemExit("--sp-exchange peer: the peer-store self-test failed")
-        exchange_used = "peer_store" if peer is not None else "allgather"
         attach_sequence_parallel(model, dist.group.WORLD, peer=peer, kv_first={'auto': None, 'fused': False, 'kv-first': True}[a.sp_qkv])
+        # first contact with RCCL / xGMI (round-2 verdict): one layer's exchange through BOTH paths into scratch caches, compared bit
+        # for bit on every rank and across ranks; a peer-store mismatch drops that path everywhere (fails closed to the all-gather),
+        # an inconsistent all-gather aborts the run.  The line reports the per-exchange microseconds it measured.
+        sp_preflight = model.cp.preflight(model, LATENT[1] // 2, LATENT[2] // 2, frames=BLOCK)
+        if a.sp_exchange == "peer" and model.cp.peer is None and peer is not None:
+            raise SystemExit(f"--sp-exchange peer: the preflight comparison failed: {sp_preflight}")
+        exchange_used = "peer_store" if model.cp.peer is not None else "allgather"
     elif a.emulate_sp > 1:
         from inferix_amd.sequence_parallel import LoopbackExchange, PeerStoreExchange, attach_sequence_parallel
         peer = PeerStoreExchange(emulate_world=a.emulate_sp) if a.sp_exchange == "peer" else None
@@ -656,7 +662,7 @@ def main():
                        "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
                        "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
                        "layers": model.num_layers},
-            "rccl_ranks": rccl_ranks, "sp_exchange": exchange_used,
+            "rccl_ranks": rccl_ranks, "sp_exchange": exchange_used, "sp_preflight": sp_preflight,
             "ms_per_denoise_step": round(sum(denoise_ms) / len(denoise_ms), 3),
             "ms_per_forward_by_block": per_block_ms,
             "generator_forwards_timed": forwards,

@@ -463,6 +463,96 @@ class HipSequenceParallel:
             self.peer.check()
         return out
 
+    def preflight(self, model, height: int, width: int, frames: int = 3, reps: int = 3) -> dict:
+        """First contact with the interconnect, before anything is timed (collective: every rank calls it).  ONE layer's exchange of a
+        synthetic block — rank-specific K/V rows of `frames` frames of `height x width` tokens — goes through the collective path
+        (stage, all-gather, scatter) into one scratch cache and, when a peer-store exchange is attached, through the peer stores
+        into a second one, `reps` times each, with a consumer (a device copy) enqueued right behind on the same stream.  Checked:
+        every slot of a cache was written (K rows are RMS-normalised: never all-zero), the two caches of a rank are bit-identical,
+        and the caches of all ranks are bit-identical (crc32 over the group).  FAILS CLOSED: a peer-store mismatch drops that path on
+        every rank (the all-gather is used); an inconsistent all-gather raises on every rank.  Returns what the bench line reports:
+        ranks seen, per-exchange microseconds of each path, the verdicts."""
+        import zlib
+        from . import hip_ops as ops
+        P, rank = self.ex.world, self.ex.rank
+        H, hd, d = model.num_heads, model.head_dim, model.dim
+        fs = height * width
+        if fs % P:
+            raise ValueError(f"a frame's {fs} tokens do not divide over {P} ranks")
+        hw_local, dev = fs // P, torch.device("cuda", torch.cuda.current_device())
+        n_local, N = frames * hw_local, frames * fs
+        g = torch.Generator(device=dev).manual_seed(4321 + rank)
+        kv_rows = torch.randn(n_local, 2 * d, generator=g, device=dev).to(torch.bfloat16)
+        wk = torch.ones(d, dtype=torch.bfloat16, device=dev)
+        rope = ops.RopeGridSpec(model.freqs, 0, height, width, rank * hw_local, hw_local)
+        report = {"ranks": P, "frames": frames, "rows_per_rank": n_local}
+
+        def gathered_equal(value) -> bool:
+            seen = [None] * P
+            if self.ex.group is not None or dist.is_initialized():
+                dist.all_gather_object(seen, value, group=self.ex.group)
+            else:
+                seen = [value] * P
+            return all(v == seen[0] for v in seen)
+
+        def run(path: str):
+            kc = torch.zeros(N, H, hd, dtype=torch.bfloat16, device=dev)
+            vc = torch.zeros_like(kc)
+            view = ops.KvCacheView(kc, vc)
+            us, snap = [], None
+            for r in range(reps):
+                kc.zero_(), vc.zero_()
+                if dist.is_initialized():
+                    dist.barrier(group=self.ex.group)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if path == "peer":
+                    ep = self.peer.push(PeerStoreExchange.MAX_LAYERS - 2, kv_rows, wk, model.eps, rope, view, 0, fs, d,
+                                        ("__preflight__", "kv", 0))
+                    self.peer.wait_done(PeerStoreExchange.MAX_LAYERS - 2, ep)
+                else:
+                    stage = torch.empty(2, n_local, H, hd, dtype=torch.bfloat16, device=dev)
+                    gathered = torch.empty(P, 2, n_local, H, hd, dtype=torch.bfloat16, device=dev)
+                    sview = ops.KvCacheView(stage[0], stage[1])
+                    ops.rmsnorm_rope_kv_push(kv_rows, wk, model.eps, rope, [stage[0].data_ptr()], [stage[1].data_ptr()], sview, 0,
+                                             hw_local, hw_local, 0, d)
+                    self.ex.all_gather_rows(stage.view(2 * n_local, H * hd), gathered.view(P * 2 * n_local, H * hd))
+                    ops.kv_scatter_shards(gathered, P, frames, hw_local, fs, 0, view)
+                snap = (kc.clone(), vc.clone())          # the consumer, stream-ordered behind the exchange
+                e1.record()
+                torch.cuda.synchronize()
+                us.append(e0.elapsed_time(e1) * 1e3)
+            k, v = snap
+            filled = bool((k.view(N, -1).float().abs().amax(1) > 0).all().item())
+            crc = zlib.crc32(k.cpu().view(torch.int16).numpy().tobytes()) ^ zlib.crc32(v.cpu().view(torch.int16).numpy().tobytes())
+            return snap, sorted(us)[len(us) // 2], filled, crc
+
+        (ag_k, ag_v), ag_us, ag_filled, ag_crc = run("allgather")
+        report["allgather_us"] = round(ag_us, 1)
+        report["allgather_ok"] = gathered_equal((ag_filled, ag_crc)) and ag_filled
+        if not gathered_equal(report["allgather_ok"]) or not report["allgather_ok"]:
+            raise RuntimeError(f"sequence-parallel preflight: the all-gather exchange left different caches on different ranks "
+                               f"(rank {rank}: filled={ag_filled}, crc={ag_crc:#x})")
+        if self.peer is not None and not self.peer.emulated:
+            ok = True
+            try:
+                (pk, pv), p_us, p_filled, p_crc = run("peer")
+                self.peer.check()
+                ok = p_filled and torch.equal(pk, ag_k) and torch.equal(pv, ag_v)
+                report["peer_store_us"] = round(p_us, 1)
+            except RuntimeError as exc:                  # a timed-out wait raises on every rank together (PeerStoreExchange.check)
+                ok = False
+                report["peer_store_error"] = str(exc)[:200]
+            ok = gathered_equal(bool(ok)) and ok
+            report["peer_store_ok"] = bool(ok)
+            if not ok:                                   # every rank sees the same votes: all of them drop the path
+                self.peer.forget("__preflight__")
+                self.peer, self.kv_first = None, True
+            else:
+                self.peer.forget("__preflight__")
+        return report
+
 
 def attach_sequence_parallel(model, group=None, overlap: bool = True,
                              exchange: Optional[SequenceParallelExchange] = None, peer: Optional[PeerStoreExchange] = None,

@@ -52,7 +52,13 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather"):
         if exchange == "peer":
             from inferix_amd.sequence_parallel import PeerStoreExchange
             peer = PeerStoreExchange(timeout_ms=10000)
-        attach_sequence_parallel(m, overlap=overlap, peer=peer)
+        sp = attach_sequence_parallel(m, overlap=overlap, peer=peer)
+        # the bench's preflight (first contact with the interconnect): both exchanges into scratch caches, compared bit for bit on
+        # every rank and across ranks, before the model's own caches see either
+        pf = sp.preflight(m, cfg.latent_h // cfg.patch_size[1], cfg.latent_w // cfg.patch_size[2], frames=3)
+        assert pf["allgather_ok"] and pf["allgather_us"] > 0 and pf["ranks"] == world, pf
+        if exchange == "peer":
+            assert pf.get("peer_store_ok") is True and sp.peer is not None, pf
         gen = HipWanDiffusionWrapper(model=m, timestep_shift=float(fx["shift"]), parallel_config=pc)
         args = SimpleNamespace(denoising_step_list=fx["steps"].tolist(), warp_denoising_step=True,
                                num_frame_per_block=3, independent_first_frame=False, context_noise=0,
