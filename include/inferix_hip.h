@@ -484,6 +484,10 @@ typedef struct {
   float q_scale;                              /* q (self-attention queries only) is multiplied by this in fp32 before its one rounding to bf16;
                                                  0 = 1.  softmax_scale * log2(e) here + attention scale = ln 2 = the same attention on the
                                                  exponent fast path (see ifx_rope_grid.q_scale) */
+  int32_t rope_half;                          /* rotary pairs per head: rope rows are [2 * rope_half] fp32 = (sin | cos), channel e < rope_half
+                                                 pairs with e + rope_half and the channels behind 2 * rope_half pass through.  0 = 64 (the whole
+                                                 head).  MAGI's table covers 96 of the 128 head channels (3 axes x head_dim / 8 bands,
+                                                 dit_module.py:673-720): rope_half = 48.  Multiple of 8. */
 } ifx_magi_head_prep_desc;
 int ifx_magi_head_prep(const ifx_magi_head_prep_desc* desc, void* stream);
 

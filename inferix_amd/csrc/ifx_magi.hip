@@ -25,7 +25,8 @@ struct HeadPrepArgs {
   int ld_in, rows, n_heads;      // n_heads 128-wide head slots per row
   int layout;                    // 0: [HQ q | HQ qx | HK k | HK v]      1: HK x (kx | v) interleaved (linear_kv_xattn output)
   int hq, hk;
-  const float* rope;             // [rows, 128] fp32 = (sin[64] | cos[64]) per token (rotary_pos_emb, dit_module.py:1097)
+  const float* rope;             // [rows, 2 * rope_half] fp32 = (sin | cos) per token (rotary_pos_emb, dit_module.py:1097)
+  int rope_half;                 // rotary pairs per head: channel e < rope_half pairs with e + rope_half, channels >= 2 rope_half pass
   const float* qn_w;             // fp32 [128] q_layernorm / k_layernorm (high-precision modules, dit_model.py:620-637)
   const float* qn_b;
   const float* kn_w;
@@ -119,18 +120,22 @@ __global__ __launch_bounds__(256) void magi_head_prep_kernel(HeadPrepArgs A) {
     const float bi = i < 4 ? b0[i] : b1[i - 4];
     y[i] = (v[i] - mean) * rstd * wi + bi;
   }
-  // rotary partner: channel e pairs with e +- 64 = the lane 8 further inside this 16-lane head group
-  const int j0 = e0 & 63;                                  // index into sin / cos
-  const float* rp = A.rope + (size_t)r * 128;
+  // rotary over the first 2 * rope_half channels of the head (flash-attn's non-interleaved form: x1 = [0, half), x2 = [half, 2 half);
+  // MAGI's table has 3 axes x head_dim / 8 bands = 96 of 128 channels, dit_module.py:673-720): channel e pairs with e +- half = the
+  // lane half / 8 further inside this 16-lane head group; the channels behind the rotary width pass through
+  const int half = A.rope_half;
+  const bool rot = e0 < 2 * half, lo = e0 < half;
+  const int j0 = rot ? (lo ? e0 : e0 - half) : 0;          // index into sin / cos
+  const float* rp = A.rope + (size_t)r * (2 * half);
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(rp + j0), s1 = *reinterpret_cast<const f32x4*>(rp + j0 + 4);
-  const f32x4 c0 = *reinterpret_cast<const f32x4*>(rp + 64 + j0), c1 = *reinterpret_cast<const f32x4*>(rp + 64 + j0 + 4);
-  const bool lo = e0 < 64;
+  const f32x4 c0 = *reinterpret_cast<const f32x4*>(rp + half + j0), c1 = *reinterpret_cast<const f32x4*>(rp + half + j0 + 4);
+  const int partner = rot ? lane + (lo ? (half >> 3) : -(half >> 3)) : lane;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float p = __shfl_xor(y[i], 8, 64);
+    const float p = __shfl(y[i], partner, 64);
     const float sn = i < 4 ? s0[i] : s1[i - 4], cs = i < 4 ? c0[i] : c1[i - 4];
     // out1 = x1 * cos - x2 * sin ; out2 = x1 * sin + x2 * cos   (products rounded separately, as the elementwise torch ops do)
-    const float out = lo ? __fmul_rn(y[i], cs) - __fmul_rn(p, sn) : __fmul_rn(p, sn) + __fmul_rn(y[i], cs);
+    const float out = !rot ? y[i] : (lo ? __fmul_rn(y[i], cs) - __fmul_rn(p, sn) : __fmul_rn(p, sn) + __fmul_rn(y[i], cs));
     o[i] = f2bf(type == HT_Q ? out * A.q_scale : out);
   }
   if (type == HT_Q) *reinterpret_cast<u16x8*>(A.q_out + (size_t)r * A.ld_q + hidx * 128 + e0) = o;
@@ -344,6 +349,8 @@ extern "C" int ifx_magi_head_prep(const ifx_magi_head_prep_desc* d, void* stream
               "ifx_magi_head_prep: k/v destination");
   IFX_REQUIRE(d->split >= 0 && d->row0 >= 0 && d->row1 >= 0, "ifx_magi_head_prep: negative destination rows");
   a.rope = d->rope;
+  a.rope_half = d->rope_half > 0 ? d->rope_half : 64;
+  IFX_REQUIRE(a.rope_half % 8 == 0 && a.rope_half <= 64, "ifx_magi_head_prep: rope_half (%d) must be a multiple of 8, at most 64", a.rope_half);
   a.qn_w = d->qn_w, a.qn_b = d->qn_b, a.kn_w = d->kn_w, a.kn_b = d->kn_b;
   a.xn_w = d->xn_w, a.xn_b = d->xn_b;
   a.eps = d->eps;

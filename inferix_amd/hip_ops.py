@@ -680,8 +680,10 @@ def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: 
     d.q_heads, d.kv_heads, d.head_dim = q_heads, kv_heads, 128
     d.eps, d.layernorm_1p = float(eps), 1 if layernorm_1p else 0
     if layout == 0:
-        assert rope is not None and rope.is_contiguous() and tuple(rope.shape) == (rows, 128)
+        assert rope is not None and rope.is_contiguous() and rope.dim() == 2 and rope.shape[0] == rows
+        assert rope.shape[1] % 16 == 0 and rope.shape[1] <= 128, "rope rows are (sin | cos) of at most 64 pairs, a multiple of 8 each"
         d.rope = _dev(rope, "rope", F32)
+        d.rope_half = rope.shape[1] // 2            # partial rotary: MAGI's table covers 96 of the 128 head channels
         d.qn_w, d.qn_b = _dev(qn[0], "q_layernorm.weight", F32), _dev(qn[1], "q_layernorm.bias", F32)
         d.kn_w, d.kn_b = _dev(kn[0], "k_layernorm.weight", F32), _dev(kn[1], "k_layernorm.bias", F32)
         d.q_out, d.ld_q = _dev(q_out, "q_out"), q_out.stride(0)

@@ -1,0 +1,191 @@
+"""MAGI-1 `VideoDiTModel` on MI355X: one denoise forward of the whole model (BASELINE config 5 as a MODEL step, not a layer stack).
+
+Mirrors `inferix/models/magi/dit/dit_model.py` of the reference:
+  forward_pre_process / get_embedding_and_meta :111-330   patch embedding, rope table, timestep / caption embedders, condition and
+                                                          condition map, packed cross- / core-attention ranges, cp_pre_process
+  forward                                      :353-398   the layer stack (HipMagiTransformerBlock: every heavy op a HIP kernel)
+  TransformerBlock.forward tail                dit_module.py:1386-1388   final LayerNorm on the fp32 hidden states
+  forward_post_process / unpatchify            :97-107,332-351   FinalLinear, cp_post_process, (T H W) N (pT pH pW C) -> N C T H W
+
+What runs where.  The 34 layers are >99.9 % of a forward's arithmetic and go through inferix_amd.magi.dit (HIP GEMMs, attention,
+norms).  The embedders, the rope table, the final LayerNorm and the final linear are fp32 modules upstream (`_high_precision_promoter`,
+:620-637; evaluated under `torch.autocast("cuda", dtype=torch.float32)`): here they are a handful of fp32 torch calls on the device —
+glue by the contract's definition (a 64-wide patchify GEMM, two-layer MLPs on one row per denoising range, an 800-row caption
+projection, a 3072 -> 64 head), with the same rounding points as the reference: the sinusoid is rounded to bf16 before the fp32
+timestep MLP (`t_freq.to(params_dtype)`), x / condition / y_xattn_flat are rounded to bf16 behind the embedders.
+
+Parity: tests/test_hip_magi_model.py against tests/golden/magi_model_tiny.npz (the reference's own VideoDiTModel.forward run by
+oracle/gen_golden_magi_model.py; the layers follow the reference's CPU path as the layer goldens do).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import context_parallel as cpl
+from .dit import HipMagiTransformerBlock
+from .types import InferenceParams, ModelMetaArgs, PackedCoreAttnParams, PackedCrossAttnParams
+
+BF16 = torch.bfloat16
+
+
+def _cfg(c, name, default):
+    return getattr(c, name, default)
+
+
+class HipVideoDiTModel:
+    """`VideoDiTModel(config)` with `.forward(x, t, y, caption_dropout_mask, xattn_mask, kv_range, inference_params, **kwargs)`.
+    `config` carries `model_config` / `engine_config` (/ `runtime_config`) as the reference's MagiConfig does."""
+
+    def __init__(self, config, device="cuda"):
+        self.model_config, self.engine_config = config.model_config, config.engine_config
+        self.runtime_config = getattr(config, "runtime_config", None)
+        mc = self.model_config
+        self.device = torch.device(device)
+        self.patch_size, self.t_patch_size = _cfg(mc, "patch_size", 2), _cfg(mc, "t_patch_size", 1)
+        self.in_channels, self.out_channels = _cfg(mc, "in_channels", 16), _cfg(mc, "out_channels", 16)
+        self.caption_max_length = _cfg(mc, "caption_max_length", 800)
+        self.x_rescale_factor, self.half_channel_vae = float(_cfg(mc, "x_rescale_factor", 1.0)), bool(_cfg(mc, "half_channel_vae", False))
+        self.frequency_embedding_size = 256
+        self.videodit_blocks = HipMagiTransformerBlock(mc, self.engine_config, device)
+        self.w: Dict[str, torch.Tensor] = {}
+
+    # ---- weights --------------------------------------------------------------------------------------------------------------
+    def load_state_dict(self, W: Dict[str, torch.Tensor]) -> None:
+        """State dict with the reference's names: `x_embedder.weight`, `t_embedder.mlp.{0,2}.*`, `y_embedder.*`, `rope.bands`,
+        `videodit_blocks.layers.{i}.*`, `videodit_blocks.final_layernorm.*`, `final_linear.linear.weight`."""
+        dev = self.device
+        for k in ("x_embedder.weight", "t_embedder.mlp.0.weight", "t_embedder.mlp.0.bias", "t_embedder.mlp.2.weight", "t_embedder.mlp.2.bias",
+                  "y_embedder.null_caption_embedding", "y_embedder.y_proj_xattn.0.weight", "y_embedder.y_proj_xattn.0.bias",
+                  "y_embedder.y_proj_adaln.0.weight", "y_embedder.y_proj_adaln.0.bias", "rope.bands",
+                  "videodit_blocks.final_layernorm.weight", "videodit_blocks.final_layernorm.bias", "final_linear.linear.weight"):
+            if k not in W:
+                raise KeyError(f"HipVideoDiTModel.load_state_dict: missing {k}")
+            self.w[k] = W[k].to(dev, torch.float32).contiguous()          # fp32 modules (_high_precision_promoter)
+        self.videodit_blocks.load_state_dict(W, "videodit_blocks.layers.")
+
+    # ---- pieces of get_embedding_and_meta ---------------------------------------------------------------------------------------
+    def _timestep_embedding(self, t: torch.Tensor) -> torch.Tensor:
+        """TimestepEmbedder.forward (dit_module.py:76-106): cos | sin of t * 1000 * 10000^(-i/half), rounded to the parameter dtype,
+        then Linear -> SiLU -> Linear in fp32."""
+        half = self.frequency_embedding_size // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32, device=t.device) / half)
+        args = t[:, None].float() * freqs[None] * 1000.0
+        tf = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(BF16).float()
+        w = self.w
+        return F.linear(F.silu(F.linear(tf, w["t_embedder.mlp.0.weight"], w["t_embedder.mlp.0.bias"])),
+                        w["t_embedder.mlp.2.weight"], w["t_embedder.mlp.2.bias"])
+
+    def _rope(self, t_total: int, H: int, W: int, rows: int) -> torch.Tensor:
+        """LearnableRotaryEmbeddingCat.get_embed (dit_module.py:602-776, in_pixels=False) for [t_total, H, W] with the reference
+        shape [t_total, H / r, W / r], r = sqrt(H W / 256) (dit_model.py:157-166); the last `rows` rows (sin | cos)."""
+        dev, bands = self.device, self.w["rope.bands"]
+        r = math.sqrt((H * W) / (16 * 16))
+        shape, ref = [t_total, H, W], [t_total, H / r, W / r]
+        axes = [torch.arange(s, dtype=torch.int64, device=dev).to(torch.float32) for s in shape]
+        axes[1] = axes[1] - (H - 1) / 2
+        axes[2] = axes[2] - (W - 1) / 2
+        scaled = [a if f == 1 else a / (f - 1) * (rf - 1) for a, f, rf in zip(axes, shape, ref)]
+        grid = torch.stack(torch.meshgrid(*scaled, indexing="ij"), dim=-1).unsqueeze(-1)
+        pos = grid * bands
+        n = t_total * H * W
+        return torch.cat([pos.sin().reshape(n, -1), pos.cos().reshape(n, -1)], -1)[-rows:].contiguous()
+
+    def forward_pre_process(self, x, t, y, caption_dropout_mask=None, xattn_mask=None, kv_range=None, **kwargs
+                            ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, ModelMetaArgs]:
+        assert kv_range is not None, "Please ensure kv_range is provided"
+        if caption_dropout_mask is None:
+            raise ValueError("caption_dropout_mask is required at inference: the AdaLN branch of the caption embedder reads the learned "
+                             "null caption it selects (dit_module.py:141-160)")
+        assert xattn_mask is not None
+        dev, w = self.device, self.w
+        x = x.to(dev) * self.x_rescale_factor
+        if self.half_channel_vae:
+            assert x.shape[1] == 16
+            x = torch.cat([x, x], dim=1)
+        x, t, y = x.float(), t.to(dev).float(), y.to(dev).float()
+        # Part 1: patch embedding (a Conv3d whose stride equals its kernel)
+        xe = F.conv3d(x, w["x_embedder.weight"], stride=(self.t_patch_size, self.patch_size, self.patch_size))
+        N, _, T, H, Wd = xe.shape
+        range_num, dn = kwargs["range_num"], kwargs["denoising_range_num"]
+        slice_point = kwargs.get("slice_point", 0)
+        frame_in_range = T // dn
+        # Part 2: rope
+        rope = self._rope(T + frame_in_range * slice_point, H, Wd, T * H * Wd)
+        # Part 3: timestep embedding
+        assert t.shape[0] == N and t.shape[1] == dn, f"Invalid t shape {tuple(t.shape)}"
+        te = self._timestep_embedding(t.flatten())
+        if _cfg(self.engine_config, "distill", False):
+            if kwargs["num_steps"] == 12:
+                factor = 4 / kwargs["distill_interval"] * 2
+            else:
+                factor = kwargs["num_steps"] / 4 * 2
+            te = te + self._timestep_embedding(torch.ones_like(t.flatten()) * factor)
+        te = te.reshape(N, dn, -1)
+        # Part 4: caption: cross-attention rows from the caption itself, the AdaLN row from the learned null caption
+        y_xattn = F.silu(F.linear(y, w["y_embedder.y_proj_xattn.0.weight"], w["y_embedder.y_proj_xattn.0.bias"]))
+        null = w["y_embedder.null_caption_embedding"]
+        drop = caption_dropout_mask.to(dev).bool()
+        cap = torch.where(drop[:, None, None], null[None, -1, :], null[None, -2, :])
+        y_adaln = F.linear(cap, w["y_embedder.y_proj_adaln.0.weight"], w["y_embedder.y_proj_adaln.0.bias"]).squeeze(1)
+        mask = xattn_mask.to(dev).squeeze(1).squeeze(1)
+        condition = te + y_adaln.unsqueeze(1)
+        assert condition.shape[0] == N and condition.shape[1] == dn
+        per = (T * H * Wd) // dn
+        condition_map = torch.repeat_interleave(torch.arange(N * dn, device=dev), per).reshape(N, -1).transpose(0, 1).contiguous()
+        y_flat = torch.masked_select(y_xattn.squeeze(1), mask.unsqueeze(-1).bool()).reshape(-1, y_xattn.shape[-1])
+        # Part 5 / 6: packed ranges
+        y_index = mask.reshape(mask.shape[0], -1).sum(-1)
+        clip = H * Wd * frame_in_range
+        cu_q = torch.tensor([0] + [clip] * dn * N, device=dev).cumsum(-1).to(torch.int32)
+        cu_k = torch.cat([y_index.new_zeros(1), y_index]).to(torch.int64).cumsum(-1).to(torch.int32)
+        q_ranges = torch.stack([cu_q[:-1], cu_q[1:]], 1)
+        k_ranges_x = torch.stack([cu_k[:-1], cu_k[1:]], 1)
+        cross = PackedCrossAttnParams(q_ranges=q_ranges, kv_ranges=k_ranges_x, cu_seqlens_q=cu_q, cu_seqlens_kv=cu_k,
+                                      max_seqlen_q=clip, max_seqlen_kv=self.caption_max_length)
+        kv_range = kv_range.to(dev)
+        flat_kv = torch.unique(kv_range, sorted=True)
+        ardf = dict(clip_token_nums=clip, slice_point=slice_point, range_num=range_num, denoising_range_num=dn, q_range=q_ranges,
+                    k_range=kv_range, max_seqlen_q=clip, max_seqlen_k=int((flat_kv[-1] - flat_kv[0]).item()))
+        xs = xe.to(BF16).permute(2, 3, 4, 0, 1).reshape(T * H * Wd, N, -1).contiguous()           # "N C T H W -> (T H W) N C"
+        core = PackedCoreAttnParams(q_range=ardf["q_range"], k_range=ardf["k_range"], np_q_range=ardf["q_range"].cpu().numpy(),
+                                    np_k_range=ardf["k_range"].cpu().numpy(), max_seqlen_q=clip, max_seqlen_k=ardf["max_seqlen_k"])
+        ec = self.engine_config
+        xs, condition_map, rope, pad, sizes, core, cross = cpl.cp_pre_process(
+            _cfg(ec, "cp_size", 1), _cfg(ec, "cp_strategy", "none"), xs, condition_map, rope, None, ardf, core, cross)
+        meta = ModelMetaArgs(H=H, W=Wd, cp_pad_size=pad, cp_split_sizes=sizes, slice_point=slice_point, denoising_range_num=dn,
+                             range_num=range_num, extract_prefix_video_feature=kwargs.get("extract_prefix_video_feature", False),
+                             fwd_extra_1st_chunk=kwargs["fwd_extra_1st_chunk"],
+                             distill_nearly_clean_chunk=kwargs.get("distill_nearly_clean_chunk", False), clip_token_nums=clip,
+                             enable_cuda_graph=False, core_attn_params=core, cross_attn_params=cross)
+        return xs, condition.to(BF16), condition_map, y_flat.to(BF16), rope, meta
+
+    def forward_post_process(self, hidden: torch.Tensor, meta: ModelMetaArgs) -> torch.Tensor:
+        mc, w = self.model_config, self.w
+        gamma = w["videodit_blocks.final_layernorm.weight"]
+        gamma = gamma + 1 if bool(_cfg(mc, "apply_layernorm_1p", False)) else gamma
+        hn = F.layer_norm(hidden.float(), (hidden.shape[-1],), gamma, w["videodit_blocks.final_layernorm.bias"], mc.layernorm_epsilon)
+        o = F.linear(hn, w["final_linear.linear.weight"])                                        # (thw / cp, N, pT pH pW C)
+        ec = self.engine_config
+        o = cpl.cp_post_process(_cfg(ec, "cp_size", 1), _cfg(ec, "cp_strategy", "none"), o, meta)
+        S, N, _ = o.shape
+        pt, p, C = self.t_patch_size, self.patch_size, self.out_channels
+        H, Wd = meta.H, meta.W
+        T = S // (H * Wd)
+        o = o.reshape(T, H, Wd, N, pt, p, p, C).permute(3, 7, 0, 4, 1, 5, 2, 6).reshape(N, C, T * pt, H * p, Wd * p).contiguous()
+        if self.half_channel_vae:
+            assert o.shape[1] == 32
+            o = o[:, :16]
+        return o / self.x_rescale_factor
+
+    @torch.no_grad()
+    def forward(self, x, t, y, caption_dropout_mask=None, xattn_mask=None, kv_range=None,
+                inference_params: Optional[InferenceParams] = None, **kwargs) -> torch.Tensor:
+        xs, condition, condition_map, y_flat, rope, meta = self.forward_pre_process(x, t, y, caption_dropout_mask, xattn_mask, kv_range, **kwargs)
+        hs = self.videodit_blocks(xs.clone(), condition, condition_map, y_flat, rope, inference_params, meta)
+        return self.forward_post_process(hs, meta)
+
+    __call__ = forward

@@ -333,7 +333,7 @@ def _layer_forward_f64(W, cfg, x, condition, condition_map, y, rope, meta, cache
         ro = cos_emb.shape[-1] * 2
         c, s = cos_emb[None, :, None, :], sin_emb[None, :, None, :]
         x1, x2 = t[..., : ro // 2], t[..., ro // 2: ro]
-        return torch.cat([x1 * c - x2 * s, x1 * s + x2 * c], dim=-1)
+        return torch.cat([x1 * c - x2 * s, x1 * s + x2 * c, t[..., ro:]], dim=-1)     # partial rotary: the tail passes through
 
     def att(q, k, v):
         rep = q.shape[1] // k.shape[1]
