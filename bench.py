@@ -364,93 +364,82 @@ def causvid_720p_leg(model, device):
                          "traffic": None, "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / ks["launches"], 4)}}
 
 
-def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34, fp8_quant: bool = True):
-    """BASELINE config 5, ONE rank of 8 emulated on one GPU (INVALID as a multi-GPU number: the all-to-alls are device copies of
-    the bytes the rank would receive, inferix_amd/magi/context_parallel.py `set_cp_emulation`): MAGI-4.5B transformer stack
-    (34 layers, hidden 3072, 24 q-heads / 8 kv-groups, ffn 12288), 720 x 720 -> 12150 tokens per chunk, window of 4 denoising
-    chunks in flight + 1 clean chunk in the cache (`noise2clean_kvrange = [5, 4, 3, 2]`, example/magi/configs/4.5B), so a forward
-    has 48600 query tokens of which this rank projects 6075 and attends all 48600 with 3 q-heads on 1 kv-head.  `fp8_quant`: the
-    named config is `4.5B_distill_quant` (`engine_config.fp8_quant = true`): layers 1 .. 32 run the static-scale FP8 linears."""
+def magi_cp8_emulated_leg(device, cp: int = 8, layers: int = 34, fp8_quant: bool = True, steps=None):
+    """BASELINE config 5 as a MODEL run, ONE rank of 8 emulated on one GPU (INVALID as a multi-GPU number: the all-to-alls are device
+    copies of the bytes the rank would receive, inferix_amd/magi/context_parallel.py `set_cp_emulation`).  `HipVideoDiTModel` with
+    MAGI-4.5B's dimensions (34 layers, hidden 3072, 24 q-heads / 8 kv-groups, ffn 12288, caption 800 x 4096; patch embedding, timestep
+    and caption embedders, rope table, final norm + linear included) driven by `ChunkSchedule.run`, the reference's SampleTransport
+    loop for `example/magi/configs/4.5B/4.5B_distill_quant_config.json`: 96 frames at 720 x 720 -> 4 chunks of 12150 tokens, 64
+    steps in a window of 4 -> 112 denoise forwards of 1 .. 4 chunks (+ the clean chunk at the first step of stages 4 .. 6, + the
+    nearly-clean re-forward), `noise2clean_kvrange = [5, 4, 3, 2]`, `cfg_number = 1`.  `fp8_quant`: layers 1 .. 32 run the
+    static-scale FP8 linears.  `steps`: a subset of the schedule (debug)."""
     from inferix_amd import hip_ops as ops
     from inferix_amd.magi import context_parallel as cpl
-    from inferix_amd.magi.dit import HipMagiTransformerLayer, synthetic_layer_state_dict
-    from inferix_amd.magi.types import InferenceParams, ModelMetaArgs, PackedCoreAttnParams, PackedCrossAttnParams
+    from inferix_amd.magi.model import HipVideoDiTModel
+    from inferix_amd.magi.schedule import ChunkSchedule
+    from inferix_amd.magi.types import InferenceParams
     mc = SimpleNamespace(num_layers=layers, hidden_size=3072, ffn_hidden_size=12288, num_attention_heads=24, num_query_groups=8,
                          kv_channels=128, layernorm_epsilon=1e-6, apply_layernorm_1p=True, gated_linear_unit=False,
-                         cond_hidden_ratio=0.25, xattn_cond_hidden_ratio=1.0, cond_gating_ratio=1.0)
-    ec = SimpleNamespace(cp_size=cp, cp_strategy="cp_ulysses", fp8_quant=fp8_quant, kv_offload=False, ulysses_overlap_degree=1)
+                         cond_hidden_ratio=0.25, xattn_cond_hidden_ratio=1.0, cond_gating_ratio=1.0, patch_size=2, t_patch_size=1,
+                         in_channels=16, out_channels=16, caption_channels=4096, caption_max_length=800, x_rescale_factor=1,
+                         half_channel_vae=False)
+    ec = SimpleNamespace(cp_size=cp, cp_strategy="cp_ulysses", fp8_quant=fp8_quant, kv_offload=False, ulysses_overlap_degree=1,
+                         distill=True, shortcut_mode="8,16,16", distill_nearly_clean_chunk_threshold=0.3)
+    rc = SimpleNamespace(cfg_number=1, noise2clean_kvrange=[5, 4, 3, 2], clean_chunk_kvrange=1, clean_t=0.9999, num_steps=64,
+                         window_size=4, chunk_width=6)
+    chunk_num, cw, lat, caption = 4, 6, 90, 100
+    clip = cw * (lat // 2) ** 2
     cpl.set_cp_emulation(cp, 0)
     try:
-        stack = []
-        for li in range(layers):
-            layer = HipMagiTransformerLayer(mc, ec, li, device)
-            layer.load_state_dict(synthetic_layer_state_dict(mc, seed=li, device=device, fp8=fp8_quant and 0 < li < layers - 1))
-            stack.append(layer)
-        clip, ranges, caption = 12150, 4, 100
-        s_all = ranges * clip
-        sizes = [s_all // cp + (1 if r < s_all % cp else 0) for r in range(cp)]
-        s_loc = sizes[0]
+        model = HipVideoDiTModel(SimpleNamespace(model_config=mc, engine_config=ec, runtime_config=rc), device)
+        model.load_synthetic(0)
+        sch = ChunkSchedule(rc.num_steps, rc.window_size, chunk_num, cw)
         g = torch.Generator(device=device).manual_seed(0)
-        x = torch.randn(s_loc, 1, 3072, generator=g, device=device).to(torch.bfloat16)
-        cond = torch.randn(1, ranges, 768, generator=g, device=device).to(torch.bfloat16)
-        cmap = (torch.arange(s_loc, device=device, dtype=torch.int32) * ranges // s_loc).reshape(s_loc, 1)
-        y = torch.randn(ranges * caption, 3072, generator=g, device=device).to(torch.bfloat16)
-        ang = torch.rand(s_loc, 64, generator=g, device=device) * 6.0
-        rope = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
-        qr = torch.tensor([[i * clip, (i + 1) * clip] for i in range(ranges)], dtype=torch.int32)
-        # keys = [1 clean chunk | 4 new]: the named config's schedule for four chunks at steps 48 / 32 / 16 / 0 of 64
-        from inferix_amd.magi.kv_ranges import generate_kvrange_for_denoising_video
-        kr = generate_kvrange_for_denoising_video(clip, 1, ranges, [48, 32, 16, 0], 64, [5, 4, 3, 2], 1)
-        core = PackedCoreAttnParams(q_range=qr, k_range=kr, np_q_range=qr.numpy(), np_k_range=kr.numpy(), max_seqlen_q=clip,
-                                    max_seqlen_k=(ranges + 1) * clip)
-        # this rank's tokens all belong to denoising range 0 (6075 < 12150): one cross-attention segment
-        cross = PackedCrossAttnParams(q_ranges=torch.tensor([[0, s_loc]], dtype=torch.int32),
-                                      kv_ranges=torch.tensor([[0, caption]], dtype=torch.int32), max_seqlen_q=s_loc, max_seqlen_kv=caption)
-        meta = ModelMetaArgs(H=45, W=45, cp_pad_size=0, cp_split_sizes=sizes, slice_point=1, denoising_range_num=ranges,
-                             range_num=ranges + 1, extract_prefix_video_feature=False, fwd_extra_1st_chunk=False,
-                             distill_nearly_clean_chunk=False, clip_token_nums=clip, enable_cuda_graph=False, core_attn_params=core,
-                             cross_attn_params=cross)
-        ip = InferenceParams(1, 8 * clip, device=device)
-        ip.update_kv_cache = False
-        for layer in stack:                          # the clean chunk's keys / values: any finite contents will do for the timing
-            mgr = layer.self_attention.kv_cache_manager
-            mgr.allocate_key_value_memory(ip, ip.max_sequence_length, 1, torch.bfloat16, scratch_rows=s_all)
-            ip.kv_cache_manager.get_raw(ip.kv_cache_request, mgr.layer_name).normal_()
-
-        def forward():
-            h = x
-            for layer in stack:
-                h = layer(h, cond, cmap, y, rope, ip, meta)
-            return h
-        out = forward()
+        x0 = torch.randn(1, 16, chunk_num * cw, lat, lat, generator=g, device=device)
+        x = torch.cat([x0, x0], 0)
+        y = torch.randn(2, chunk_num, 800, 4096, generator=g, device=device)
+        masks = torch.zeros(2, chunk_num, 800, device=device)
+        masks[0, :, :caption] = 1                              # a 100-token caption; the null caption row keeps its 2 special tokens
+        masks[1, :, :2] = 1
+        ip = InferenceParams(1, chunk_num * clip, device=device)
+        plans = []
+        sch.run(model, x.clone(), y, masks, ip, steps=[0, 48, 64])                 # warm: 1 chunk, 4 chunks, clean + 3 chunks
         torch.cuda.synchronize()
-        assert torch.isfinite(out.float()).all()
-        t = ops.KernelTimer(names=("attn_magi", "gemm", "gemm_q8"))
+        t = ops.KernelTimer(names=("attn_magi", "gemm", "gemm_q8", "quant_static"))
         ops.set_kernel_timer(t)
         t0 = time.perf_counter()
-        n = 2
-        for _ in range(n):
-            forward()
+        out = sch.run(model, x.clone(), y, masks, ip, steps=steps, on_forward=plans.append)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n * 1e3
+        ms = (time.perf_counter() - t0) * 1e3
         ops.set_kernel_timer(None)
+        assert torch.isfinite(out).all()
         ks = t.summary()
         at, ge = ks["attn_magi"], ks["gemm"]
         g8 = ks.get("gemm_q8", {"ms": 0.0, "flops": 0.0, "launches": 0})
+        qz = ks.get("quant_static", {"ms": 0.0, "launches": 0})
         atf, gtf = at["flops"] / (at["ms"] * 1e-3) / 1e12, ge["flops"] / (ge["ms"] * 1e-3) / 1e12
-        return {"workload": f"config 5 (MAGI-4.5B, 720x720, chunk 12150 tokens, 4 denoising chunks + 1 clean chunk), ONE rank of cp={cp} "
-                            f"emulated on one GPU: {s_loc} local tokens, {cp and 24 // cp} q-heads on 1 kv-head over {s_all} queries x "
-                            f"{2 * clip}..{(ranges + 1) * clip} keys, {layers} layers; all-to-alls replaced by device copies",
-                "INVALID": "emulated rank: no xGMI transfer; not a multi-GPU measurement",
-                "ms_per_denoise_forward_rank": round(ms, 1),
-                "chunk_tokens_per_s_rank_view": round(s_all / ms * 1e3, 1),
-                "attn_ms": round(at["ms"] / n, 1), "gemm_ms": round(ge["ms"] / n, 1),
+        n = len(plans)
+        ranges = sum(p.denoising_range_num for p in plans)
+        full = steps is None
+        del model
+        torch.cuda.empty_cache()
+        return {"workload": f"config 5 (MAGI-4.5B distill{'_quant' if fp8_quant else ''}, 96 frames 720x720 = {chunk_num} chunks x {clip} "
+                            f"tokens, 64 steps, window 4), the reference's chunk schedule through the whole model, ONE rank of cp={cp} "
+                            f"emulated on one GPU ({24 // cp} q-heads on 1 kv-head, 1/{cp} of the tokens through the linears); all-to-alls "
+                            "replaced by device copies",
+                "INVALID": "emulated rank: no xGMI transfer; not a multi-GPU measurement" + ("" if full else "; partial schedule"),
+                "denoise_forwards": n, "chunk_forwards": ranges, "ms_clip_rank": round(ms, 1),
+                "ms_per_denoise_forward_rank": round(ms / n, 2),
+                "latent_frames_per_s_rank_view": round(chunk_num * cw / ms * 1e3, 3) if full else None,
+                "chunk_tokens_per_s_rank_view": round(ranges * clip / ms * 1e3, 1),
+                "attn_ms": round(at["ms"], 1), "gemm_ms": round(ge["ms"], 1),
                 "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (MAGI range attention, 3 q-heads on 1 kv-head)", "bound": "mfma",
                              "achieved": round(atf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(atf / PEAK_BF16_TFLOPS, 4),
-                             "traffic": None, "launches": at["launches"] // n, "avg_launch_ms": round(at["ms"] / at["launches"], 4)},
+                             "traffic": None, "launches": at["launches"], "avg_launch_ms": round(at["ms"] / at["launches"], 4)},
                 "gemm_tflops": round(gtf, 1), "fp8_quant": bool(fp8_quant),
-                "gemm_fp8_ms": round(g8["ms"] / n, 1),
-                "gemm_fp8_tflops": round(g8["flops"] / (g8["ms"] * 1e-3) / 1e12, 1) if g8["ms"] else None}
+                "gemm_fp8_ms": round(g8["ms"], 1),
+                "gemm_fp8_tflops": round(g8["flops"] / (g8["ms"] * 1e-3) / 1e12, 1) if g8["ms"] else None,
+                "quantiser_ms": round(qz["ms"], 1), "quantiser_launches": qz["launches"]}
     finally:
         ops.set_kernel_timer(None)
         cpl.set_cp_emulation(None)
@@ -478,6 +467,9 @@ def main():
     ap.add_argument("--sp-qkv", choices=["auto", "fused", "kv-first"], default="auto",
                     help="N > 1: one fused q/k/v projection before the exchange starts, or the K/V projection first so that the exchange "
                          "runs under the q projection; auto = kv-first in front of the all-gather, fused in front of the peer stores")
+    ap.add_argument("--magi-leg", choices=["fp8", "bf16"], default=None,
+                    help="debug: run ONLY the config 5 leg (MAGI-4.5B model through the chunk schedule, one emulated cp rank) and print it")
+    ap.add_argument("--magi-steps", type=int, default=0, help="debug: with --magi-leg, only the first N steps of each schedule stage")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -491,6 +483,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if a.magi_leg:
+        sub = [st * 16 + i for st in range(7) for i in range(a.magi_steps)] if a.magi_steps else None
+        print(json.dumps(magi_cp8_emulated_leg(device, fp8_quant=a.magi_leg == "fp8", steps=sub)), flush=True)
+        return
     import torch.distributed as dist
     pc = None
     if world > 1:
@@ -703,7 +699,7 @@ def main():
             res["config1_gpu"] = config1_gpu(model, gen, device)
             res["magi_cp8_emulated"] = magi_cp8_emulated_leg(device)                          # the named config: fp8_quant
             bf = magi_cp8_emulated_leg(device, fp8_quant=False)
-            res["magi_cp8_emulated"]["bf16_weights"] = {k: bf[k] for k in ("ms_per_denoise_forward_rank", "attn_ms", "gemm_ms", "gemm_tflops")}
+            res["magi_cp8_emulated"]["bf16_weights"] = {k: bf[k] for k in ("ms_clip_rank", "ms_per_denoise_forward_rank", "attn_ms", "gemm_ms", "gemm_tflops")}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_layers)
             if "config1_gpu" in res:

@@ -731,9 +731,10 @@ def quant_static(x: torch.Tensor, divisor: torch.Tensor, fmt: int, via_bf16: boo
     rows, K, ldx = _rows2d(x, "x")
     q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
     divisor = divisor.reshape(-1)
-    _hip.check(_hip.load().ifx_quant_static(_dev(x, "x"), ldx, _dev(q, "q", torch.uint8), q.stride(0), _dev(divisor, "divisor", F32),
-                                            divisor.numel(), _dev(row_scale, "row_scale", F32) if row_scale is not None else None,
-                                            rows, K, int(fmt), 1 if via_bf16 else 0, _stream()), "ifx_quant_static")
+    with _timed("quant_static", 0.0, 3.0 * rows * K):
+        _hip.check(_hip.load().ifx_quant_static(_dev(x, "x"), ldx, _dev(q, "q", torch.uint8), q.stride(0), _dev(divisor, "divisor", F32),
+                                                divisor.numel(), _dev(row_scale, "row_scale", F32) if row_scale is not None else None,
+                                                rows, K, int(fmt), 1 if via_bf16 else 0, _stream()), "ifx_quant_static")
     return q
 
 

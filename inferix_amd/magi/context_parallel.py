@@ -135,7 +135,14 @@ def gather_from_context_parallel_region(input_: torch.Tensor, cp_split_sizes: Se
     input_ = input_.contiguous()
     tail = tuple(input_.shape[1:])
     out = torch.empty((sum(cp_split_sizes),) + tail, dtype=input_.dtype, device=input_.device)
-    dist.all_gather(list(torch.split(out, list(cp_split_sizes), dim=0)), input_, group=get_cp_group())
+    if _CP_EMULATED is not None:                    # peers' shards := this rank's own rows (a device copy of the gathered bytes)
+        for piece in torch.split(out, list(cp_split_sizes), dim=0):
+            n = min(piece.shape[0], input_.shape[0])
+            piece[:n].copy_(input_[:n])
+            if n < piece.shape[0]:
+                piece[n:].copy_(input_[:piece.shape[0] - n])
+    else:
+        dist.all_gather(list(torch.split(out, list(cp_split_sizes), dim=0)), input_, group=get_cp_group())
     if cp_shuffle_num > 1:
         dn = cp_shuffle_num
         m = divide(cp_split_sizes[0], dn)

@@ -67,6 +67,35 @@ class HipVideoDiTModel:
             self.w[k] = W[k].to(dev, torch.float32).contiguous()          # fp32 modules (_high_precision_promoter)
         self.videodit_blocks.load_state_dict(W, "videodit_blocks.layers.")
 
+    def load_synthetic(self, seed: int = 0, fp8: Optional[bool] = None) -> None:
+        """Random weights of the whole model with the reference's shapes and dtypes, generated on the device layer by layer (no
+        checkpoint exists offline): benchmarks and smoke runs.  `fp8` (default `engine_config.fp8_quant`): layers 1 .. n - 2 carry the
+        static-scale e4m3 linears of an fp8_quant checkpoint (dit_module.py:434-490)."""
+        from .dit import synthetic_layer_state_dict
+        mc, dev = self.model_config, self.device
+        fp8 = bool(_cfg(self.engine_config, "fp8_quant", False)) if fp8 is None else fp8
+        g = torch.Generator(device=dev).manual_seed(seed)
+        h, heads = mc.hidden_size, mc.num_attention_heads
+        cond, xat = int(h * _cfg(mc, "cond_hidden_ratio", 0.25)), int(h * _cfg(mc, "xattn_cond_hidden_ratio", 1.0))
+        cin = self.in_channels * (2 if self.half_channel_vae else 1)
+        cap = _cfg(mc, "caption_channels", 4096)
+        rnd = lambda *shape: torch.randn(*shape, generator=g, device=dev)
+        mat = lambda *shape: rnd(*shape) * math.prod(shape[1:]) ** -0.5
+        n = h // heads // 8
+        bands = 1.0 / (10000.0 ** (torch.arange(0, n, dtype=torch.int64, device=dev).to(torch.float32) / n))
+        self.w = {"x_embedder.weight": mat(h, cin, self.t_patch_size, self.patch_size, self.patch_size),
+                  "t_embedder.mlp.0.weight": mat(cond, self.frequency_embedding_size), "t_embedder.mlp.0.bias": 0.1 * rnd(cond),
+                  "t_embedder.mlp.2.weight": mat(cond, cond), "t_embedder.mlp.2.bias": 0.1 * rnd(cond),
+                  "y_embedder.null_caption_embedding": rnd(self.caption_max_length, cap),
+                  "y_embedder.y_proj_xattn.0.weight": mat(xat, cap), "y_embedder.y_proj_xattn.0.bias": 0.1 * rnd(xat),
+                  "y_embedder.y_proj_adaln.0.weight": mat(cond, cap), "y_embedder.y_proj_adaln.0.bias": 0.1 * rnd(cond),
+                  "rope.bands": bands, "videodit_blocks.final_layernorm.weight": 0.1 * rnd(h),
+                  "videodit_blocks.final_layernorm.bias": 0.1 * rnd(h),
+                  "final_linear.linear.weight": mat(self.patch_size * self.patch_size * self.t_patch_size * self.out_channels, h)}
+        layers = self.videodit_blocks.layers
+        for i, layer in enumerate(layers):
+            layer.load_state_dict(synthetic_layer_state_dict(mc, seed=seed * 1000 + i, device=dev, fp8=fp8 and 0 < i < len(layers) - 1))
+
     # ---- pieces of get_embedding_and_meta ---------------------------------------------------------------------------------------
     def _timestep_embedding(self, t: torch.Tensor) -> torch.Tensor:
         """TimestepEmbedder.forward (dit_module.py:76-106): cos | sin of t * 1000 * 10000^(-i/half), rounded to the parameter dtype,
@@ -189,3 +218,48 @@ class HipVideoDiTModel:
         return self.forward_post_process(hs, meta)
 
     __call__ = forward
+
+    def generate_kv_range_for_uncondition(self, uncond_x: torch.Tensor) -> torch.Tensor:
+        """dit_model.py:91-100: one self-contained key range per batch row of `uncond_x`."""
+        B, _, T, H, W = uncond_x.shape
+        n = (T // self.t_patch_size) * (H // self.patch_size) * (W // self.patch_size)
+        return torch.tensor([[b * n, (b + 1) * n] for b in range(B)], dtype=torch.int32, device=self.device)
+
+    @torch.no_grad()
+    def forward_dispatcher(self, x, timestep, y, mask, kv_range, inference_params, **kwargs) -> torch.Tensor:
+        """dit_model.py:499-596 for `runtime_config.cfg_number == 1` (the distilled checkpoints: one conditional forward, no guidance
+        batch).  x `[2, C, T, H, W]` with equal halves, y / mask hold the conditional rows first.  When the newest finished chunk is
+        nearly clean (`distill_nearly_clean_chunk`) it is forwarded a second time as an extra range that sees only itself, and the two
+        results are blended `prev_chunks_scale : 1 - prev_chunks_scale` (env `prev_chunks_scale`, 0.7)."""
+        import os
+        rc = self.runtime_config
+        if rc is None or getattr(rc, "cfg_number", None) != 1:
+            raise NotImplementedError("HipVideoDiTModel.forward_dispatcher: only runtime_config.cfg_number == 1 (distilled MAGI) is built; "
+                                      "the 3-way guidance batch (cfg_number == 3) is not")
+        assert x.shape[0] == 2
+        x = torch.cat([x[0:1], x[0:1]], dim=0)
+        kwargs = dict(kwargs)
+        kwargs["caption_dropout_mask"] = torch.tensor([False], dtype=torch.bool, device=x.device)
+        inference_params.update_kv_cache = True
+        half = y.shape[0] // 2
+        cw = kwargs["chunk_width"]
+        if kwargs.get("distill_nearly_clean_chunk", False):
+            scale = float(os.getenv("prev_chunks_scale", 0.7))
+            s0 = 1 if kwargs["fwd_extra_1st_chunk"] else 0
+            width = x.shape[2]
+            new_x = x[0:1, :, s0 * cw:(s0 + 1) * cw]
+            new_kv = self.generate_kv_range_for_uncondition(new_x) + kv_range.max()
+            kwargs["denoising_range_num"] += 1
+            out = self.forward(torch.cat([x[0:1], new_x], dim=2), torch.cat([timestep[0:1], timestep[0:1, s0:s0 + 1]], dim=1),
+                               torch.cat([y[0:half], y[s0:s0 + 1]], dim=0), xattn_mask=torch.cat([mask[0:half], mask[s0:s0 + 1]], dim=0),
+                               kv_range=torch.cat([kv_range.to(new_kv.device), new_kv], dim=0), inference_params=inference_params, **kwargs)
+            out[:, :, s0 * cw:(s0 + 1) * cw] = out[:, :, s0 * cw:(s0 + 1) * cw] * scale + out[:, :, width:] * (1 - scale)
+            out = out[:, :, :width]
+        else:
+            out = self.forward(x[0:1], timestep[0:1], y[0:half], xattn_mask=mask[0:half], kv_range=kv_range,
+                               inference_params=inference_params, **kwargs)
+        denoise_width = cw * kwargs["denoising_range_num"]
+        if kwargs["fwd_extra_1st_chunk"]:
+            denoise_width -= cw
+        x = torch.cat([x[0:1, :, :-denoise_width], out[:, :, -denoise_width:]], dim=2)
+        return torch.cat([x[0:1], x[0:1]], dim=0)

@@ -97,3 +97,85 @@ def test_model_forward_vs_reference_golden():
         assert mine <= 1.25 * floor + 5e-4 and r <= 1.25 * floor + 5e-4, (ci, floor, mine, r)
     with pytest.raises(ValueError):
         model.forward_pre_process(args[0], args[1], args[2], None, args[4], args[5], **kw)
+
+
+class _OracleModel:
+    """The bf16 restatement behind the same `forward` / `forward_dispatcher` surface (CPU): what `ChunkSchedule.run` drives in the
+    reference, with `HipVideoDiTModel`'s dispatcher wiring (a mirror of dit_model.py:537-594) borrowed unbound."""
+
+    def __init__(self, cfg, EW, Ws, config, max_tokens):
+        from inferix_amd.magi.model import HipVideoDiTModel
+        self.cfg, self.EW, self.Ws = cfg, EW, Ws
+        self.model_config, self.engine_config, self.runtime_config = config.model_config, config.engine_config, config.runtime_config
+        self.device, self.patch_size, self.t_patch_size = torch.device("cpu"), cfg.patch_size, cfg.t_patch_size
+        L = cfg.layer
+        self.caches = [MB.MagiLayerCache(max_tokens, L.num_query_groups, L.kv_channels) for _ in Ws]
+        self._dispatch = HipVideoDiTModel.forward_dispatcher
+        self._uncond = HipVideoDiTModel.generate_kv_range_for_uncondition
+
+    def generate_kv_range_for_uncondition(self, x):
+        return self._uncond(self, x)
+
+    def forward(self, x, t, y, caption_dropout_mask=None, xattn_mask=None, kv_range=None, inference_params=None, **kw):
+        cfg = self.cfg
+        xs, cond, cmap, yf, rope, meta = MM.pre_process(self.EW, cfg, x, t, y, xattn_mask, kv_range, caption_dropout_mask,
+                                                        range_num=kw["range_num"], denoising_range_num=kw["denoising_range_num"],
+                                                        slice_point=kw["slice_point"])
+        lm = MB.LayerMeta(q_ranges=[tuple(r) for r in meta["q_range"].tolist()], k_ranges=[tuple(r) for r in kv_range.tolist()],
+                          cu_seqlens_q=meta["cu_seqlens_q"].tolist(), cu_seqlens_kv=meta["cu_seqlens_kv"].tolist(),
+                          clip_token_nums=meta["clip_token_nums"], slice_point=kw["slice_point"],
+                          update_kv_cache=bool(inference_params.update_kv_cache),
+                          use_cache=bool(kw["fwd_extra_1st_chunk"]) or kw["slice_point"] > 0,
+                          distill_nearly_clean_chunk=bool(kw.get("distill_nearly_clean_chunk", False)))
+        h = xs
+        for W, cache in zip(self.Ws, self.caches):
+            h = MB.layer_forward(W, cfg.layer, h, cond, cmap, yf, rope, lm, cache)
+        return MM.post_process(self.EW, cfg, h.float(), meta["H"], meta["W"])
+
+    def forward_dispatcher(self, **kw):
+        return self._dispatch(self, **kw)
+
+
+def test_chunk_schedule_rollout_vs_oracle_model():
+    """MAGI's whole denoising loop at tiny dimensions: 3 chunks x 2 latent frames, 8 steps in a window of 4 -> 12 forwards through
+    `ChunkSchedule.run` + `forward_dispatcher` (clean-chunk prefix forwards, nearly-clean re-forwards, cache writes every step), the
+    HIP model on the GPU against the bf16 restatement on the CPU from the same noise.  What is compared is the integrated velocity
+    (x_final - x_noise); twelve bf16 forwards feed each other through the latents and the KV cache, hence a few e-2."""
+    from inferix_amd.magi.model import HipVideoDiTModel
+    from inferix_amd.magi.schedule import ChunkSchedule
+    from inferix_amd.magi.types import InferenceParams
+    cfg = MM.tiny_model_config()
+    EW = MM.init_embedder_weights(cfg, 5)
+    Ws = [MB.init_layer_weights(cfg.layer, 40 + li) for li in range(cfg.num_layers)]
+    config = _config(cfg)
+    config.runtime_config = SimpleNamespace(cfg_number=1, noise2clean_kvrange=[4, 3, 2, 2], clean_chunk_kvrange=1, clean_t=0.9999)
+    config.engine_config.shortcut_mode = "8,16,16"
+    config.engine_config.distill_nearly_clean_chunk_threshold = 0.3
+    chunk_num, cw, Hl, Wl = 3, 2, 8, 12
+    tokens = cw * (Hl // 2) * (Wl // 2)
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(1, cfg.in_channels, chunk_num * cw, Hl, Wl, generator=g)
+    x = torch.cat([x0, x0], 0)
+    y = torch.randn(2, chunk_num, cfg.caption_max_length, cfg.caption_channels, generator=g)
+    masks = torch.zeros(2, chunk_num, cfg.caption_max_length)
+    masks[0, :, :7] = 1
+    masks[1, :, :2] = 1
+    sch = ChunkSchedule(8, 4, chunk_num, cw)
+    seen = []
+    om = _OracleModel(cfg, EW, Ws, config, chunk_num * tokens)
+    want = sch.run(om, x.clone(), y, masks, SimpleNamespace(update_kv_cache=False), on_forward=seen.append)
+    assert len(seen) == 12 and any(p.fwd_extra_1st_chunk for p in seen)
+    sd = dict(EW)
+    for li, W in enumerate(Ws):
+        sd.update({f"videodit_blocks.layers.{li}.{k}": v for k, v in W.items()})
+    model = HipVideoDiTModel(config, "cuda")
+    model.load_state_dict(sd)
+    got = sch.run(model, x.clone().cuda(), y.cuda(), masks.cuda(), InferenceParams(1, chunk_num * tokens)).cpu()
+    assert torch.equal(got[0], got[1]) and torch.isfinite(got).all()
+    moved = float((want - x).norm() / x.norm())
+    r = rel_l2(got - x, want - x)
+    print(f"magi schedule rollout: 12 forwards, |x_final - x_noise| / |x_noise| = {moved:.3f}; HIP vs oracle on x_final - x_noise: {r:.3e}")
+    assert r < 1e-2, r            # measured 3.3e-3
+    config.runtime_config.cfg_number = 3
+    with pytest.raises(NotImplementedError):
+        model.forward_dispatcher(x=x.cuda(), timestep=None, y=None, mask=None, kv_range=None, inference_params=None)
