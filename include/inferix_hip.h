@@ -38,10 +38,10 @@ typedef uint16_t ifx_bf16;
 
 /* library identity ------------------------------------------------------- */
 /* The MINOR number is the ABI generation: it changes whenever an argument struct gains a field or an entry point changes its
- * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: this round).  Callers built against another minor
+ * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static).  Callers built against another minor
  * must not call in: zero-initialise every struct (new fields default to 0 = off) and compare IFX_ABI_MINOR with
  * (ifx_version() >> 8) & 255 at load time, as inferix_amd/_hip.py does. */
-#define IFX_ABI_MINOR 3
+#define IFX_ABI_MINOR 4
 int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */
@@ -305,6 +305,21 @@ int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* w
 int ifx_layernorm_quant(const ifx_bf16* x, void* q, int32_t ldq, float* scale, int32_t rows, int32_t dim, float eps,
                         int32_t mode, const ifx_bf16* gamma, const ifx_bf16* beta, const ifx_bf16* mod, int32_t mod_slots,
                         int32_t shift_slot, int32_t scale_slot, int32_t rows_per_group, int32_t format, void* stream);
+
+/* ifx_gemm_q8_quant_out: ifx_gemm_q8 with a GELU epilogue (IFX_EPI_GELU_TANH / IFX_EPI_GELU_ERF) whose bf16 result goes straight through
+ * ifx_quant_static's rule instead of to memory: yq[m, n] = e4m3(div_clamp_to(gelu(bf16(acc * scales + bias)), out_divisor[n])), bytes at
+ * yq + m * ldyq + n (ldyq in BYTES, % 8).  It is fc1 -> fc2 of MAGI's fp8_quant MLP (CustomMLP, dit_module.py:493-560: the input of the
+ * PerChannelQuantizedFp8Linear fc2 is fc1's activation divided by smooth_scale): same bytes as ifx_gemm_q8 + ifx_quant_static, bit for
+ * bit, without the [rows, ffn] bf16 round trip.  N % 8 == 0.
+ * ifx_layernorm_quant_static: ifx_layernorm (plain / affine) followed by n_out ifx_quant_static passes of its bf16 row, each with its own
+ * per-input-channel divisor vector (divisors [n_out][dim] fp32): output j lands at byte column j * dim of q (row stride ldq >= n_out *
+ * dim bytes).  MAGI's q / qx / k / v linears quantise the same normalised row with their own input_scale vectors (:448-462). */
+int ifx_gemm_q8_quant_out(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                          const ifx_bf16* bias, void* yq, int32_t ldyq, int32_t M, int32_t N, int32_t K, int32_t format,
+                          const ifx_epilogue* epi, const float* out_divisor, int32_t via_bf16, void* stream);
+int ifx_layernorm_quant_static(const ifx_bf16* x, void* q, int32_t ldq, const float* divisors, int32_t n_out, int32_t rows,
+                               int32_t dim, float eps, int32_t mode, const ifx_bf16* gamma, const ifx_bf16* beta,
+                               int32_t via_bf16, void* stream);
 
 /* Static-scale and per-tensor quantisers (the other qconfig families north_star names, and MAGI's own FP8 linears).
  *   ifx_quant_static     : q[m,k] = cast(clamp(x[m,k] / divisor[k or 0], +-QMAX)).  With via_bf16 = 1 the clamped quotient is

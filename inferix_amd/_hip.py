@@ -125,6 +125,8 @@ SIGNATURES = {
     "ifx_gemm_q8": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
     "ifx_attn_fwd_paged_ld": (C.c_int, [_vp, _i32, _vp, _i32, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
                                         C.c_int64, _vp]),
+    "ifx_gemm_q8_quant_out": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp]),
+    "ifx_layernorm_quant_static": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "ifx_quant_static": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ifx_quant_per_tensor": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "ifx_magi_head_prep": (C.c_int, [C.POINTER(MagiHeadPrepDesc), _vp]),
@@ -138,7 +140,7 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
-ABI_MINOR = 3      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
+ABI_MINOR = 4      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
 
 
 def load() -> C.CDLL:

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int rows, int dim, float eps,
     int mode, const unsigned short* __restrict__ gamma, const unsigned short* __restrict__ beta,
     const unsigned short* __restrict__ mod, int mod_slots, int shift_slot, int scale_slot,
-    int rows_per_group, unsigned char* __restrict__ q = nullptr, int ldq = 0, float* __restrict__ qscale = nullptr) {
+    int rows_per_group, unsigned char* __restrict__ q = nullptr, int ldq = 0, float* __restrict__ qscale = nullptr,
+    int n_out = 0, int via_bf16 = 0) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -140,7 +141,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     if (QUANT == 0) *reinterpret_cast<u16x8*>(y + (size_t)r * dim + col) = o;
     else qrow[c] = o;
   }
-  if (QUANT != 0) {
+  if (QUANT == 3) {
+    // static-scale e4m3 (MAGI's PerTensorQuantizedFp8Linear inputs): output j = div_clamp_to(row, divisor_j) at byte column j * dim of
+    // q; the q / qx / k / v linears quantise the same normalised row with their own input_scale vectors, so one read feeds all four
+    const float* divs = qscale;
+    for (int j = 0; j < n_out; ++j) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col >= dim) continue;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(divs + (size_t)j * dim + col);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(divs + (size_t)j * dim + col + 4);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = fminf(fmaxf(bf2f(qrow[c][i]) / (i < 4 ? d0[i] : d1[i - 4]), -448.0f), 448.0f);
+          if (via_bf16) t = rbf(t);
+          v[i] = t;
+        }
+        unsigned w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+        *reinterpret_cast<u32x2*>(q + (size_t)r * ldq + (size_t)j * dim + col) = u32x2{w0, w1};
+      }
+    }
+  } else if (QUANT != 0) {
     constexpr float QMAX = QUANT == 1 ? 448.0f : 127.0f;
     float amax = 0.f;
 #pragma unroll
@@ -439,6 +466,23 @@ extern "C" int ifx_layernorm_quant(const ifx_bf16* x, void* q, int32_t ldq, floa
       hipLaunchKernelGGL((layernorm_kernel<NC, 2>), grid, block, 0, (hipStream_t)stream, x, (unsigned short*)nullptr, rows, dim, eps,
                          mode, gamma, beta, mod, mod_slots, shift_slot, scale_slot, rpg, (unsigned char*)q, ldq, scale);
     return check_launch("ifx_layernorm_quant");
+  });
+}
+
+extern "C" int ifx_layernorm_quant_static(const ifx_bf16* x, void* q, int32_t ldq, const float* divisors, int32_t n_out, int32_t rows,
+                                          int32_t dim, float eps, int32_t mode, const ifx_bf16* gamma, const ifx_bf16* beta,
+                                          int32_t via_bf16, void* stream) {
+  IFX_REQUIRE(x && q && divisors && rows >= 0 && dim > 0 && dim % 8 == 0 && n_out >= 1 && n_out <= 8 && ldq >= n_out * dim && ldq % 8 == 0,
+              "ifx_layernorm_quant_static: bad x/q/divisors/rows/dim(%d)/n_out(%d)/ldq(%d)", dim, n_out, ldq);
+  IFX_REQUIRE(mode == IFX_LN_PLAIN || mode == IFX_LN_AFFINE, "ifx_layernorm_quant_static: mode %d (plain or affine)", mode);
+  if (mode == IFX_LN_AFFINE) IFX_REQUIRE(gamma && beta, "ifx_layernorm_quant_static: affine mode needs gamma/beta");
+  if (rows == 0) return IFX_OK;
+  return dispatch_nch(dim, [&](auto nch) {
+    constexpr int NC = decltype(nch)::value;
+    hipLaunchKernelGGL((layernorm_kernel<NC, 3>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)nullptr,
+                       rows, dim, eps, mode, gamma, beta, (const unsigned short*)nullptr, 0, 0, 0, 1, (unsigned char*)q, ldq,
+                       const_cast<float*>(divisors), n_out, via_bf16);
+    return check_launch("ifx_layernorm_quant_static");
   });
 }
 

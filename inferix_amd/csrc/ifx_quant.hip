@@ -110,7 +110,22 @@ struct EpiArgsQ {
   int ld_res;
   const unsigned short* mod;
   int mod_slots, gate_slot, rows_per_group;
+  const float* qdiv = nullptr;   // GELU epilogues only: y is e4m3 bytes (ldy in bytes), q = div_clamp_to(bf16 result, qdiv[n])
+  int q_via_bf16 = 0;
 };
+
+// div_clamp_to (dit_module.py:367-387) of four bf16 values -> four e4m3 bytes
+__device__ __forceinline__ unsigned quant4_e4m3(const float (&x)[4], const f32x4 d, int via_bf16) {
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = fminf(fmaxf(x[e] / d[e], -448.0f), 448.0f);
+    v[e] = via_bf16 ? rbf(t) : t;
+  }
+  unsigned w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+}
 
 __device__ __forceinline__ float gelu_tanh_q(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -272,7 +287,13 @@ if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch arou
             for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(rbf(v[e]) * bf2f(gv[e])));
           }
         }
-        *reinterpret_cast<u16x4*>(y + (size_t)m * ldy + n) = o;
+        if (EPI == IFX_EPI_GELU_TANH && ea.qdiv != nullptr) {
+          const float ob[4] = {bf2f(o[0]), bf2f(o[1]), bf2f(o[2]), bf2f(o[3])};
+          *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(y) + (size_t)m * ldy + n) =
+              quant4_e4m3(ob, *reinterpret_cast<const f32x4*>(ea.qdiv + n), ea.q_via_bf16);
+        } else {
+          *reinterpret_cast<u16x4*>(y + (size_t)m * ldy + n) = o;
+        }
       }
   }
 }
@@ -496,7 +517,15 @@ if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch arou
           for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
         }
       }
-      *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+      if (EPI == IFX_EPI_GELU_TANH && ea.qdiv != nullptr) {
+        const float lo[4] = {bf2f(o[0]), bf2f(o[1]), bf2f(o[2]), bf2f(o[3])};
+        const float hi4[4] = {bf2f(o[4]), bf2f(o[5]), bf2f(o[6]), bf2f(o[7])};
+        const unsigned w0 = quant4_e4m3(lo, *reinterpret_cast<const f32x4*>(ea.qdiv + n), ea.q_via_bf16);
+        const unsigned w1 = quant4_e4m3(hi4, *reinterpret_cast<const f32x4*>(ea.qdiv + n + 4), ea.q_via_bf16);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(y) + (size_t)m * ldy + n) = u32x2{w0, w1};
+      } else {
+        *reinterpret_cast<u16x8*>(y + (size_t)m * ldy + n) = o;
+      }
     }
   }
 }
@@ -563,15 +592,22 @@ extern "C" int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int3
   return check_launch("ifx_quant_per_token");
 }
 
-extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
-                           const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
-                           int32_t format, const ifx_epilogue* epi, void* stream) {
+static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                        const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
+                        int32_t format, const ifx_epilogue* epi, void* stream, const float* qdiv, int q_via_bf16) {
   IFX_REQUIRE(xq && wq && x_scale && w_scale && y && M >= 0 && N > 0 && K > 0, "ifx_gemm_q8: null/empty operand");
   IFX_REQUIRE(K % 128 == 0, "ifx_gemm_q8: K (%d) must be a multiple of 128", K);
   IFX_REQUIRE(N % 4 == 0 && ldx % 16 == 0 && ldy % 4 == 0, "ifx_gemm_q8: N %% 4, ldx %% 16, ldy %% 4 required");
   IFX_REQUIRE(format == IFX_Q_FP8_E4M3 || format == IFX_Q_INT8, "ifx_gemm_q8: unknown format %d", format);
   int mode = epi ? epi->epilogue : IFX_EPI_BIAS;
   EpiArgsQ ea{x_scale, w_scale, bias, nullptr, 0, nullptr, 1, 0, 1};
+  if (qdiv != nullptr) {
+    IFX_REQUIRE(mode == IFX_EPI_GELU_TANH || mode == IFX_EPI_GELU_ERF, "ifx_gemm_q8_quant_out: epilogue %d (a GELU epilogue feeds the "
+                "quantised output)", mode);
+    IFX_REQUIRE(ldy % 8 == 0, "ifx_gemm_q8_quant_out: ldyq (%d) must be a multiple of 8 bytes", ldy);
+    ea.qdiv = qdiv;
+    ea.q_via_bf16 = q_via_bf16;
+  }
   if (mode == IFX_EPI_GELU_ERF) {       // the GELU instantiation with the exact-erf activation selected at run time
     mode = IFX_EPI_GELU_TANH;
     ea.gate_slot = 1;
@@ -645,4 +681,17 @@ extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, co
 #undef IFX_SWITCH_Q8
 #undef IFX_LAUNCH_Q8
   return check_launch("ifx_gemm_q8");
+}
+
+extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                           const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
+                           int32_t format, const ifx_epilogue* epi, void* stream) {
+  return gemm_q8_impl(xq, ldx, x_scale, wq, w_scale, bias, y, ldy, M, N, K, format, epi, stream, nullptr, 0);
+}
+
+extern "C" int ifx_gemm_q8_quant_out(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                                     const ifx_bf16* bias, void* yq, int32_t ldyq, int32_t M, int32_t N, int32_t K, int32_t format,
+                                     const ifx_epilogue* epi, const float* out_divisor, int32_t via_bf16, void* stream) {
+  IFX_REQUIRE(out_divisor && epi && N % 8 == 0, "ifx_gemm_q8_quant_out: out_divisor / epilogue missing or N %% 8 != 0");
+  return gemm_q8_impl(xq, ldx, x_scale, wq, w_scale, bias, (ifx_bf16*)yq, ldyq, M, N, K, format, epi, stream, out_divisor, via_bf16);
 }

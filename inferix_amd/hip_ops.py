@@ -535,6 +535,41 @@ def linear_q8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale
     return out
 
 
+def linear_q8_quant_out(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, fmt: int, out_divisor: torch.Tensor,
+                        *, epilogue: int = _hip.IFX_EPI_GELU_ERF, via_bf16: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """e4m3 bytes `[M, N]` = quant_static(gelu(bf16((xq @ wq.T) * scales)), out_divisor) in the GEMM's epilogue (ifx_gemm_q8_quant_out)."""
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and wq.is_contiguous() and xq.stride(1) == 1 and out_divisor.numel() == N
+    out = torch.empty(M, N, dtype=torch.uint8, device=xq.device) if out is None else out
+    epi = _hip.Epilogue(epilogue, None, 0, None, 1, 0, 1)
+    with _timed("gemm_q8", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 1.0 * M * N):
+        _hip.check(_hip.load().ifx_gemm_q8_quant_out(_dev(xq, "xq", torch.uint8), xq.stride(0), _dev(x_scale, "x_scale", F32),
+                                                     _dev(wq, "wq", torch.uint8), _dev(w_scale, "w_scale", F32), None,
+                                                     _dev(out, "out", torch.uint8), out.stride(0), M, N, K, int(fmt), C.byref(epi),
+                                                     _dev(out_divisor, "out_divisor", F32), 1 if via_bf16 else 0, _stream()),
+                   "ifx_gemm_q8_quant_out")
+    return out
+
+
+def layernorm_quant_static(x: torch.Tensor, eps: float, divisors: torch.Tensor, gamma: Optional[torch.Tensor] = None,
+                           beta: Optional[torch.Tensor] = None, via_bf16: bool = True) -> torch.Tensor:
+    """LayerNorm (plain / affine) of `[rows, dim]` bf16 + `n_out` static e4m3 quantisations of its bf16 result, one per divisor
+    vector of `divisors` `[n_out, dim]` fp32 -> bytes `[rows, n_out, dim]` (ifx_layernorm_quant_static)."""
+    rows, dim, ldx = _rows2d(x, "x")
+    assert ldx == dim, "layernorm_quant_static: dense rows"
+    n_out = divisors.shape[0]
+    assert divisors.shape == (n_out, dim) and divisors.is_contiguous()
+    q = torch.empty(rows, n_out, dim, dtype=torch.uint8, device=x.device)
+    mode = _hip.IFX_LN_AFFINE if gamma is not None else _hip.IFX_LN_PLAIN
+    with _timed("layernorm", 0.0, (2.0 + n_out) * rows * dim):
+        _hip.check(_hip.load().ifx_layernorm_quant_static(_dev(x, "x"), _dev(q, "q", torch.uint8), n_out * dim, _dev(divisors, "divisors", F32),
+                                                          n_out, rows, dim, float(eps), mode, _dev(gamma, "gamma") if gamma is not None else None,
+                                                          _dev(beta, "beta") if beta is not None else None, 1 if via_bf16 else 0, _stream()),
+                   "ifx_layernorm_quant_static")
+    return q
+
+
 def kv_roll(kv: KvCacheView, sink_tokens: int, evicted: int, rolled: int, scratch: torch.Tensor) -> None:
     lib = _hip.load()
     ks = kv.struct()

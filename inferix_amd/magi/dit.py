@@ -84,6 +84,8 @@ class HipFullyParallelAttention:
             for nm in ("q", "qx", "k", "v"):
                 k = f"linear_qkv.{nm}."
                 self.fp8[nm] = StaticFp8Linear(g(k + "weight"), g(k + "weight_scale"), g(k + "input_scale"), g(k + "input_scale"))
+            h = self.fp8["q"].in_features
+            self.qkv_divisors = torch.stack([self.fp8[nm].divisor.expand(h) for nm in ("q", "qx", "k", "v")]).contiguous()
         else:
             self.w["qkv"] = torch.cat([g("linear_qkv.q.weight"), g("linear_qkv.qx.weight"), g("linear_qkv.k.weight"),
                                        g("linear_qkv.v.weight")], dim=0).to(BF16).contiguous()
@@ -118,15 +120,17 @@ class HipFullyParallelAttention:
         eps, one_p = mc.layernorm_epsilon, bool(mc.apply_layernorm_1p)
         Q = self.hq * self.hd
         x2 = hidden_states.view(s_len, h)
-        hln = ops.layernorm(x2, eps, gamma=w["ln_w"], beta=w["ln_b"])
         if self.fp8:                                                                      # [s, q | qx | k | v]
             KV = self.hk * self.hd
             mixed = torch.empty(s_len, 2 * Q + 2 * KV, dtype=BF16, device=x2.device)
+            # one pass: LayerNorm + the four linears' own static quantisers of its bf16 row (each has its own input_scale vector)
+            hq = ops.layernorm_quant_static(x2, eps, self.qkv_divisors, gamma=w["ln_w"], beta=w["ln_b"])
             off = 0
-            for nm, n in (("q", Q), ("qx", Q), ("k", KV), ("v", KV)):
-                self.fp8[nm](hln, out=mixed[:, off:off + n])
+            for i, (nm, n) in enumerate((("q", Q), ("qx", Q), ("k", KV), ("v", KV))):
+                self.fp8[nm].matmul(hq[:, i], out=mixed[:, off:off + n])
                 off += n
         else:
+            hln = ops.layernorm(x2, eps, gamma=w["ln_w"], beta=w["ln_b"])
             mixed = ops.linear(hln, w["qkv"], None)
         if attn_cat is None:
             attn_cat = torch.empty(s_len, 2 * Q, dtype=BF16, device=x2.device)
@@ -302,10 +306,12 @@ class HipMagiTransformerLayer:
         proj = sa.fp8["proj"](attn_cat) if sa.fp8 else ops.linear(attn_cat, sa.w["proj"], None)
         gate = self.gate(condition)
         hs = ops.magi_gate_norm_residual(proj, x2, cmap, gate[:, :h], *w["self_attn_post_norm"], eps, one_p)
-        m = ops.layernorm(hs, eps, gamma=w["mlp_ln"][0], beta=w["mlp_ln"][1])
-        if self.fp8:
-            m = self.fp8["fc2"](self.fp8["fc1"](m, epilogue=_hip.IFX_EPI_GELU_ERF))
+        if self.fp8:      # LayerNorm -> fc1's quantiser in one pass; fc1's GELU epilogue writes fc2's quantised input
+            fc1, fc2 = self.fp8["fc1"], self.fp8["fc2"]
+            mq = ops.layernorm_quant_static(hs, eps, fc1.divisor.expand(h).view(1, -1).contiguous(), gamma=w["mlp_ln"][0], beta=w["mlp_ln"][1])
+            m = fc2.matmul(fc1.matmul_quant_out(mq[:, 0], fc2, _hip.IFX_EPI_GELU_ERF))
         else:
+            m = ops.layernorm(hs, eps, gamma=w["mlp_ln"][0], beta=w["mlp_ln"][1])
             m = ops.linear(m, w["fc1"], None, epilogue=_hip.IFX_EPI_GELU_ERF)
             m = ops.linear(m, w["fc2"], None)
         out = ops.magi_gate_norm_residual(m, hs, cmap, gate[:, h:], *w["mlp_post_norm"], eps, one_p)

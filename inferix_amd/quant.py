@@ -80,15 +80,32 @@ class StaticFp8Linear:
         assert self.divisor.numel() in (1, self.in_features)
         self._sx: Optional[torch.Tensor] = None          # per-row activation scale (one value repeated), kept between calls
 
+    def _row_scale(self, rows: int) -> torch.Tensor:
+        if self._sx is None or self._sx.shape[0] != rows:
+            self._sx = self.in_scale.expand(rows).contiguous()
+        return self._sx
+
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, **epilogue) -> torch.Tensor:
         """`out`: optional `[rows, out_features]` destination (any row stride: a column block of a wider buffer)."""
         from . import hip_ops as ops
         x2 = x.reshape(-1, self.in_features)
         q = ops.quant_static(x2, self.divisor, _hip.IFX_Q_FP8_E4M3, via_bf16=True)
-        sx = self._sx if self._sx is not None and self._sx.shape[0] == x2.shape[0] else self.in_scale.expand(x2.shape[0]).contiguous()
-        self._sx = sx
-        y = ops.linear_q8(q, sx, self.weight, self.w_scale, None, _hip.IFX_Q_FP8_E4M3, out=out, **epilogue)
+        y = self.matmul(q, out=out, **epilogue)
         return y if out is not None else y.view(*x.shape[:-1], self.out_features)
+
+    def matmul(self, q: torch.Tensor, out: Optional[torch.Tensor] = None, **epilogue) -> torch.Tensor:
+        """The GEMM half on bytes some producer already quantised with THIS linear's divisor (`q` `[rows, in_features]` uint8, any
+        row stride): `ops.layernorm_quant_static` for the linears behind a LayerNorm, `matmul_quant_out` of the linear in front."""
+        from . import hip_ops as ops
+        return ops.linear_q8(q, self._row_scale(q.shape[0]), self.weight, self.w_scale, None, _hip.IFX_Q_FP8_E4M3, out=out, **epilogue)
+
+    def matmul_quant_out(self, q: torch.Tensor, nxt: "StaticFp8Linear", epilogue: int) -> torch.Tensor:
+        """GEMM + GELU whose result is quantised for `nxt` in the epilogue: bytes `[rows, out_features]`, = nxt's own quantiser
+        applied to `self.matmul(q, epilogue=...)`, bit for bit."""
+        from . import hip_ops as ops
+        assert nxt.in_features == self.out_features and nxt.divisor.numel() == self.out_features
+        return ops.linear_q8_quant_out(q, self._row_scale(q.shape[0]), self.weight, self.w_scale, _hip.IFX_Q_FP8_E4M3, nxt.divisor,
+                                       epilogue=epilogue, via_bf16=True)
 
 
 def quantize_weight(w: torch.Tensor, qc: QConfig) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -42,6 +42,13 @@ def test_cabi_argument_validation_without_gpu():
     assert b"unknown format" in lib.ifx_last_error()
     assert lib.ifx_layernorm_quant(C.c_void_p(8), C.c_void_p(8), 64, C.c_void_p(8), 4, 128, 1e-6, 0, None, None, None, 0, 0, 0, 1,
                                    0, None) == -1                      # row stride of the bytes shorter than the row
+    assert lib.ifx_layernorm_quant_static(C.c_void_p(8), C.c_void_p(8), 256, C.c_void_p(8), 4, 4, 128, 1e-6, 0, None, None, 1, None) == -1
+    assert b"ldq" in lib.ifx_last_error()                               # four outputs of 128 bytes do not fit a 256-byte row
+    assert lib.ifx_layernorm_quant_static(C.c_void_p(8), C.c_void_p(8), 512, C.c_void_p(8), 4, 4, 128, 1e-6, 2, None, None, 1, None) == -1
+    epi = _hip.Epilogue(_hip.IFX_EPI_BIAS, None, 0, None, 1, 0, 1)
+    assert lib.ifx_gemm_q8_quant_out(C.c_void_p(16), 128, C.c_void_p(8), C.c_void_p(16), C.c_void_p(8), None, C.c_void_p(16), 64, 4, 64, 128,
+                                     0, C.byref(epi), C.c_void_p(8), 1, None) == -1
+    assert b"GELU" in lib.ifx_last_error()
     assert lib.ifx_set_option(b"gemm_variant", 25) == 0 and lib.ifx_set_option(b"gemm_variant", 26) != 0
     assert lib.ifx_set_option(b"gemm_variant", 0) == 0
     assert lib.ifx_set_option(b"gemm_small_split", 1) == 0 and lib.ifx_set_option(b"gemm_small_split", 2) != 0

@@ -293,6 +293,43 @@ def test_static_and_per_tensor_quantisers_vs_reference_golden():
     assert float(s[0]) == 1.0 and int(q.sum()) == 0
 
 
+def test_fused_static_quantisers_are_the_separate_passes_bit_for_bit():
+    """The two producers that now carry MAGI's static quantisers: LayerNorm + n quantisations of its row (ifx_layernorm_quant_static)
+    == ifx_layernorm then ifx_quant_static per divisor; a GELU GEMM whose epilogue quantises for the next linear
+    (ifx_gemm_q8_quant_out) == ifx_gemm_q8 then ifx_quant_static — every byte, on every kernel the dispatcher picks (128-row
+    register-staged tile, 256 x 128 and 256 x 256 LDS-DMA tiles), ragged row counts included."""
+    from inferix_amd import _hip
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    FP8 = _hip.IFX_Q_FP8_E4M3
+    for rows, dim, n_out in ((1519, 3072, 4), (6075, 3072, 1), (37, 256, 3), (300, 1536, 2)):
+        x = (torch.randn(rows, dim, generator=g, device="cuda") * 1.7 + 0.3).to(BF)
+        gamma = (1 + 0.1 * torch.randn(dim, generator=g, device="cuda")).to(BF)
+        beta = (0.1 * torch.randn(dim, generator=g, device="cuda")).to(BF)
+        divs = (0.03 * (1 + 0.5 * torch.rand(n_out, dim, generator=g, device="cuda"))).contiguous()
+        for affine in (True, False):
+            kw = dict(gamma=gamma, beta=beta) if affine else {}
+            fused = ops.layernorm_quant_static(x, 1e-6, divs, **kw)
+            ln = ops.layernorm(x, 1e-6, **kw)
+            for j in range(n_out):
+                assert torch.equal(fused[:, j], ops.quant_static(ln, divs[j], FP8, via_bf16=True)), (rows, dim, j, affine)
+        direct = ops.layernorm_quant_static(x, 1e-6, divs[:1].contiguous(), via_bf16=False)
+        assert torch.equal(direct[:, 0], ops.quant_static(ops.layernorm(x, 1e-6), divs[0], FP8, via_bf16=False))
+    for M, N, K in ((1519, 12288, 3072), (6075, 12288, 3072), (24300, 12288, 3072), (100, 512, 256), (300, 1024, 384)):
+        xq = torch.randn(M, K, generator=g, device="cuda").to(torch.float8_e4m3fn).view(torch.uint8)
+        wq = (torch.randn(N, K, generator=g, device="cuda") * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
+        sx = torch.full((M,), 0.03, device="cuda")
+        sw = (0.002 * (1 + torch.rand(N, generator=g, device="cuda"))).contiguous()
+        div = (0.02 * (1 + torch.rand(N, generator=g, device="cuda"))).contiguous()
+        for epi in (_hip.IFX_EPI_GELU_ERF, _hip.IFX_EPI_GELU_TANH):
+            y = ops.linear_q8(xq, sx, wq, sw, None, FP8, epilogue=epi)
+            want = ops.quant_static(y, div, FP8, via_bf16=True)
+            got = ops.linear_q8_quant_out(xq, sx, wq, sw, FP8, div, epilogue=epi)
+            assert torch.equal(got, want), (M, N, K, epi, int((got != want).sum()))
+    with pytest.raises(RuntimeError):
+        ops.linear_q8_quant_out(xq, sx, wq, sw, FP8, div, epilogue=_hip.IFX_EPI_BIAS)
+
+
 def test_full_size_chunk_properties():
     """MAGI-4.5B at its workload size — one 720x720 chunk = 12150 tokens, 24 q-heads on 8 kv-groups, 2 denoising ranges, a
     prefix of one stored chunk — where the CPU oracle is out of reach: size-independent properties of the layer.
