@@ -27,11 +27,14 @@ if "gemm" in which:
     x = rnd(N, d)
     wqkv, wo, w1, w2 = rnd(3 * d, d), rnd(d, d), rnd(f, d), rnd(d, f)
     b3, b1, bf_ = rnd(3 * d), rnd(d), rnd(f)
+    mod = rnd(3, 6, d)
     for _ in range(reps):
-        ops.linear(x, wqkv, b3)
-        ops.linear(x, wo, b1, epilogue=_hip.IFX_EPI_RESIDUAL, residual=x)
-        u = ops.linear(x, w1, bf_, epilogue=_hip.IFX_EPI_GELU_TANH)
-        ops.linear(u, w2, b1)
+        ops.linear(x, wqkv, b3)                                                                      # qkv            (pp <0, 3, 1>)
+        ops.linear(x, wo, b1, epilogue=_hip.IFX_EPI_GATE_RES, residual=x, mod=mod, gate_slot=2, rows_per_group=1560)   # o + gate  (pp <3, ., 1>)
+        ops.linear(x, wo, b1)                                                                        # cross q        (pp <0, ., 1>)
+        ops.linear(x, wo, b1, epilogue=_hip.IFX_EPI_RESIDUAL, residual=x)                            # cross o + res  (pp <2, ., 1>)
+        u = ops.linear(x, w1, bf_, epilogue=_hip.IFX_EPI_GELU_TANH)                                  # ffn up + GELU  (pp <1, 4, 1>)
+        ops.linear(u, w2, b1, epilogue=_hip.IFX_EPI_GATE_RES, residual=x, mod=mod, gate_slot=5, rows_per_group=1560)   # ffn down + gate, split-K (pp <3, 4, 2>)
 if "w4" in which:
     # long-K shapes of the MAGI layer (one rank of cp = 8): the four-wave register-staged tile (auto) against the eight-wave 256x256 tile
     M, hdn, ffn = 6075, 3072, 12288
