@@ -44,6 +44,12 @@ struct EpiArgsP {
   int ld_res;
   const unsigned short* mod;
   int mod_slots, gate_slot, rows_per_group;
+  // 8-bit operands (Q8 instantiations): per-token / per-channel dequantisation scales, and (GELU epilogues) an optional static quantiser
+  // of the result for the next linear (ifx_gemm_q8_quant_out): y then holds e4m3 bytes, ldy in bytes
+  const float* sa = nullptr;
+  const float* sw = nullptr;
+  const float* qdiv = nullptr;
+  int q_via_bf16 = 0;
 };
 
 namespace gpp {
@@ -52,6 +58,7 @@ constexpr int SLOT = 16384, STAGE = 4 * SLOT, SCRATCH = 2 * STAGE;      // two 6
 constexpr int LDS_BYTES = SCRATCH + 32768;
 constexpr int X_UP = 0, W_LO = SLOT, W_HI = 2 * SLOT, X_DN = 3 * SLOT;  // slots of a stage
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, int voff, int soff) {
@@ -88,7 +95,11 @@ struct Cursor {
 };
 }  // namespace gpp
 
-template <int EPI, int TJ, int KS>
+// Q8: e4m3 operands (one byte per element: a K-step is 128 elements, the same 128-byte rows), two v_mfma_scale_f32_32x32x64_f8f6f4 with
+// unit block scales per accumulator and K-step in place of four v_mfma_f32_32x32x16_bf16 — the same 1024 matrix-pipe cycles per phase for
+// twice the arithmetic — and the dequantisation acc * (sa[m] * sw[n]) in the epilogue (ifx_gemm_q8's contract).  The K order inside a
+// fragment is whatever the hardware uses: both operands are read with the same lane -> byte map.
+template <int EPI, int TJ, int KS, bool Q8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* __restrict__ x, int ldx,
                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
                                                          int ldy, int M, int N, int K, int tiles_m, int total, int per_xcd,
@@ -105,7 +116,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   // KS = 2: every tile is TWO work items, the K halves, on two workgroups (neighbouring ids: same XCD, same position of their lists).
   // The second half's workgroup leaves its fp32 accumulators in the workspace (write-through stores) and raises the tile's flag; the
   // first half's workgroup adds them to its own — always first + second — and runs the epilogue.  `total` counts ITEMS.
-  const int KT = K / BK / KS;               // K-steps of one work item
+  constexpr int ES = Q8 ? 1 : 2;            // bytes per operand element
+  const unsigned char* const xb = reinterpret_cast<const unsigned char*>(x);
+  const unsigned char* const wb = reinterpret_cast<const unsigned char*>(w);
+  const int KT = K * ES / 128 / KS;         // K-steps (128 bytes of every operand row) of one work item
   const int tiles_n = total / KS / tiles_m;
 
   // ---- this workgroup's tiles: XCD (bid & 7) owns ids [xcd * per_xcd, ...); its wg_per_xcd workgroups take them round-robin, so the
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   const int r8 = lane >> 3, pc = lane & 7;
   const int prow = w4 * 8 + r8;
   const int ld_op = grp == 0 ? K : ldx;              // row pitch of the operand this group requests (W / x)
-  const int voff = prow * ld_op * 2 + ((pc ^ ((prow >> 1) & 7)) << 4);
+  const int voff = prow * ld_op * ES + ((pc ^ ((prow >> 1) & 7)) << 4);
   const unsigned lds_piece0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + w4 * 1024;
   auto cur_desc = [&](Cursor& c) __attribute__((always_inline)) {                   // descriptor (and lab rotation) of tile c.i
     int mb, nb;
@@ -143,8 +157,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     if (dbg & 1) mb = nb = 0;                        // lab: every workgroup streams tile 0's operands (L2-hot), timing only
     c.rot = (dbg & 4) ? ((nb / BN) * 3) % KT : 0;    // lab: K rotation by column tile
     c.k0 = item_split(c.i) * KT;
-    if (grp == 0) c.rs = make_rsrc(w + (size_t)nb * K, (unsigned)min(((long)N - nb) * (long)K * 2L, 0xffffffffL));
-    else c.rs = make_rsrc(x + (size_t)mb * ldx, (unsigned)min(((long)M - mb - 1) * (long)ldx * 2L + (long)K * 2L, 0xffffffffL));
+    if (grp == 0) c.rs = make_rsrc(wb + (size_t)nb * K * ES, (unsigned)min(((long)N - nb) * (long)K * ES, 0xffffffffL));
+    else c.rs = make_rsrc(xb + (size_t)mb * ldx * ES, (unsigned)min(((long)M - mb - 1) * (long)ldx * ES + (long)K * ES, 0xffffffffL));
   };
   auto cur_init = [&](Cursor& c) __attribute__((always_inline)) {
     c.i = 0, c.kt = 0, c.g = 0;
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     const unsigned p = lds_piece0 + (c.g & 1) * STAGE + slot;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (q < pieces) dma16(c.rs, p + q * 4096, voff, kb + (row0 + q * 32) * ld_op * 2);
+      if (q < pieces) dma16(c.rs, p + q * 4096, voff, kb + (row0 + q * 32) * ld_op * ES);
   };
   Cursor ca, cb;                                     // group 0: ca = W.  group 1: ca = x-lower, cb = x-upper (one K-step ahead of ca)
   cur_init(ca);
@@ -192,8 +206,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   };
 
   f32x16 acc[2][TJ];
+  auto q8_mfma = [&](int kk, int i, int j, const f32x16 c) __attribute__((always_inline)) {
+    const v8i a = __builtin_shufflevector(__builtin_bit_cast(v4i, fw[2 * kk][i]), __builtin_bit_cast(v4i, fw[2 * kk + 1][i]), 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8i b = __builtin_shufflevector(__builtin_bit_cast(v4i, fx[2 * kk][j]), __builtin_bit_cast(v4i, fx[2 * kk + 1][j]), 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  };
   auto mfma_first = [&]() __attribute__((always_inline)) {                          // first K-step of a tile: the accumulators start from zero
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (Q8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = q8_mfma(0, i, j, z);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = q8_mfma(1, i, j, acc[i][j]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -206,6 +236,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
   };
   auto mfma_next = [&]() __attribute__((always_inline)) {
+    if constexpr (Q8) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = q8_mfma(kk, i, j, acc[i][j]);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -276,6 +315,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + i * 32 + g * 8 + hi * 4);
         e_bias[i][g] = u32x2{b[0] & bias_mask, b[1] & bias_mask};
       }
+    f32x4 e_sw[Q8 ? 2 : 1][Q8 ? 4 : 1];               // Q8: per-channel weight scales of the lane's channels, per-token scales of its TJ tokens
+    float e_sa[Q8 ? TJ : 1];
+    f32x4 e_qd[2];                                    // quantised output: the divisors of the 8 channels this lane stores per row
+    if constexpr (Q8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_sw[i][g] = *reinterpret_cast<const f32x4*>(ea.sw + e_n0 + i * 32 + g * 8 + hi * 4);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) e_sa[j] = ea.sa[min(e_m0 + j * 32 + l31, M - 1)];
+      if constexpr (EPI == IFX_EPI_GELU_TANH) {
+        const float* const qd = ea.qdiv != nullptr ? ea.qdiv : ea.sw;       // any valid address when the output is bf16
+        e_qd[0] = *reinterpret_cast<const f32x4*>(qd + e_n0 + cc * 8);
+        e_qd[1] = *reinterpret_cast<const f32x4*>(qd + e_n0 + cc * 8 + 4);
+      }
+    }
     u32x4 e_res[2][4], e_gate[2];                     // residual rows of two 32-token blocks: the next block's are in flight under this one's work
     int e_split = 0;                                  // first token of the wave's second gate group
     auto fetch_res = [&](int j) __attribute__((always_inline)) {
@@ -309,6 +364,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_bias[i][g]));
+    if constexpr (Q8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_sw[i][g]));
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(e_sa[j]));
+      if constexpr (EPI == IFX_EPI_GELU_TANH) asm volatile("" : "+v"(e_qd[0]), "+v"(e_qd[1]));
+    }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
       if (j + 1 < TJ) fetch_res(j + 1);
@@ -324,6 +388,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024, part_so, 16));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += pq[e];
+          }
+          if constexpr (Q8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(v[e], __fmul_rn(e_sa[j], e_sw[i][g][e]));   // not contracted with the bias add
           }
           const u32x2 b = e_bias[i][g];
           v[0] += __builtin_bit_cast(float, b[0] << 16);
@@ -366,6 +434,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
             const u16x8 gv = __builtin_bit_cast(u16x8, m >= e_split ? e_gate[1] : e_gate[0]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rv[e]) + rbf(bf2f(vv[e]) * bf2f(gv[e])));
+          }
+        }
+        if constexpr (Q8 && EPI == IFX_EPI_GELU_TANH) {
+          if (ea.qdiv != nullptr) {                    // wave-uniform: the result leaves as the next linear's e4m3 input
+            unsigned wq[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              float t[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float q = fminf(fmaxf(bf2f(o[4 * h + e]) / e_qd[h][e], -448.0f), 448.0f);
+                t[e] = ea.q_via_bf16 ? rbf(q) : q;
+              }
+              unsigned pk = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0u, false);
+              wq[h] = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], pk, true);
+            }
+            if (m < M && n_ok)
+              *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(y) + (size_t)(e_m0 + rr + j * 32 + p * 8) * ldy + e_n0 + cc * 8) =
+                  u32x2{wq[0], wq[1]};
+            continue;
           }
         }
         if (m < M && n_ok) *reinterpret_cast<u16x8*>(yrow + (size_t)(j * 32 + p * 8) * ldy) = o;
@@ -559,9 +647,15 @@ size_t gemm_pp_workspace_bytes(int M, int N, int K) {
 
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
-                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace) {
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16) {
   using namespace gpp;
-  EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group};
+  const bool q8 = q8_sa != nullptr;                  // e4m3 operands: x / w point at bytes, ldx and K count elements = bytes
+  EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, q8_sa, q8_sw, q8_qdiv, q8_via_bf16};
+  if (q8 && (K % 128 != 0 || ldx % 16 != 0 || ((uintptr_t)q8_sw & 15) || ((uintptr_t)q8_qdiv & 15))) {
+    set_error("ifx_gemm_q8: the ping-pong tile needs K %% 128 == 0, ldx %% 16 == 0 and 16-byte aligned scale vectors (K = %d, ldx = %d)", K, ldx);
+    return IFX_EINVAL;
+  }
   if (N % 64 != 0 || K % 64 != 0) {
     set_error("ifx_gemm_bf16: the ping-pong tile needs N and K to be multiples of 64 (N = %d, K = %d)", N, K);
     return IFX_EINVAL;
@@ -587,7 +681,7 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   // split K between two workgroups per tile when a workspace is given and the shape asks for it (gemm_pp_split: a function of N and K
   // only, so that a row's bits do not depend on how many rows the launch has)
-  const int ks = (workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
+  const int ks = (!q8 && workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
   const int total = tiles_m * tiles_n * ks, per_xcd = (total + 7) / 8;
   const int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
   const dim3 grid(wg_per_xcd * 8), block(512);
@@ -605,30 +699,35 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     if (e) trace = (unsigned long long*)strtoull(e, nullptr, 0);
   }
 #endif
-#define IFX_LAUNCH_PP(E, T, S)                                                                                                       \
+#define IFX_LAUNCH_PP(E, T, S, Q)                                                                                                    \
   do {                                                                                                                               \
     static bool attr_set = false;                                                                                                    \
     if (!attr_set) {                                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<E, T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);   \
+      (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<E, T, S, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES); \
       attr_set = true;                                                                                                               \
     }                                                                                                                                \
-    hipLaunchKernelGGL((gemm_pp_kernel<E, T, S>), grid, block, LDS_BYTES, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd,    \
+    hipLaunchKernelGGL((gemm_pp_kernel<E, T, S, Q>), grid, block, LDS_BYTES, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd, \
                        wg_per_xcd, ea, trace, dbg, ws_part, ws_flag);                                                                \
   } while (0)
-#define IFX_SWITCH_PP(T, S)                                              \
-  switch (mode) {                                                        \
-    case IFX_EPI_BIAS: IFX_LAUNCH_PP(IFX_EPI_BIAS, T, S); break;         \
-    case IFX_EPI_GELU_TANH: IFX_LAUNCH_PP(IFX_EPI_GELU_TANH, T, S); break; \
-    case IFX_EPI_RESIDUAL: IFX_LAUNCH_PP(IFX_EPI_RESIDUAL, T, S); break; \
-    case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T, S); break; \
-    default: return IFX_EINVAL;                                          \
+#define IFX_SWITCH_PP(T, S, Q)                                              \
+  switch (mode) {                                                           \
+    case IFX_EPI_BIAS: IFX_LAUNCH_PP(IFX_EPI_BIAS, T, S, Q); break;         \
+    case IFX_EPI_GELU_TANH: IFX_LAUNCH_PP(IFX_EPI_GELU_TANH, T, S, Q); break; \
+    case IFX_EPI_RESIDUAL: IFX_LAUNCH_PP(IFX_EPI_RESIDUAL, T, S, Q); break; \
+    case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T, S, Q); break; \
+    default: return IFX_EINVAL;                                             \
   }
-  if (ks == 2) {                                     // split K: the 256-token tile only (what long-K, narrow-N shapes want)
+  if (q8) {
+    if (tj == 4) { IFX_SWITCH_PP(4, 1, true) }
+    else if (tj == 3) { IFX_SWITCH_PP(3, 1, true) }
+    else if (tj == 2) { IFX_SWITCH_PP(2, 1, true) }
+    else return IFX_EINVAL;
+  } else if (ks == 2) {                              // split K: the 256-token tile only (what long-K, narrow-N shapes want)
     if (tj != 4) return IFX_EINVAL;
-    IFX_SWITCH_PP(4, 2)
-  } else if (tj == 4) { IFX_SWITCH_PP(4, 1) }
-  else if (tj == 3) { IFX_SWITCH_PP(3, 1) }
-  else if (tj == 2) { IFX_SWITCH_PP(2, 1) }
+    IFX_SWITCH_PP(4, 2, false)
+  } else if (tj == 4) { IFX_SWITCH_PP(4, 1, false) }
+  else if (tj == 3) { IFX_SWITCH_PP(3, 1, false) }
+  else if (tj == 2) { IFX_SWITCH_PP(2, 1, false) }
   else return IFX_EINVAL;
 #undef IFX_SWITCH_PP
 #undef IFX_LAUNCH_PP

@@ -592,6 +592,31 @@ extern "C" int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int3
   return check_launch("ifx_quant_per_token");
 }
 
+// the persistent ping-pong tile with e4m3 operands (ifx_gemm_pp.hip, Q8 instantiations)
+namespace ifx {
+int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
+                   int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
+                   int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16);
+}
+
+// Ping-pong tile for an FP8 launch (tokens = 64 tj), 0 = none: the model of pick_pp (ifx_gemm.hip) — a K-step moves the same bytes and
+// occupies the matrix pipe for the same cycles as a bf16 one, there are half as many of them.
+static int pick_pp_q8(int M, int N, int K, int mode) {
+  if (M < 2048 || N % 64 != 0 || K % 128 != 0) return 0;
+  static const float step_us[5] = {0.f, 0.f, 1.2f, 1.4f, 1.6f};
+  const float tile_us = (mode == IFX_EPI_GELU_TANH ? 8.f : 3.f);
+  int best = 0;
+  float best_t = 1e30f;
+  for (int tj = 4; tj >= 2; --tj) {
+    const int tiles = ((M + 64 * tj - 1) / (64 * tj)) * ((N + 255) / 256);
+    const int rounds = (tiles + 255) / 256;
+    const float t = rounds * ((K / 128) * step_us[tj] + tile_us);
+    if (t < best_t) best_t = t, best = tj;
+  }
+  return best;
+}
+
 static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
                         const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
                         int32_t format, const ifx_epilogue* epi, void* stream, const float* qdiv, int q_via_bf16) {
@@ -632,6 +657,18 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
   // large shapes: LDS-DMA tiles (256x256 with >= 2 rounds of tiles, else 256x128 when it fills the chip);
   // variant override through ifx_set_option("gemm_variant"): 1 = always the register-staged 128x128 kernel
   const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0) && K % 64 == 0;
+  // FP8 launches of >= 2048 rows: the ping-pong tile (gemm_variant 22 / 23 / 24 force its 256 / 192 / 128-token form, 3 = never)
+  if (format == IFX_Q_FP8_E4M3 && wide_ok && gemm_variant() != 1 && gemm_variant() != 2 && gemm_variant() != 3) {
+    const int v = gemm_variant();
+    int tj = v == 22 ? 4 : v == 23 ? 3 : v == 24 ? 2 : pick_pp_q8(M, N, K, mode);
+    if (mode == IFX_EPI_GATE_RES && ea.rows_per_group < 32 * tj) tj = ea.rows_per_group >= 64 ? 2 : 0;
+    const bool aligned = ((uintptr_t)bias & 7) == 0 && ((uintptr_t)ea.residual & 15) == 0 && ((uintptr_t)ea.mod & 15) == 0 &&
+                         ((uintptr_t)w_scale & 15) == 0 && ((uintptr_t)qdiv & 15) == 0 && ldx % 16 == 0 && N % 64 == 0 && K % 128 == 0;
+    if (tj != 0 && aligned)
+      return launch_gemm_pp((const unsigned short*)xp, ldx, (const unsigned short*)wp, y, ldy, M, N, K,
+                            mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj, nullptr, x_scale, w_scale, qdiv,
+                            q_via_bf16);
+  }
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     const int t = wgs(256, 256) >= 512 ? 2 : (wgs(256, 128) >= 224 ? 1 : 0);
