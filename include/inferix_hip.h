@@ -57,7 +57,11 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   21 = 256x192x64 (what 0 = auto picks where 192-wide columns fill the rounds better: the QKV projection),
  *                   22 / 23 / 24 = the persistent ping-pong tiles of ifx_gemm_pp.hip: 256 / 192 / 128 tokens x 256 channels (what 0 =
  *                   auto picks for launches of at least 2048 rows); 22 splits K over two workgroups per tile where N <= 2048 and
- *                   K >= 4096 when the caller gives a workspace (ifx_gemm_bf16_ws), 25 = 22 without that split
+ *                   K >= 4096 when the caller gives a workspace (ifx_gemm_bf16_ws), 25 = 22 without that split,
+ *                   26 = stream-K on the 128-token ping-pong tile (needs the ifx_gemm_workspace_bytes workspace; an experiment that
+ *                   lost to the tiles above at every size tried, kept for the lab: profiles/r3_gemm_pp.md).
+ *                   ifx_gemm_q8 reads the same option: 1 / 2 = register-staged 128x128 / 64-byte-row LDS-DMA tiles, 3 = the LDS-DMA
+ *                   tiles, never the ping-pong tile, 22 / 23 / 24 = the ping-pong tile with 256 / 192 / 128 tokens (FP8 only)
  *   "gemm_small_split": 1 lets the auto choice split K between the wave groups of one workgroup for launches of at most one workgroup
  *                   per CU (a sequence-parallel rank's 585 .. 2340 rows).  Off by default: those tiles sum K in a different order and
  *                   which launches get them depends on the row count, while the default auto choice keeps a row's bits independent

@@ -42,7 +42,7 @@ extern "C" int ifx_version(void) { return (0 << 16) | (IFX_ABI_MINOR << 8) | 0; 
 extern "C" const char* ifx_last_error(void) { return ifx::g_err; }
 extern "C" const char* ifx_arch(void) { return "gfx950"; }
 extern "C" int ifx_set_option(const char* key, int32_t value) {
-  if (key && !strcmp(key, "gemm_variant") && value >= 0 && value <= 25) { ifx::g_gemm_variant = value; return IFX_OK; }
+  if (key && !strcmp(key, "gemm_variant") && value >= 0 && value <= 26) { ifx::g_gemm_variant = value; return IFX_OK; }
   if (key && !strcmp(key, "gemm_small_split") && (value == 0 || value == 1)) { ifx::g_gemm_small_split = value; return IFX_OK; }
   if (key && !strcmp(key, "attn_variant") && value >= 0 && value <= 7) { ifx::g_attn_variant = value; return IFX_OK; }
   ifx::set_error("ifx_set_option: unknown key or value out of range: %s = %d", key ? key : "(null)", (int)value);

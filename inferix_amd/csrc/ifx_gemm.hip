@@ -191,7 +191,8 @@ size_t gemm_w4_workspace_bytes(int M, int N, int splits);
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa = nullptr,
-                   const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0);
+                   const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0, int stream_k = 0);
+size_t gemm_pp_stream_k_workspace_bytes();
 bool gemm_pp_split(int N, int K);
 size_t gemm_pp_workspace_bytes(int M, int N, int K);
 
@@ -335,6 +336,20 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
                           ea.rows_per_group, (hipStream_t)stream, 2, workspace);
   // persistent ping-pong tiles: 22 / 23 / 24 force the 256 / 192 / 128-token tile (25 = 256 without the K split), 0 = auto picks one for
   // launches of at least 2048 rows; the gate epilogue needs groups of at least a wave's token rows, the operands 16-byte rows
+  // stream-K on the 128-token ping-pong tile, meant for the shard-sized launches of a sequence-parallel rank (the K partition, hence the
+  // summation order of a row, depends on the row count of the launch).
+  // MEASURED AND NOT IN THE AUTO CHOICE (gemm_variant 26 only, profiles/r3_gemm_pp.md): at 585 rows a tile's K range is spread over 3-9
+  // workgroups and the owner's epilogue reads that many partial sums one memory latency after the other — 36 us against 19 us (QKV), 79
+  // against 37 us (FFN down) for the in-workgroup split tiles below.
+  if (wide_ok && variant == 26 && N % 64 == 0 && K % 64 == 0 && workspace != nullptr &&
+      workspace_bytes >= (int64_t)gemm_pp_stream_k_workspace_bytes() && (long)((M + 127) / 128) * ((N + 255) / 256) * (K / 64) >= 48) {
+    const bool res = mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES;
+    const bool fits = !((uintptr_t)bias & 7) && (!res || (!((uintptr_t)ea.residual & 15) && ea.ld_res % 8 == 0)) &&
+                      (mode != IFX_EPI_GATE_RES || (!((uintptr_t)ea.mod & 15) && ea.rows_per_group >= 64));
+    if (fits)
+      return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                            ea.rows_per_group, (hipStream_t)stream, 2, workspace, nullptr, nullptr, nullptr, 0, 1);
+  }
   if (wide_ok && (variant == 0 || (variant >= 22 && variant <= 25))) {
     const bool ws_ok = workspace != nullptr && workspace_bytes >= (int64_t)gemm_pp_workspace_bytes(M, N, K) && variant != 25;
     int tj = variant == 0 ? pick_pp(M, N, K, mode, ws_ok) : (variant == 22 || variant == 25 ? 4 : variant == 23 ? 3 : 2);
@@ -346,7 +361,7 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
                             ea.rows_per_group, (hipStream_t)stream, tj, ws_ok ? workspace : nullptr);
   }
   if (wide_ok && variant != 1) {
-    const int tile = (variant >= 2 && variant != 20) ? variant - 2 : pick_tile(M, N, K);
+    const int tile = (variant >= 2 && variant != 20 && variant != 26) ? variant - 2 : pick_tile(M, N, K);
     return launch_gemm_lds_dma(tile, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod,
                                ea.mod_slots, ea.gate_slot, ea.rows_per_group, (hipStream_t)stream);
   }
@@ -384,6 +399,7 @@ extern "C" int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int v = gemm_variant();
   if (v == 20) return want_w4_splitk(M, N, K) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
+  if (v == 26 && N % 64 == 0 && K % 64 == 0) return (int64_t)gemm_pp_stream_k_workspace_bytes();
   if ((v == 0 && N % 64 == 0 && K % 64 == 0 && !(gemm_small_split() && M < 2048)) || v == 22) return (int64_t)gemm_pp_workspace_bytes(M, N, K);
   return 0;
 }

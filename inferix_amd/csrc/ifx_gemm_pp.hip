@@ -90,7 +90,7 @@ __device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F);
 
 // one request cursor: K-step kt of tile i (the g-th K-step of this workgroup's stream), descriptor of that tile's operand rows
 struct Cursor {
-  int i, kt, g, rot, k0;     // k0: first K-step of the item inside the tile's K range (split-K)
+  int i, kt, g, rot, k0, len;     // k0 / len: first K-step and number of K-steps of the item inside the tile's K range (split-K, stream-K)
   v4i rs;
 };
 }  // namespace gpp
@@ -119,21 +119,48 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   constexpr int ES = Q8 ? 1 : 2;            // bytes per operand element
   const unsigned char* const xb = reinterpret_cast<const unsigned char*>(x);
   const unsigned char* const wb = reinterpret_cast<const unsigned char*>(w);
-  const int KT = K * ES / 128 / KS;         // K-steps (128 bytes of every operand row) of one work item
-  const int tiles_n = total / KS / tiles_m;
+  // KS = 0: STREAM-K.  The launch's K-steps (tiles x S, tile-major) are cut into gridDim.x equal contiguous ranges; a workgroup's range
+  // is the tail of one tile (K-steps k0 .. S: multiplied FIRST, accumulators dumped to the workgroup's slot of the workspace), whole
+  // tiles, and the head of one more tile (K-steps 0 .. k1: multiplied LAST; this workgroup owns that tile, adds the slots of the
+  // workgroups after it that hold the rest of the tile's K range — dumped long before, at the start of their runs — in ascending K
+  // order and runs the epilogue).  Nobody waits for a workgroup that waits.  The K partition depends on the row count of the launch:
+  // only callers that opted into that (ifx_set_option "gemm_small_split": the sequence-parallel shard sizes) get this path.
+  constexpr bool SK = KS == 0;
+  constexpr int KSD = KS > 0 ? KS : 1;
+  const int S = K * ES / 128;               // K-steps (128 bytes of every operand row) of a whole tile
+  const int KT = S / KSD;          // K-steps of one work item (stream-K: of a whole tile; items are shorter)
+  const int tiles_n = total / KSD / tiles_m;
 
   // ---- this workgroup's tiles: XCD (bid & 7) owns ids [xcd * per_xcd, ...); its wg_per_xcd workgroups take them round-robin, so the
   //      workgroups resident on one XCD always work on consecutive ids = a GM x (32 / GM) block of tiles sharing operand panels in L2
   const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
   const int id_first = xcd * per_xcd + slot_i;
   const int id_end = min(xcd * per_xcd + per_xcd, total);
-  if (id_first >= id_end) return;
-  const int n_my = (id_end - id_first + wg_per_xcd - 1) / wg_per_xcd;
-  const int G = n_my * KT;                  // K-steps of the whole request stream
-  auto item_split = [&](int i) __attribute__((always_inline)) { return KS > 1 ? (id_first + i * wg_per_xcd) % KS : 0; };
-  auto item_tile = [&](int i) __attribute__((always_inline)) { return (id_first + i * wg_per_xcd) / KS; };
+  if (!SK && id_first >= id_end) return;
+  // stream-K: workgroup sk_p of sk_P (the workgroups of one XCD hold neighbouring ranges), K-steps [sk_u0, sk_u1) of total * S
+  const int sk_P = (int)gridDim.x, sk_p = xcd * (sk_P >> 3) + slot_i;
+  auto sk_start = [&](int q) __attribute__((always_inline)) { return (int)((long)q * total * S / sk_P); };
+  const int sk_u0 = SK ? sk_start(sk_p) : 0, sk_u1 = SK ? sk_start(sk_p + 1) : 0;
+  const int sk_t0 = SK ? sk_u0 / S : 0;
+  const int n_my = SK ? (sk_u1 - 1) / S - sk_t0 + 1 : (id_end - id_first + wg_per_xcd - 1) / wg_per_xcd;
+  const int G = SK ? sk_u1 - sk_u0 : n_my * KT;       // K-steps of the whole request stream
+  auto item_split = [&](int i) __attribute__((always_inline)) { return KS > 1 ? (id_first + i * wg_per_xcd) % KSD : 0; };
+  auto item_tile = [&](int i) __attribute__((always_inline)) { return SK ? sk_t0 + i : (id_first + i * wg_per_xcd) / KSD; };
+  auto item_k0 = [&](int i) __attribute__((always_inline)) { return SK ? (i == 0 ? sk_u0 - sk_t0 * S : 0) : item_split(i) * KT; };
+  auto item_len = [&](int i) __attribute__((always_inline)) {
+    return SK ? min(S, sk_u1 - (sk_t0 + i) * S) - (i == 0 ? sk_u0 - sk_t0 * S : 0) : KT;
+  };
+  // an item whose accumulators go to the workspace instead of through the epilogue / the number of later partial sums its epilogue adds
+  auto item_dumps = [&](int i) __attribute__((always_inline)) { return SK ? (i == 0 && sk_u0 > sk_t0 * S) : (KS > 1 && item_split(i) == 1); };
+  auto item_parts = [&](int i) __attribute__((always_inline)) {
+    if (!SK) return KS > 1 ? 1 : 0;
+    const int t_end = (sk_t0 + i + 1) * S;            // first K-step of the next tile
+    int n = 0;
+    while (sk_p + 1 + n < sk_P && sk_start(sk_p + 1 + n) < t_end) ++n;
+    return sk_u1 < t_end ? n : 0;
+  };
   auto tile_base = [&](int i, int& m_base, int& n_base) __attribute__((always_inline)) {
-    const int t_id = (id_first + i * wg_per_xcd) / KS;
+    const int t_id = item_tile(i);
     const int grp_sz = GM * tiles_n;
     const int first_m = (t_id / grp_sz) * GM;
     const int gm = min(GM, tiles_m - first_m);
@@ -155,8 +182,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     int mb, nb;
     tile_base(c.i, mb, nb);
     if (dbg & 1) mb = nb = 0;                        // lab: every workgroup streams tile 0's operands (L2-hot), timing only
-    c.rot = (dbg & 4) ? ((nb / BN) * 3) % KT : 0;    // lab: K rotation by column tile
-    c.k0 = item_split(c.i) * KT;
+    c.rot = (!SK && (dbg & 4)) ? ((nb / BN) * 3) % KT : 0;    // lab: K rotation by column tile
+    c.k0 = item_k0(c.i);
+    c.len = item_len(c.i);
     if (grp == 0) c.rs = make_rsrc(wb + (size_t)nb * K * ES, (unsigned)min(((long)N - nb) * (long)K * ES, 0xffffffffL));
     else c.rs = make_rsrc(xb + (size_t)mb * ldx * ES, (unsigned)min(((long)M - mb - 1) * (long)ldx * ES + (long)K * ES, 0xffffffffL));
   };
@@ -166,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   };
   auto cur_next = [&](Cursor& c) __attribute__((always_inline)) {
     ++c.g;
-    if (++c.kt == KT) {
+    if (++c.kt == c.len) {
       c.kt = 0;
       if (++c.i < n_my) cur_desc(c);
     }
@@ -174,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   // `pieces` 1 KiB pieces of the cursor's K-step: rows row0 + (q * 4 + w4) * 8 ... of the tile's operand -> slot `slot` of its stage
   auto issue = [&](const Cursor& c, int slot, int row0, int pieces) __attribute__((always_inline)) {
     const int kk = c.kt + c.rot;
-    const int kb = ((kk >= KT ? kk - KT : kk) + c.k0) * 128;
+    const int kb = ((!SK && kk >= KT ? kk - KT : kk) + c.k0) * 128;
     const unsigned p = lds_piece0 + (c.g & 1) * STAGE + slot;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -268,8 +296,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   //      the workspace.  Write-through (sc1) stores on the producing side, sc1 loads on the consuming side, one flag per tile in between
   //      (raised once every wave of the producer has waited for its stores: vmcnt(0) + the workgroup barrier).
   const __amdgpu_buffer_rsrc_t rs_ws =
-      __builtin_amdgcn_make_buffer_rsrc((void*)ws_part, 0, KS > 1 ? (int)min((long)(total / KS) * BM * BN * 4L, 0x7fffffffL) : 0, 0x00020000);
-  auto part_soff = [&](int i) __attribute__((always_inline)) { return item_tile(i) * (BM * BN * 4) + wave * (TJ * 8192); };
+      __builtin_amdgcn_make_buffer_rsrc((void*)ws_part, 0,
+                                        KS != 1 ? (int)min((long)(SK ? sk_P : total / KSD) * BM * BN * 4L, 0x7fffffffL) : 0, 0x00020000);
+  // slot of the workspace an item dumps to / the first slot its epilogue reads: the tile's (split-K), the workgroup's (stream-K)
+  auto part_soff = [&](int i) __attribute__((always_inline)) { return (SK ? sk_p : item_tile(i)) * (BM * BN * 4) + wave * (TJ * 8192); };
+  auto flag_of = [&](int i) __attribute__((always_inline)) { return SK ? sk_p : item_tile(i); };
   auto dump_partial = [&](int i) __attribute__((always_inline)) {
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(ln));
@@ -285,12 +316,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         }
   };
   int flag_pending = 0;                              // 1 + tile whose partial this workgroup has dumped and not yet announced
-  auto consumer_sync = [&](int i) __attribute__((always_inline)) {              // all eight waves: the partner's partial is complete and visible
+  auto consumer_sync = [&](int i) __attribute__((always_inline)) {              // all eight waves: the partial sums the epilogue adds are complete and visible
+    const int first = SK ? sk_p + 1 : item_tile(i), n = item_parts(i);
     if (wave == 0) {
-      while (__hip_atomic_load(ws_flag + item_tile(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+      for (int q = 0; q < n; ++q)
+        while (__hip_atomic_load(ws_flag + first + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_s_barrier();
-    if (wave == 0) __hip_atomic_store(ws_flag + item_tile(i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as found: zero
+    if (wave == 0)
+      for (int q = 0; q < n; ++q) __hip_atomic_store(ws_flag + first + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as found: zero
   };
   auto epilogue = [&](int i_tile, auto between) __attribute__((always_inline)) {
     between();
@@ -299,7 +333,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     const int l31 = ln & 31, hi = ln >> 5, rr = ln >> 3, cc = ln & 7;
     int m_base, n_base;
     tile_base(i_tile, m_base, n_base);
-    const int part_so = KS > 1 ? part_soff(i_tile) : 0;
+    const int part_so = KS != 1 ? part_soff(i_tile) + (SK ? BM * BN * 4 : 0) : 0;      // stream-K: the slots of the workgroups after this one
+    const int part_n = KS != 1 ? item_parts(i_tile) : 0;
     const int e_n0 = min(n_base + w4 * 64, N - 64);   // a wave whose 64 channels lie past N (N % 64 == 0) fetches valid addresses, stores nothing
     const bool n_ok = n_base + w4 * 64 < N;
     const int e_m0 = m_base + grp * (32 * TJ);
@@ -388,6 +423,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024, part_so, 16));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += pq[e];
+          }
+          if constexpr (SK) {                          // the later K ranges of the tile, in ascending K order
+            for (int q = 0; q < part_n; ++q) {
+              const f32x4 pq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                             rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024, part_so + q * (BM * BN * 4), 16));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += pq[e];
+            }
           }
           if constexpr (Q8) {
 #pragma unroll
@@ -489,7 +532,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 
   // ---- the two role sequences.  Both execute 2 G + 1 barriers.  Segments of the trace: 0 barrier behind the MFMA phase, 1 DMA issue
   //      (+ fragment reads of the staggered waves), 2 epilogue, 3 fragment reads + waits, 4 barrier behind the loader phase, 5 MFMAs
-  int kt = 0, it = 0;                                // K-step within the tile / tile index of the K-step g being multiplied
+  int kt = 0, it = 0;                                // K-step within the item / item index of the K-step g being multiplied
+  int klen = item_len(0);
   if (grp == 0) {
     issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);          // W(0)
     wait_vm<0>();
@@ -500,17 +544,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       const bool epi = g > 0 && kt == 0;
       const bool issued = ca.g < G;
       const bool early_reads = reads_first && !epi;
-      if (epi && KS > 1 && item_split(it - 1) == 1) {
+      if (epi && KS != 1 && item_dumps(it - 1)) {
         // second K half: the accumulators go to the workspace, the partner finishes the tile
         if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
         PP_STAMP();
         dump_partial(it - 1);
         wait_vm<0>();
-        flag_pending = item_tile(it - 1) + 1;
+        flag_pending = flag_of(it - 1) + 1;
         PP_STAMP();
         read_frags();
       } else if (epi) {
-        if (KS > 1) consumer_sync(it - 1);
+        if (KS != 1) consumer_sync(it - 1);
         epilogue(it - 1, [&]() __attribute__((always_inline)) {
           if (issued) issue(ca, W_LO, 0, 4), issue(ca, W_HI, 128, 4), cur_next(ca);
           PP_STAMP();                                // 1: DMA issue
@@ -535,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- phase 2g: MFMA ----------------
       PP_STAMP();
-      if (KS > 1 && flag_pending) {                  // every wave waited for its dump before the barrier above
+      if (KS != 1 && flag_pending) {                  // every wave waited for its dump before the barrier above
         if (wave == 0) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag_pending = 0;
       }
@@ -543,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         if (kt == 0) mfma_first();
         else mfma_next();
       }
-      if (++kt == KT) kt = 0, ++it;
+      if (++kt == klen) kt = 0, ++it, klen = it < n_my ? item_len(it) : 0;
       wait_vm<0>();                                  // W(g+1) (requested one phase ago) landed for the next phase's readers
       __builtin_amdgcn_sched_barrier(0);
       PP_STAMP();
@@ -551,15 +595,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       __builtin_amdgcn_sched_barrier(0);
     }
     // phase 2G - 1: the last item, under group 1's last MFMAs
-    if (KS > 1 && item_split(it - 1) == 1) {
+    if (KS != 1 && item_dumps(it - 1)) {
       dump_partial(it - 1);
       wait_vm<0>();
-      flag_pending = item_tile(it - 1) + 1;
+      flag_pending = flag_of(it - 1) + 1;
     } else {
-      if (KS > 1) consumer_sync(it - 1);
+      if (KS != 1) consumer_sync(it - 1);
       epilogue(it - 1, [&]() __attribute__((always_inline)) {});
     }
-    if (KS > 1) {
+    if (KS != 1) {
       __builtin_amdgcn_s_barrier();                  // group 1's dump of the last item is complete as well
       if (flag_pending && wave == 0) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -606,22 +650,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         if (kt == 0) mfma_first();
         else mfma_next();
       }
-      if (++kt == KT) kt = 0, ++it;
+      if (++kt == klen) kt = 0, ++it, klen = it < n_my ? item_len(it) : 0;
       // x-lower(g+1) landed for this group's next phase: all but the x-upper(g+2) pieces behind it
       if (upper) wait_vm<TJ>();
       else wait_vm<0>();
       __builtin_amdgcn_sched_barrier(0);
       PP_STAMP();
       if (kt == 0) {                                 // K-step g closed item it - 1
-        if (KS > 1 && item_split(it - 1) == 1) {
+        if (KS != 1 && item_dumps(it - 1)) {
           dump_partial(it - 1);
           wait_vm<0>();
         } else {
-          if (KS > 1) consumer_sync(it - 1);
+          if (KS != 1) consumer_sync(it - 1);
           epilogue(it - 1, [&]() __attribute__((always_inline)) {});
         }
       }
-      if (g + 1 < G || KS > 1) {
+      if (g + 1 < G || KS != 1) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -639,6 +683,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 // Split K in two for long-K launches with few column tiles (the block's FFN down-projection, 1536 x 8960: 114 tiles of 256 x 256 for
 // 256 CUs).  Depends on (N, K) ONLY: a row's summation order must not change with the number of rows in the launch.
 bool gemm_pp_split(int N, int K) { return K >= 4096 && N <= 2048 && (K / 64) % 2 == 0; }
+// stream-K (128-token tile): one 128 KiB slot per workgroup behind the 4 KiB of flags
+size_t gemm_pp_stream_k_workspace_bytes() { return 4096 + (size_t)256 * 128 * 256 * 4; }
 size_t gemm_pp_workspace_bytes(int M, int N, int K) {
   if (!gemm_pp_split(N, K)) return 0;
   const size_t tiles = (size_t)((M + 255) / 256) * ((N + 255) / 256);
@@ -648,7 +694,7 @@ size_t gemm_pp_workspace_bytes(int M, int N, int K) {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16) {
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k) {
   using namespace gpp;
   const bool q8 = q8_sa != nullptr;                  // e4m3 operands: x / w point at bytes, ldx and K count elements = bytes
   EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, q8_sa, q8_sw, q8_qdiv, q8_via_bf16};
@@ -681,9 +727,18 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   // split K between two workgroups per tile when a workspace is given and the shape asks for it (gemm_pp_split: a function of N and K
   // only, so that a row's bits do not depend on how many rows the launch has)
-  const int ks = (!q8 && workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
-  const int total = tiles_m * tiles_n * ks, per_xcd = (total + 7) / 8;
-  const int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
+  const int ks = stream_k ? 0 : (!q8 && workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
+  const int total = tiles_m * tiles_n * (ks ? ks : 1), per_xcd = (total + 7) / 8;
+  int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
+  if (stream_k) {
+    // equal K-step ranges over as many workgroups as leave each at least six K-steps (a dump + a partial read cost about two)
+    const long units = (long)total * (K * (q8 ? 1 : 2) / 128);
+    if (q8 || tj != 2 || workspace == nullptr || units < 8) {
+      set_error("ifx_gemm_bf16: stream-K needs the bf16 128-token tile, a workspace and at least 8 K-steps");
+      return IFX_EINVAL;
+    }
+    wg_per_xcd = (int)max(1L, min((long)min(n_cu, 256) / 8, units / 6 / 8));
+  }
   const dim3 grid(wg_per_xcd * 8), block(512);
   unsigned* ws_flag = (unsigned*)workspace;          // the first 4096 bytes: zero on entry, zero on exit
   float* ws_part = workspace ? (float*)((char*)workspace + 4096) : nullptr;
@@ -722,6 +777,8 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     else if (tj == 3) { IFX_SWITCH_PP(3, 1, true) }
     else if (tj == 2) { IFX_SWITCH_PP(2, 1, true) }
     else return IFX_EINVAL;
+  } else if (ks == 0) {
+    IFX_SWITCH_PP(2, 0, false)
   } else if (ks == 2) {                              // split K: the 256-token tile only (what long-K, narrow-N shapes want)
     if (tj != 4) return IFX_EINVAL;
     IFX_SWITCH_PP(4, 2, false)

@@ -597,7 +597,7 @@ namespace ifx {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16);
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k);
 }
 
 // Ping-pong tile for an FP8 launch (tokens = 64 tj), 0 = none: the model of pick_pp (ifx_gemm.hip) — a K-step moves the same bytes and
@@ -667,7 +667,7 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
     if (tj != 0 && aligned)
       return launch_gemm_pp((const unsigned short*)xp, ldx, (const unsigned short*)wp, y, ldy, M, N, K,
                             mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj, nullptr, x_scale, w_scale, qdiv,
-                            q_via_bf16);
+                            q_via_bf16, 0);
   }
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };

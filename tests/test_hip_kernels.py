@@ -521,6 +521,31 @@ def test_gemm_ping_pong_split_k_is_deterministic_and_row_invariant(ops):
     assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-tile flags must be left zero"
 
 
+def test_gemm_stream_k_variant_is_correct_and_deterministic(ops):
+    """gemm_variant 26 (lab only: it lost to the in-workgroup split tiles at the shard sizes it was written for): equal K-step ranges
+    over the workgroups, the tile's owner adds the later ranges' partial sums in ascending K order.  Same values as the auto choice up
+    to the summation split, bit-identical run to run, flags left zero, every epilogue."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(17)
+    for M, N, K, kw_name in ((585, 4608, 1536, "bias"), (585, 1536, 8960, "gate"), (585, 8960, 1536, "gelu"), (1170, 1536, 1536, "res"),
+                             (300, 512, 1024, "bias")):
+        x, w, b = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))
+        res, mod = gpu(rnd(g, M, N)), gpu(rnd(g, 6, 6, N, scale=0.5))
+        kw = {"bias": {}, "gelu": dict(epilogue=_hip.IFX_EPI_GELU_TANH), "res": dict(epilogue=_hip.IFX_EPI_RESIDUAL, residual=res),
+              "gate": dict(epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=5, rows_per_group=195)}[kw_name]
+        want = ops.linear(x, w, b, **kw)
+        ops.set_option("gemm_variant", 26)
+        try:
+            outs = [ops.linear(x, w, b, **kw) for _ in range(3)]
+        finally:
+            ops.set_option("gemm_variant", 0)
+        assert all(torch.equal(o, outs[0]) for o in outs), (M, N, K)
+        assert_bf16_parity(outs[0], want, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what=f"stream-K {M}x{N}x{K} {kw_name}")
+    torch.cuda.synchronize()
+    for ws in ops._GEMM_WS.values():
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-workgroup flags must be left zero"
+
+
 def test_gemm_split_k_tiles_refuse_indivisible_k(ops):
     """A forced split-K tile on a K it cannot split evenly is an error, not a silently different kernel; the auto choice
     (variant 0) only picks those tiles when K divides."""
