@@ -30,6 +30,8 @@
 //     channels of one token), K order and the LDS-transposed epilogue are those of the other tiles: outputs are bit-identical.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ifx_common.h"
 
 #ifndef IFX_PP_TRACE
@@ -528,7 +530,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 #ifndef IFX_PP_STAGGER
 #define IFX_PP_STAGGER 0
 #endif
-  const bool reads_first = IFX_PP_STAGGER && (w4 & 1);     // (a run-time switch here costs 400 spilled registers: two definitions of the fragment set)
+  // (a run-time switch between the two placements INSIDE the loop costs 400 spilled registers — two definitions of the fragment set —
+  //  so the whole role sequence is instantiated twice and the wave picks its copy once)
+  auto roles = [&](auto stagger_tag) __attribute__((always_inline)) {
+  constexpr bool reads_first = decltype(stagger_tag)::value;
 
   // ---- the two role sequences.  Both execute 2 G + 1 barriers.  Segments of the trace: 0 barrier behind the MFMA phase, 1 DMA issue
   //      (+ fragment reads of the staggered waves), 2 epilogue, 3 fragment reads + waits, 4 barrier behind the loader phase, 5 MFMAs
@@ -671,6 +676,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       }
     }
   }
+  };
+  if (IFX_PP_STAGGER && (w4 & 1)) roles(std::true_type{});
+  else roles(std::false_type{});
 #if IFX_PP_TRACE
   if (trace != nullptr && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) {
 #pragma unroll
