@@ -218,11 +218,81 @@ class HipVideoDiTModel:
     @torch.no_grad()
     def forward(self, x, t, y, caption_dropout_mask=None, xattn_mask=None, kv_range=None,
                 inference_params: Optional[InferenceParams] = None, **kwargs) -> torch.Tensor:
+        if x.shape[0] > 1:
+            # a batch: only the unconditional pass of forward_3cfg has one (chunks turned into batch rows, no cache, dit_model.py:436-489).
+            # The layers run the cached path with batch 1; rows of a batch do not interact, so they go through one at a time — row b with
+            # its own timesteps, its captions (range_num = denoising ranges per row) and its key ranges rebased to the row.
+            if inference_params is not None:
+                raise NotImplementedError("HipVideoDiTModel.forward: a batch with a KV cache (the reference batches only forward_3cfg's "
+                                          "unconditional pass, inference_params=None)")
+            N, dn = x.shape[0], kwargs["denoising_range_num"]
+            rows = kv_range.shape[0] // N
+            drop = caption_dropout_mask.expand(N) if caption_dropout_mask.numel() == 1 else caption_dropout_mask
+            outs = []
+            for b in range(N):
+                kv = kv_range[b * rows:(b + 1) * rows]
+                outs.append(self.forward(x[b:b + 1], t[b:b + 1], y[b * dn:(b + 1) * dn], drop[b:b + 1], xattn_mask[b * dn:(b + 1) * dn],
+                                         kv - kv.min(), None, **kwargs))
+            return torch.cat(outs, dim=0)
         xs, condition, condition_map, y_flat, rope, meta = self.forward_pre_process(x, t, y, caption_dropout_mask, xattn_mask, kv_range, **kwargs)
         hs = self.videodit_blocks(xs.clone(), condition, condition_map, y_flat, rope, inference_params, meta)
         return self.forward_post_process(hs, meta)
 
     __call__ = forward
+
+    @torch.no_grad()
+    def forward_3cfg(self, x, timestep, y, mask, kv_range, inference_params, **kwargs):
+        """dit_model.py:399-492: the three forwards of classifier-free guidance — (previous chunks + text) WITHOUT touching the cache,
+        (previous chunks, null caption) which writes it, and the unconditional one: the denoising chunks as batch rows that see only
+        themselves, no cache.  -> (out_cond_pre_and_text, out_cond_pre, out_uncond, denoise_width)."""
+        assert x.shape[0] == 2 and mask.shape[0] % 2 == 0
+        x = torch.cat([x[0:1], x[0:1]], dim=0)
+        half = y.shape[0] // 2
+        drop = torch.tensor([False, True], dtype=torch.bool, device=x.device)
+        kwargs = dict(kwargs)
+        inference_params.update_kv_cache = False
+        out_text = self.forward(x[0:1], timestep[0:1], y[0:half], caption_dropout_mask=drop[0:1], xattn_mask=mask[0:half],
+                                kv_range=kv_range, inference_params=inference_params, **kwargs)
+        inference_params.update_kv_cache = True
+        out_pre = self.forward(x[1:2], timestep[1:2], y[half:], caption_dropout_mask=drop[1:2], xattn_mask=mask[half:],
+                               kv_range=kv_range, inference_params=inference_params, **kwargs)
+        cw = kwargs["chunk_width"]
+        dn = kwargs["denoising_range_num"] - (1 if kwargs.get("fwd_extra_1st_chunk", False) else 0)     # UnconditionGuard (:448-469)
+        denoise_width = cw * dn
+        u = x[0:1, :, -denoise_width:].squeeze(0)
+        uncond_x = u.reshape(-1, dn, cw, *u.shape[2:]).transpose(0, 1)                                   # chunk_to_batch: [dn, C, cw, H, W]
+        ukw = dict(kwargs, range_num=1, denoising_range_num=1, slice_point=0, fwd_extra_1st_chunk=False)
+        out_uncond = self.forward(uncond_x, timestep[0:1, -dn:].transpose(0, 1), y[half:][-dn:],
+                                  caption_dropout_mask=torch.tensor([True], dtype=torch.bool, device=x.device), xattn_mask=mask[half:][-dn:],
+                                  kv_range=self.generate_kv_range_for_uncondition(uncond_x), inference_params=None, **ukw)
+        o = out_uncond.transpose(0, 1)
+        out_uncond = o.reshape(1, -1, dn * cw, *o.shape[3:])                                             # batch_to_chunk
+        return out_text, out_pre, out_uncond, denoise_width
+
+    def _dispatch_3cfg(self, x, timestep, y, mask, kv_range, inference_params, **kwargs) -> torch.Tensor:
+        """dit_model.py:500-535: per denoising chunk, scales looked up by its timestep in `cfg_t_range`:
+        (1 - s_prev) uncond + (s_prev - s_text) cond_pre + s_text cond_pre_and_text."""
+        rc = self.runtime_config
+        out_text, out_pre, out_uncond, denoise_width = self.forward_3cfg(x, timestep, y, mask, kv_range, inference_params, **kwargs)
+        dev = out_text.device
+        prev_s = torch.tensor(rc.prev_chunk_scales, device=dev)
+        text_s = torch.tensor(rc.text_scales, device=dev)
+        t_range = torch.tensor(rc.cfg_t_range, device=dev)
+        assert len(prev_s) == len(t_range) and len(text_s) == len(t_range), "prev_chunk_scales / text_scales and cfg_t_range differ in length"
+        n, cw = kwargs["denoising_range_num"], kwargs["chunk_width"]
+        if kwargs["fwd_extra_1st_chunk"]:
+            n -= 1
+        cfg_t = timestep[0, -n:].to(dev)
+        pieces = []
+        for ci in range(n):
+            idx = torch.searchsorted(t_range - 1e-7, cfg_t[ci]) - 1                                       # get_cfg_scale (:494-497)
+            assert 0 <= int(idx) < len(prev_s)
+            sp, st = prev_s[idx], text_s[idx]
+            sl = slice(ci * cw, (ci + 1) * cw)
+            pieces.append((1 - sp) * out_uncond[:, :, sl] + (sp - st) * out_pre[:, :, -denoise_width:][:, :, sl]
+                          + st * out_text[:, :, -denoise_width:][:, :, sl])
+        x = torch.cat([x[0:1, :, :-denoise_width].to(dev), torch.cat(pieces, dim=2)], dim=2)
+        return torch.cat([x, x], dim=0)
 
     def generate_kv_range_for_uncondition(self, uncond_x: torch.Tensor) -> torch.Tensor:
         """dit_model.py:91-100: one self-contained key range per batch row of `uncond_x`."""
@@ -238,9 +308,11 @@ class HipVideoDiTModel:
         results are blended `prev_chunks_scale : 1 - prev_chunks_scale` (env `prev_chunks_scale`, 0.7)."""
         import os
         rc = self.runtime_config
+        if rc is not None and getattr(rc, "cfg_number", None) == 3:
+            return self._dispatch_3cfg(x, timestep, y, mask, kv_range, inference_params, **kwargs)
         if rc is None or getattr(rc, "cfg_number", None) != 1:
-            raise NotImplementedError("HipVideoDiTModel.forward_dispatcher: only runtime_config.cfg_number == 1 (distilled MAGI) is built; "
-                                      "the 3-way guidance batch (cfg_number == 3) is not")
+            raise NotImplementedError("HipVideoDiTModel.forward_dispatcher: runtime_config.cfg_number must be 1 (distilled checkpoints) or 3 "
+                                      "(the reference's own NotImplementedError for anything else, dit_model.py:596)")
         assert x.shape[0] == 2
         x = torch.cat([x[0:1], x[0:1]], dim=0)
         kwargs = dict(kwargs)

@@ -71,7 +71,8 @@ def calls(cfg: MM.MagiModelConfig, seed: int):
     return out, clip
 
 
-def run_reference(cfg: MM.MagiModelConfig, cs, max_tokens: int):
+def build_reference(cfg: MM.MagiModelConfig, max_tokens: int):
+    """-> (the reference's VideoDiTModel with the seeded weights, a factory of fresh InferenceParams with an empty CPU KV cache)."""
     dm = _refstub.import_magi_dit()
     torch.cuda.current_device = lambda: "cpu"
     M = importlib.import_module("inferix.models.magi.dit.dit_model")
@@ -114,11 +115,22 @@ def run_reference(cfg: MM.MagiModelConfig, cs, max_tokens: int):
         with fp32_autocast():
             return post0(*a, **k)
     model.forward_pre_process, model.forward_post_process = pre1, post1
-    ip = object.__new__(types.InferenceParams)
-    ip.max_sequence_length, ip.max_batch_size, ip.sequence_len_offset = max_tokens, 1, 0
-    ip.kv_cache_request = kvm.KVCacheRequest(request_id="magi")
-    ip.kv_cache_manager = kvm.KVCacheManager(device="cpu")
-    ip.key_value_memory_dict, ip.update_kv_cache = {}, False
+    count = [0]
+
+    def make_ip():
+        ip = object.__new__(types.InferenceParams)
+        ip.max_sequence_length, ip.max_batch_size, ip.sequence_len_offset = max_tokens, 1, 0
+        count[0] += 1
+        ip.kv_cache_request = kvm.KVCacheRequest(request_id=f"magi{count[0]}")
+        ip.kv_cache_manager = kvm.KVCacheManager(device="cpu")
+        ip.key_value_memory_dict, ip.update_kv_cache = {}, False
+        return ip
+    return model, make_ip
+
+
+def run_reference(cfg: MM.MagiModelConfig, cs, max_tokens: int):
+    model, make_ip = build_reference(cfg, max_tokens)
+    ip = make_ip()
     outs, pres = [], []
     for c in cs:
         kw = dict(c["kw"])
