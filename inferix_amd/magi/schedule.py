@@ -10,8 +10,8 @@ Host mirror of the planning half of `SampleTransport` (inferix/pipeline/magi/vid
   integrate                                  :531-552   x += v * (t[i + 1] - t[i]) per chunk
 
 Pure integer / small-tensor work on the host: `ChunkSchedule.plan(step)` is everything `forward_velocity` computes before it calls the
-model, `ChunkSchedule.run(model, ...)` is the reference's forward_velocity + integrate_velocity loop for one clip without a prefix
-video (cfg_number = 1 dispatch).  tests/test_magi_schedule.py checks plans, timesteps and key ranges against a golden the reference's
+model, `ChunkSchedule.run(model, ...)` is the reference's forward_velocity + integrate_velocity loop for one clip, with or without a
+prefix video (`extract_prefix_video_feature` / `try_pad_prefix_video`, :391-454).  tests/test_magi_schedule.py checks plans, timesteps and key ranges against a golden the reference's
 own methods produced for every step of the 4.5B distill configuration.
 """
 from __future__ import annotations
@@ -121,15 +121,38 @@ class ChunkSchedule:
         return generate_kvrange_for_denoising_video(tokens, plan.slice_point, plan.denoising_range_num, plan.denoise_step_of_each_chunk,
                                                     self.num_steps, noise2clean_kvrange, clean_chunk_kvrange, 1, device)
 
+    def extract_prefix_video_feature(self, model, prefix_video, y, emb_masks, inference_params, tokens: int, distill_interval) -> None:
+        """One forward over the prefix video's whole chunks for the sake of its KV-cache writes (:391-435)."""
+        from .kv_ranges import generate_kvrange_for_prefix_video
+        rc, off, cw = model.runtime_config, self.chunk_offset, self.chunk_width
+        xc = prefix_video[:, :, :off * cw]
+        if xc.shape[0] == 1:
+            xc = torch.cat([xc, xc], 0)
+        null_y = torch.cat([y[1:2, :off], y[1:2, :off]], 0)                   # clean feature without y embedding
+        null_m = torch.cat([emb_masks[1:2, :off], emb_masks[1:2, :off]], 0)
+        t = (torch.ones(off, device=xc.device) * rc.clean_t).unsqueeze(0).repeat(xc.size(0), 1)
+        kv = generate_kvrange_for_prefix_video(tokens, off, rc.noise2clean_kvrange, rc.clean_chunk_kvrange, 1, xc.device)
+        model.forward_dispatcher(x=xc, timestep=t, y=null_y.flatten(0, 1).unsqueeze(1), mask=null_m.flatten(0, 1).unsqueeze(1), kv_range=kv,
+                                 inference_params=inference_params, chunk_width=cw, num_steps=self.num_steps, slice_point=0, range_num=off,
+                                 denoising_range_num=off, fwd_extra_1st_chunk=False, extract_prefix_video_feature=True,
+                                 distill_interval=distill_interval)
+
     # ---- the loop -------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, model, x: torch.Tensor, y: torch.Tensor, emb_masks: torch.Tensor, inference_params, t_schedule_config=None,
-            steps: Optional[Sequence[int]] = None, on_forward=None) -> torch.Tensor:
-        """forward_velocity + integrate_velocity for every step (or the listed `steps`) of one clip without a prefix video.
+            steps: Optional[Sequence[int]] = None, on_forward=None, prefix_video: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """forward_velocity + integrate_velocity for every step (or the listed `steps`) of one clip.
         x `[2 N, C, T, H, W]` noise (both halves equal, as upstream's `torch.cat([x, x])`), y `[2, chunk_num, L, C]` caption
-        embeddings (row 1: the null caption), emb_masks `[2, chunk_num, L]`.  Returns x denoised in place."""
+        embeddings (row 1: the null caption), emb_masks `[2, chunk_num, L]`.  `prefix_video` `[2 N, C, Tp, H, W]` clean latents in front
+        (image / video continuation; the schedule must have been built with `chunk_offset = Tp // chunk_width`): its whole chunks go
+        through the model once, at clean_t with the null caption, to fill the KV cache (`extract_prefix_video_feature`, :391-435), and
+        every forward has the prefix frames it overlaps pasted over its noise at t = 1 (`try_pad_prefix_video`, :437-454).
+        Returns x denoised in place."""
         rc, ec, mc = model.runtime_config, model.engine_config, model.model_config
         dev = x.device
+        if (prefix_video.size(2) // self.chunk_width if prefix_video is not None else 0) != self.chunk_offset:
+            raise ValueError(f"the schedule was built for chunk_offset {self.chunk_offset}, the prefix video holds "
+                             f"{0 if prefix_video is None else prefix_video.size(2) // self.chunk_width} whole chunks")
         shortcut = getattr(ec, "shortcut_mode", "")
         t_total = init_t(t_schedule_config or {}, self.num_steps, dev, shortcut)
         interval = init_interval(self.num_steps, dev, shortcut)
@@ -143,8 +166,18 @@ class ChunkSchedule:
                 xc = torch.cat([x[:, :, (p.chunk_start - 1) * cw: p.chunk_start * cw].clone(), xc], dim=2)
                 yc = torch.cat([y[1:2, 0:1].expand(yc.size(0), -1, -1, -1), yc], dim=1)          # clean feature without y embedding
                 mk = torch.cat([emb_masks[1:2, 1:2].expand(mk.size(0), -1, -1), mk], dim=1)
+            if self.chunk_offset > 0 and step == 0:
+                self.extract_prefix_video_feature(model, prefix_video, y, emb_masks, inference_params, tokens, interval[0])
             t = self.timestep(t_total, p, rc.clean_t).unsqueeze(0).repeat(xc.size(0), 1)
             kv = self.kv_range(p, tokens, rc.noise2clean_kvrange, rc.clean_chunk_kvrange, dev)
+            if prefix_video is not None:                                      # try_pad_prefix_video
+                start = p.slice_point * cw
+                if prefix_video.size(2) > start:
+                    n = min(prefix_video.size(2) - start, xc.size(2))
+                    xc[:, :, :n] = prefix_video[:, :, start:start + n]
+                    clean = (prefix_video.size(2) - start) // cw
+                    if clean > 0:
+                        t[:, :clean] = 1.0
             nearly_clean_t = t[0, int(p.fwd_extra_1st_chunk)].item()
             kwargs = dict(chunk_width=cw, fwd_extra_1st_chunk=p.fwd_extra_1st_chunk, num_steps=self.num_steps, slice_point=p.slice_point,
                           range_num=p.range_num, denoising_range_num=p.denoising_range_num,

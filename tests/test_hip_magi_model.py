@@ -125,7 +125,7 @@ class _OracleModel:
                           cu_seqlens_q=meta["cu_seqlens_q"].tolist(), cu_seqlens_kv=meta["cu_seqlens_kv"].tolist(),
                           clip_token_nums=meta["clip_token_nums"], slice_point=kw["slice_point"],
                           update_kv_cache=bool(inference_params.update_kv_cache),
-                          use_cache=bool(kw["fwd_extra_1st_chunk"]) or kw["slice_point"] > 0,
+                          use_cache=bool(kw["fwd_extra_1st_chunk"]) or kw["slice_point"] > 0 or bool(kw.get("extract_prefix_video_feature", False)),
                           distill_nearly_clean_chunk=bool(kw.get("distill_nearly_clean_chunk", False)))
         h = xs
         for W, cache in zip(self.Ws, self.caches):
@@ -176,6 +176,18 @@ def test_chunk_schedule_rollout_vs_oracle_model():
     r = rel_l2(got - x, want - x)
     print(f"magi schedule rollout: 12 forwards, |x_final - x_noise| / |x_noise| = {moved:.3f}; HIP vs oracle on x_final - x_noise: {r:.3e}")
     assert r < 1e-2, r            # measured 3.3e-3
+    # video continuation: a prefix of one whole chunk + one frame (extraction pass into the cache, the frame pasted over chunk 1's noise)
+    prefix = torch.randn(1, cfg.in_channels, cw + 1, Hl, Wl, generator=g).repeat(2, 1, 1, 1, 1)
+    sch_p = ChunkSchedule(8, 4, chunk_num, cw, chunk_offset=1)
+    om_p = _OracleModel(cfg, EW, Ws, config, chunk_num * tokens)
+    want_p = sch_p.run(om_p, x.clone(), y, masks, SimpleNamespace(update_kv_cache=False), prefix_video=prefix)
+    model_p = HipVideoDiTModel(config, "cuda")
+    model_p.load_state_dict(sd)
+    got_p = sch_p.run(model_p, x.clone().cuda(), y.cuda(), masks.cuda(), InferenceParams(1, chunk_num * tokens), prefix_video=prefix.cuda()).cpu()
+    assert torch.equal(got_p[:, :, :cw], x[:, :, :cw]) and torch.isfinite(got_p).all()
+    rp = rel_l2(got_p[:, :, cw:] - x[:, :, cw:], want_p[:, :, cw:] - x[:, :, cw:])
+    print(f"magi schedule rollout behind a prefix video: {sch_p.total_forward_step()} + 1 forwards; HIP vs oracle on x_final - x_noise: {rp:.3e}")
+    assert rp < 1e-2, rp
     config.runtime_config.cfg_number = 2            # 1 and 3 are built; the reference raises for everything else as well
     with pytest.raises(NotImplementedError):
         model.forward_dispatcher(x=x.cuda(), timestep=None, y=None, mask=None, kv_range=None, inference_params=None)

@@ -94,3 +94,46 @@ def test_run_loop_walks_every_chunk_from_noise_to_clean():
     # the nearly-clean flag follows the oldest denoising chunk's time
     for shape, t, ys, ms, kv, kw in m.calls:
         assert kw["distill_nearly_clean_chunk"] == (t[0, int(kw["fwd_extra_1st_chunk"])].item() > 0.3)
+
+
+def test_run_loop_with_a_prefix_video():
+    """Video continuation (one whole prefix chunk) and image-to-video (one prefix frame): the prefix chunks go through the model once at
+    clean_t with the null caption and `extract_prefix_video_feature`; afterwards every forward that overlaps prefix frames carries them
+    instead of its noise, at t = 1 where a whole chunk is covered (video_generate.py:391-454)."""
+    from inferix_amd.magi import schedule as S
+    import pytest
+    cw = 2
+    x0 = torch.randn(1, 16, 8, 4, 6)
+    x = torch.cat([x0, x0], 0)
+    y = torch.randn(2, 4, 5, 8)
+    masks = torch.ones(2, 4, 5)
+    prefix = torch.full((2, 16, 2, 4, 6), 7.0)
+    m = _Recorder()
+    kept = []
+    orig = m.forward_dispatcher
+    m.forward_dispatcher = lambda **kw: (kept.append(kw["x"].clone()), orig(**kw))[1]
+    sch = S.ChunkSchedule(8, 4, 4, cw, chunk_offset=1)
+    out = sch.run(m, x.clone(), y, masks, inference_params=None, prefix_video=prefix)
+    assert len(m.calls) == 1 + sch.total_forward_step() == 1 + 2 * 6
+    shape, t, ys, ms, kv, kw = m.calls[0]                              # the extraction pass
+    assert kw["extract_prefix_video_feature"] and kw["denoising_range_num"] == kw["range_num"] == 1 and kw["slice_point"] == 0
+    assert shape == (2, 16, 2, 4, 6) and torch.all(kept[0] == 7.0) and torch.allclose(t, torch.full((2, 1), 0.9999))
+    assert kv.tolist() == [[0, cw * 2 * 3]]
+    # stage 0 of a schedule with offset 1 denoises chunk 1 only; nothing overlaps the prefix until a clean chunk 0 would be needed — it is
+    # never re-forwarded (chunk_start > chunk_offset is what asks for the extra chunk): no later forward holds prefix frames
+    assert all(not torch.any(k == 7.0) for k in kept[1:])
+    assert all(c[5]["slice_point"] >= 1 for c in m.calls[1:])
+    assert torch.equal(out[:, :, :cw], x[:, :, :cw]), "the prefix chunk's noise is not touched"
+    assert torch.allclose(out[:, :, cw:], x[:, :, cw:] + 1.0, atol=1e-5)
+    with pytest.raises(ValueError):
+        S.ChunkSchedule(8, 4, 4, cw).run(m, x.clone(), y, masks, inference_params=None, prefix_video=prefix)
+    # image-to-video: a single prefix frame, no whole chunk -> no extraction pass, the frame is pasted into every forward of chunk 0
+    m2, kept2 = _Recorder(), []
+    orig2 = m2.forward_dispatcher
+    m2.forward_dispatcher = lambda **kw: (kept2.append((kw["x"].clone(), kw["timestep"].clone(), kw["slice_point"])), orig2(**kw))[1]
+    sch2 = S.ChunkSchedule(8, 4, 4, cw)
+    sch2.run(m2, x.clone(), y, masks, inference_params=None, prefix_video=prefix[:, :, :1])
+    assert len(kept2) == sch2.total_forward_step()
+    for xk, tk, sp in kept2:
+        assert bool(torch.all(xk[:, :, 0] == 7.0)) == (sp == 0) and not torch.any(xk[:, :, 1:] == 7.0)
+        assert not torch.any(tk == 1.0)                                # half a chunk is not a clean chunk
