@@ -690,7 +690,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 
 // Split K in two for long-K launches with few column tiles (the block's FFN down-projection, 1536 x 8960: 114 tiles of 256 x 256 for
 // 256 CUs).  Depends on (N, K) ONLY: a row's summation order must not change with the number of rows in the launch.
-bool gemm_pp_split(int N, int K) { return K >= 4096 && N <= 2048 && (K / 64) % 2 == 0; }
+bool gemm_pp_split(int N, int K) {
+  static int min_k = -1;
+  if (min_k < 0) {
+    const char* e = getenv("IFX_PP_SPLIT_MIN_K");      // lab: where the two-workgroup split starts to pay
+    min_k = e ? atoi(e) : 4096;
+  }
+  return K >= min_k && N <= 2048 && (K / 64) % 2 == 0;
+}
 // stream-K (128-token tile): one 128 KiB slot per workgroup behind the 4 KiB of flags
 size_t gemm_pp_stream_k_workspace_bytes() { return 4096 + (size_t)256 * 128 * 256 * 4; }
 size_t gemm_pp_workspace_bytes(int M, int N, int K) {
