@@ -302,8 +302,8 @@ def quant_leg(fmt, gen, clip):
         tf = gq["flops"] / (gq["ms"] * 1e-3) / 1e12
         return {"workload": f"config 4: Self-Forcing 480p clip, {qc.name} linears + bf16 attention", "clips_run": 2,
                 "ms_per_clip": round(ms, 1), "latent_frames_per_s": round(FRAMES / ms * 1e3, 3),
-                "roofline": {"kernel": ("ifx::gemm_pp_kernel<.., Q8> (e4m3 operands on the persistent ping-pong tile" if fmt == "fp8" else
-                                        "ifx::gemm_q8_dma_kernel (int8 MFMA") + ", per-token x per-channel dequant epilogue)", "bound": "mfma",
+                "roofline": {"kernel": f"ifx::gemm_pp_kernel<.., Q8> ({'e4m3' if fmt == 'fp8' else 'int8'} operands on the persistent ping-pong tile, "
+                                       "per-token x per-channel dequant epilogue)", "bound": "mfma",
                              "achieved": round(tf, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP8_TFLOPS, 4),
                              "traffic": None, "launches": gq["launches"], "avg_launch_ms": round(gq["ms"] / gq["launches"], 4)},
                 "quantiser_gbps": round(qa["bytes"] / (qa["ms"] * 1e-3) / 1e9, 1) if qa["ms"] else None,

@@ -61,7 +61,7 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   26 = stream-K on the 128-token ping-pong tile (needs the ifx_gemm_workspace_bytes workspace; an experiment that
  *                   lost to the tiles above at every size tried, kept for the lab: profiles/r3_gemm_pp.md).
  *                   ifx_gemm_q8 reads the same option: 1 / 2 = register-staged 128x128 / 64-byte-row LDS-DMA tiles, 3 = the LDS-DMA
- *                   tiles, never the ping-pong tile, 22 / 23 / 24 = the ping-pong tile with 256 / 192 / 128 tokens (FP8 only)
+ *                   tiles, never the ping-pong tile, 22 / 23 / 24 = the ping-pong tile with 256 / 192 / 128 tokens (FP8 and INT8)
  *   "gemm_small_split": 1 lets the auto choice split K between the wave groups of one workgroup for launches of at most one workgroup
  *                   per CU (a sequence-parallel rank's 585 .. 2340 rows).  Off by default: those tiles sum K in a different order and
  *                   which launches get them depends on the row count, while the default auto choice keeps a row's bits independent

@@ -191,7 +191,7 @@ size_t gemm_w4_workspace_bytes(int M, int N, int splits);
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa = nullptr,
-                   const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0, int stream_k = 0);
+                   const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0, int stream_k = 0, int q8_int8 = 0);
 size_t gemm_pp_stream_k_workspace_bytes();
 bool gemm_pp_split(int N, int K);
 size_t gemm_pp_workspace_bytes(int M, int N, int K);

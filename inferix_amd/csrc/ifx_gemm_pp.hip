@@ -61,6 +61,7 @@ constexpr int LDS_BYTES = SCRATCH + 32768;
 constexpr int X_UP = 0, W_LO = SLOT, W_HI = 2 * SLOT, X_DN = 3 * SLOT;  // slots of a stage
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, int voff, int soff) {
@@ -101,7 +102,9 @@ struct Cursor {
 // unit block scales per accumulator and K-step in place of four v_mfma_f32_32x32x16_bf16 — the same 1024 matrix-pipe cycles per phase for
 // twice the arithmetic — and the dequantisation acc * (sa[m] * sw[n]) in the epilogue (ifx_gemm_q8's contract).  The K order inside a
 // fragment is whatever the hardware uses: both operands are read with the same lane -> byte map.
-template <int EPI, int TJ, int KS, bool Q8 = false>
+// Q8 = 2: int8 operands, four v_mfma_i32_32x32x32_i8 per accumulator and K-step (the bf16 loop with another instruction; exact int32 sums kept
+// as bit patterns in the accumulator registers), the same dequantising epilogue.
+template <int EPI, int TJ, int KS, int Q8 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* __restrict__ x, int ldx,
                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
                                                          int ldy, int M, int N, int K, int tiles_m, int total, int per_xcd,
@@ -241,9 +244,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     const v8i b = __builtin_shufflevector(__builtin_bit_cast(v4i, fx[2 * kk][j]), __builtin_bit_cast(v4i, fx[2 * kk + 1][j]), 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
   };
+  auto i8_mfma = [&](int ks, int i, int j, const f32x16 c) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(v4i, fw[ks][i]), __builtin_bit_cast(v4i, fx[ks][j]),
+                                                                            __builtin_bit_cast(v16i, c), 0, 0, 0));
+  };
   auto mfma_first = [&]() __attribute__((always_inline)) {                          // first K-step of a tile: the accumulators start from zero
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (Q8) {
+    if constexpr (Q8 == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = i8_mfma(ks, i, j, ks == 0 ? z : acc[i][j]);
+      return;
+    }
+    if constexpr (Q8 == 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -266,7 +282,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
   };
   auto mfma_next = [&]() __attribute__((always_inline)) {
-    if constexpr (Q8) {
+    if constexpr (Q8 == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = i8_mfma(ks, i, j, acc[i][j]);
+      return;
+    }
+    if constexpr (Q8 == 1) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -418,6 +443,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if constexpr (Q8 == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)__builtin_bit_cast(int, v[e]);                  // the exact int32 sum
+          }
           if constexpr (KS > 1) {
             // + the partner's partial sums of the second K half, read where the accumulators are consumed (writing them back into
             // the accumulator vectors first costs hipcc ~300 spilled registers): first half + second half, then the bias
@@ -709,7 +738,7 @@ size_t gemm_pp_workspace_bytes(int M, int N, int K) {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k) {
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8) {
   using namespace gpp;
   const bool q8 = q8_sa != nullptr;                  // e4m3 operands: x / w point at bytes, ldx and K count elements = bytes
   EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, q8_sa, q8_sw, q8_qdiv, q8_via_bf16};
@@ -787,19 +816,24 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T, S, Q); break; \
     default: return IFX_EINVAL;                                             \
   }
-  if (q8) {
-    if (tj == 4) { IFX_SWITCH_PP(4, 1, true) }
-    else if (tj == 3) { IFX_SWITCH_PP(3, 1, true) }
-    else if (tj == 2) { IFX_SWITCH_PP(2, 1, true) }
+  if (q8 && q8_int8) {
+    if (tj == 4) { IFX_SWITCH_PP(4, 1, 2) }
+    else if (tj == 3) { IFX_SWITCH_PP(3, 1, 2) }
+    else if (tj == 2) { IFX_SWITCH_PP(2, 1, 2) }
+    else return IFX_EINVAL;
+  } else if (q8) {
+    if (tj == 4) { IFX_SWITCH_PP(4, 1, 1) }
+    else if (tj == 3) { IFX_SWITCH_PP(3, 1, 1) }
+    else if (tj == 2) { IFX_SWITCH_PP(2, 1, 1) }
     else return IFX_EINVAL;
   } else if (ks == 0) {
-    IFX_SWITCH_PP(2, 0, false)
+    IFX_SWITCH_PP(2, 0, 0)
   } else if (ks == 2) {                              // split K: the 256-token tile only (what long-K, narrow-N shapes want)
     if (tj != 4) return IFX_EINVAL;
-    IFX_SWITCH_PP(4, 2, false)
-  } else if (tj == 4) { IFX_SWITCH_PP(4, 1, false) }
-  else if (tj == 3) { IFX_SWITCH_PP(3, 1, false) }
-  else if (tj == 2) { IFX_SWITCH_PP(2, 1, false) }
+    IFX_SWITCH_PP(4, 2, 0)
+  } else if (tj == 4) { IFX_SWITCH_PP(4, 1, 0) }
+  else if (tj == 3) { IFX_SWITCH_PP(3, 1, 0) }
+  else if (tj == 2) { IFX_SWITCH_PP(2, 1, 0) }
   else return IFX_EINVAL;
 #undef IFX_SWITCH_PP
 #undef IFX_LAUNCH_PP

@@ -597,7 +597,7 @@ namespace ifx {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k);
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8);
 }
 
 // Ping-pong tile for an FP8 launch (tokens = 64 tj), 0 = none: the model of pick_pp (ifx_gemm.hip) — a K-step moves the same bytes and
@@ -657,8 +657,8 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
   // large shapes: LDS-DMA tiles (256x256 with >= 2 rounds of tiles, else 256x128 when it fills the chip);
   // variant override through ifx_set_option("gemm_variant"): 1 = always the register-staged 128x128 kernel
   const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0) && K % 64 == 0;
-  // FP8 launches of >= 2048 rows: the ping-pong tile (gemm_variant 22 / 23 / 24 force its 256 / 192 / 128-token form, 3 = never)
-  if (format == IFX_Q_FP8_E4M3 && wide_ok && gemm_variant() != 1 && gemm_variant() != 2 && gemm_variant() != 3) {
+  // FP8 / INT8 launches of >= 2048 rows: the ping-pong tile (gemm_variant 22 / 23 / 24 force its 256 / 192 / 128-token form, 3 = never)
+  if (wide_ok && gemm_variant() != 1 && gemm_variant() != 2 && gemm_variant() != 3) {
     const int v = gemm_variant();
     int tj = v == 22 ? 4 : v == 23 ? 3 : v == 24 ? 2 : pick_pp_q8(M, N, K, mode);
     if (mode == IFX_EPI_GATE_RES && ea.rows_per_group < 32 * tj) tj = ea.rows_per_group >= 64 ? 2 : 0;
@@ -667,7 +667,7 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
     if (tj != 0 && aligned)
       return launch_gemm_pp((const unsigned short*)xp, ldx, (const unsigned short*)wp, y, ldy, M, N, K,
                             mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj, nullptr, x_scale, w_scale, qdiv,
-                            q_via_bf16, 0);
+                            q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0);
   }
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };

@@ -112,32 +112,33 @@ def test_gemm_q8_epilogues():
         assert_bf16_parity(got, ref, max_ulp=2, floor=1.0, what="q8 gate+residual")
 
 
+@pytest.mark.parametrize("fmt", [Q.FP8, Q.INT8])
 @pytest.mark.parametrize("variant", [22, 23, 24])
-def test_gemm_q8_ping_pong_tiles_vs_oracle(variant):
-    """The FP8 instantiations of the persistent ping-pong tile (what the auto choice takes from 2048 rows), forced at ragged sizes:
+def test_gemm_q8_ping_pong_tiles_vs_oracle(variant, fmt):
+    """The FP8 and INT8 instantiations of the persistent ping-pong tile (what the auto choice takes from 2048 rows), forced at ragged sizes:
     rows that end inside a tile, channel counts that end inside the 256-wide tile, one to many K-steps, several tiles per workgroup;
     every epilogue against oracle/quant_oracle.py, and bit for bit against the LDS-DMA tiles they replace wherever both round the
     same way (no bias: the dequantisation is one multiply)."""
     from inferix_amd import _hip, hip_ops as ops
     from inferix_amd.quant import QConfig, quantize_weight
-    g = torch.Generator().manual_seed(variant)
+    g = torch.Generator().manual_seed(variant + 100 * fmt)
     fs = 195
     try:
         for M, N, K in ((585, 320, 128), (2340, 1536, 1536), (4680, 4608, 1536), (2535, 704, 8960), (6045, 1024, 3072)):
             x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
             res, mod = rnd(g, M, N), rnd(g, M // fs, 6, N, scale=0.5)
-            wq, sw = quantize_weight(w.cuda(), QConfig(Q.FP8, "t"))
-            xq, sx = ops.quant_per_token(x.cuda(), Q.FP8)
-            y = Q.linear_q8(x, w, b, Q.FP8)
+            wq, sw = quantize_weight(w.cuda(), QConfig(fmt, "t"))
+            xq, sx = ops.quant_per_token(x.cuda(), fmt)
+            y = Q.linear_q8(x, w, b, fmt)
             ops.set_option("gemm_variant", variant)
-            got = ops.linear_q8(xq, sx, wq, sw, b.cuda(), Q.FP8)
-            plain = ops.linear_q8(xq, sx, wq, sw, None, Q.FP8)
-            gelu = ops.linear_q8(xq, sx, wq, sw, b.cuda(), Q.FP8, epilogue=_hip.IFX_EPI_GELU_TANH)
-            resid = ops.linear_q8(xq, sx, wq, sw, b.cuda(), Q.FP8, epilogue=_hip.IFX_EPI_RESIDUAL, residual=res.cuda())
-            gated = ops.linear_q8(xq, sx, wq, sw, b.cuda(), Q.FP8, epilogue=_hip.IFX_EPI_GATE_RES, residual=res.cuda(), mod=mod.cuda(),
+            got = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt)
+            plain = ops.linear_q8(xq, sx, wq, sw, None, fmt)
+            gelu = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt, epilogue=_hip.IFX_EPI_GELU_TANH)
+            resid = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt, epilogue=_hip.IFX_EPI_RESIDUAL, residual=res.cuda())
+            gated = ops.linear_q8(xq, sx, wq, sw, b.cuda(), fmt, epilogue=_hip.IFX_EPI_GATE_RES, residual=res.cuda(), mod=mod.cuda(),
                                   gate_slot=5, rows_per_group=fs)
             ops.set_option("gemm_variant", 3)
-            assert torch.equal(plain, ops.linear_q8(xq, sx, wq, sw, None, Q.FP8)), (M, N, K)
+            assert torch.equal(plain, ops.linear_q8(xq, sx, wq, sw, None, fmt)), (M, N, K)
             what = f"q8 ping-pong v{variant} {M}x{N}x{K}"
             assert_bf16_parity(got, y, what=what)
             assert_bf16_parity(gelu, torch.nn.functional.gelu(y, approximate="tanh"), max_ulp=4, max_mismatch_frac=0.05, rel=3e-3, floor=1.0,
