@@ -603,7 +603,8 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
 // Ping-pong tile for an FP8 launch (tokens = 64 tj), 0 = none: the model of pick_pp (ifx_gemm.hip) — a K-step moves the same bytes and
 // occupies the matrix pipe for the same cycles as a bf16 one, there are half as many of them.
 static int pick_pp_q8(int M, int N, int K, int mode) {
-  if (M < 2048 || N % 64 != 0 || K % 128 != 0) return 0;
+  // from 1024 rows (one MAGI chunk of a cp = 8 rank, 1519 rows: q 50 -> 33 us, proj 86 -> 55, fc2 148 -> 90, tools/bench_q8.py)
+  if (M < 1024 || N % 64 != 0 || K % 128 != 0) return 0;
   static const float step_us[5] = {0.f, 0.f, 1.2f, 1.4f, 1.6f};
   const float tile_us = (mode == IFX_EPI_GELU_TANH ? 8.f : 3.f);
   int best = 0;
@@ -657,7 +658,7 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
   // large shapes: LDS-DMA tiles (256x256 with >= 2 rounds of tiles, else 256x128 when it fills the chip);
   // variant override through ifx_set_option("gemm_variant"): 1 = always the register-staged 128x128 kernel
   const bool wide_ok = N % 8 == 0 && ldy % 8 == 0 && (ea.residual == nullptr || ea.ld_res % 8 == 0) && K % 64 == 0;
-  // FP8 / INT8 launches of >= 2048 rows: the ping-pong tile (gemm_variant 22 / 23 / 24 force its 256 / 192 / 128-token form, 3 = never)
+  // FP8 / INT8 launches of >= 1024 rows: the ping-pong tile (gemm_variant 22 / 23 / 24 force its 256 / 192 / 128-token form, 3 = never)
   if (wide_ok && gemm_variant() != 1 && gemm_variant() != 2 && gemm_variant() != 3) {
     const int v = gemm_variant();
     int tj = v == 22 ? 4 : v == 23 ? 3 : v == 24 ? 2 : pick_pp_q8(M, N, K, mode);

@@ -20,7 +20,11 @@ SHAPES = [  # name, M, N, K, epilogue
     ("magi q", 6075, 3072, 3072, "none"), ("magi k", 6075, 1024, 3072, "none"), ("magi fc1", 6075, 12288, 3072, "gelu_erf"),
     ("magi fc1 -> e4m3", 6075, 12288, 3072, "gelu_erf_q"), ("magi proj", 6075, 3072, 6144, "none"), ("magi fc2", 6075, 3072, 12288, "none"),
     ("magi fc1 3 chunks", 4557, 12288, 3072, "gelu_erf"), ("magi fc1 2 chunks", 3038, 12288, 3072, "gelu_erf"),
+    ("magi q 1 chunk", 1519, 3072, 3072, "none"), ("magi k 1 chunk", 1519, 1024, 3072, "none"), ("magi fc1 1 chunk", 1519, 12288, 3072, "gelu_erf_q"),
+    ("magi proj 1 chunk", 1519, 3072, 6144, "none"), ("magi fc2 1 chunk", 1519, 3072, 12288, "none"),
 ]
+if len(sys.argv) > 2:
+    SHAPES = [s_ for s_ in SHAPES if sys.argv[2] in s_[0]]
 print("| launch | M x N x K | epilogue | LDS-DMA tiles us | ping-pong auto us | TFLOP/s | of 5 PF | forced 256 / 192 / 128 us | bits |")
 print("|---|---|---|---:|---:|---:|---:|---|---|")
 for name, M, N, K, epi in SHAPES:
