@@ -84,8 +84,18 @@ class HipFullyParallelAttention:
             for nm in ("q", "qx", "k", "v"):
                 k = f"linear_qkv.{nm}."
                 self.fp8[nm] = StaticFp8Linear(g(k + "weight"), g(k + "weight_scale"), g(k + "input_scale"), g(k + "input_scale"))
+            # the four linears quantise the same LayerNorm row, each with its own input_scale vector: one pass produces one e4m3 copy per
+            # DISTINCT vector (a checkpoint calibrated on the shared input may well carry the same vector four times: then one copy)
             h = self.fp8["q"].in_features
-            self.qkv_divisors = torch.stack([self.fp8[nm].divisor.expand(h) for nm in ("q", "qx", "k", "v")]).contiguous()
+            uniq, self.qkv_slot = [], {}
+            for nm in ("q", "qx", "k", "v"):
+                d = self.fp8[nm].divisor.expand(h)
+                hit = next((i for i, u in enumerate(uniq) if torch.equal(u, d)), None)
+                if hit is None:
+                    uniq.append(d)
+                    hit = len(uniq) - 1
+                self.qkv_slot[nm] = hit
+            self.qkv_divisors = torch.stack(uniq).contiguous()
         else:
             self.w["qkv"] = torch.cat([g("linear_qkv.q.weight"), g("linear_qkv.qx.weight"), g("linear_qkv.k.weight"),
                                        g("linear_qkv.v.weight")], dim=0).to(BF16).contiguous()
@@ -126,8 +136,8 @@ class HipFullyParallelAttention:
             # one pass: LayerNorm + the four linears' own static quantisers of its bf16 row (each has its own input_scale vector)
             hq = ops.layernorm_quant_static(x2, eps, self.qkv_divisors, gamma=w["ln_w"], beta=w["ln_b"])
             off = 0
-            for i, (nm, n) in enumerate((("q", Q), ("qx", Q), ("k", KV), ("v", KV))):
-                self.fp8[nm].matmul(hq[:, i], out=mixed[:, off:off + n])
+            for nm, n in (("q", Q), ("qx", Q), ("k", KV), ("v", KV)):
+                self.fp8[nm].matmul(hq[:, self.qkv_slot[nm]], out=mixed[:, off:off + n])
                 off += n
         else:
             hln = ops.layernorm(x2, eps, gamma=w["ln_w"], beta=w["ln_b"])

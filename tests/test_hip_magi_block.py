@@ -483,6 +483,48 @@ def test_layer_under_cp_shuffle_overlap_two_ranks_matches_single_device_golden()
             assert rel_l2(got, ref) < 1e-2, (ci, r, rel_l2(got, ref))
 
 
+def test_fp8_layer_shares_one_quantised_copy_between_linears_with_the_same_input_scale():
+    """q / qx / k / v quantise the same LayerNorm row; a checkpoint that carries the same `input_scale` vector for several of them gets
+    ONE e4m3 copy of the row for those (fewer bytes written by the fused LayerNorm + quantiser), with bit-identical layer output."""
+    from inferix_amd.magi.dit import HipMagiTransformerLayer, synthetic_layer_state_dict
+    from inferix_amd.magi.types import InferenceParams
+    mc = SimpleNamespace(num_layers=3, hidden_size=512, ffn_hidden_size=1024, num_attention_heads=4, num_query_groups=2, kv_channels=128,
+                         layernorm_epsilon=1e-6, apply_layernorm_1p=True, gated_linear_unit=False, cond_hidden_ratio=0.25,
+                         xattn_cond_hidden_ratio=1.0, cond_gating_ratio=1.0)
+    ec = SimpleNamespace(cp_size=1, cp_strategy="none", fp8_quant=True, kv_offload=False, ulysses_overlap_degree=1)
+    sd = synthetic_layer_state_dict(mc, seed=3, device="cuda", fp8=True)
+    for nm in ("qx", "k"):
+        sd[f"self_attention.linear_qkv.{nm}.input_scale"] = sd["self_attention.linear_qkv.q.input_scale"].clone()
+    layer = HipMagiTransformerLayer(mc, ec, 1, "cuda")
+    layer.load_state_dict(sd)
+    sa = layer.self_attention
+    assert sa.qkv_divisors.shape[0] == 2 and sa.qkv_slot == {"q": 0, "qx": 0, "k": 0, "v": 1}
+    ref = HipMagiTransformerLayer(mc, ec, 1, "cuda")
+    ref.load_state_dict(sd)
+    h = ref.self_attention.fp8["q"].in_features           # the same weights with the sharing switched off: four copies
+    ref.self_attention.qkv_divisors = torch.stack([ref.self_attention.fp8[nm].divisor.expand(h) for nm in ("q", "qx", "k", "v")]).contiguous()
+    ref.self_attention.qkv_slot = {"q": 0, "qx": 1, "k": 2, "v": 3}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    s_len, clip = 96, 96
+    x = torch.randn(s_len, 1, 512, generator=g, device="cuda").to(BF)
+    cond = torch.randn(1, 1, 128, generator=g, device="cuda").to(BF)
+    cmap = torch.zeros(s_len, 1, dtype=torch.int32, device="cuda")
+    y = torch.randn(7, 512, generator=g, device="cuda").to(BF)
+    ang = torch.rand(s_len, 48, generator=g, device="cuda") * 6.0
+    rope = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
+    from inferix_amd.magi.types import ModelMetaArgs, PackedCoreAttnParams, PackedCrossAttnParams
+    qr = torch.tensor([[0, clip]], dtype=torch.int32)
+    core = PackedCoreAttnParams(q_range=qr, k_range=qr, np_q_range=qr.numpy(), np_k_range=qr.numpy(), max_seqlen_q=clip, max_seqlen_k=clip)
+    cross = PackedCrossAttnParams(q_ranges=qr, kv_ranges=torch.tensor([[0, 7]], dtype=torch.int32), cu_seqlens_q=torch.tensor([0, clip], dtype=torch.int32),
+                                  cu_seqlens_kv=torch.tensor([0, 7], dtype=torch.int32), max_seqlen_q=clip, max_seqlen_kv=7)
+    meta = ModelMetaArgs(H=8, W=12, cp_pad_size=0, cp_split_sizes=[s_len], slice_point=0, denoising_range_num=1, range_num=1,
+                         extract_prefix_video_feature=False, fwd_extra_1st_chunk=False, distill_nearly_clean_chunk=False, clip_token_nums=clip,
+                         enable_cuda_graph=False, core_attn_params=core, cross_attn_params=cross)
+    out = layer(x, cond, cmap, y, rope, None, meta)
+    want = ref(x, cond, cmap, y, rope, None, meta)
+    assert torch.isfinite(out.float()).all() and torch.equal(out, want)
+
+
 def test_fp8_quant_layer_stack_vs_reference_golden():
     """`engine_config.fp8_quant` (the 4.5B distill-quant config of BASELINE config 5): three layers, the middle one on the
     static-scale FP8 linears (q / qx / k / v / fc1 per-tensor form, linear_proj / fc2 per-channel form, dit_module.py:408-413,
