@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     const int kk = c.kt + c.rot;
     const int kb = ((!SK && kk >= KT ? kk - KT : kk) + c.k0) * 128;
     const unsigned p = lds_piece0 + (c.g & 1) * STAGE + slot;
+    if ((dbg & 8) && c.g >= 2) return;               // lab: no DMA after the first two K-steps (what would a loader phase of reads alone cost?)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (q < pieces) dma16(c.rs, p + q * 4096, voff, kb + (row0 + q * 32) * ld_op * ES);

@@ -1,2 +1,2 @@
-export IFX_GEMM_SMALL_SPLIT=1
-timeout 300 tools/bin/gemm_lab -r 9 0,9,10,3,5,8 585,4608,1536,0 585,8960,1536,1 585,1536,8960,3 585,1536,1536,3
+L=inferix_amd/libinferix_hip_trace.so
+for d in 0 8; do for s in "24 4680,1536,1536,0" "22 6075,8192,3072,0"; do set -- $s; echo "=== IFX_PP_DEBUG=$d v$1 $2"; IFX_PP_DEBUG=$d timeout 100 tools/bin/gemm_lab -l $L -t -r 5 $1 $2 | grep -v "^ *$"; done; done
