@@ -209,3 +209,12 @@ def test_reference_import_paths_resolve_to_the_hip_implementation():
     assert quantize_dynamic is Q.quantize_dynamic and f8().fmt == 0 and "HipPagedFA" in collect_supported_attn()
     assert set_random_seed(7) == 7 and float(torch.rand(1)) == float(torch.manual_seed(7) and torch.rand(1))
     assert ParallelConfig().world_size == 1
+    # MAGI (config 5): the model class, the layer classes and the scheduler half of SampleTransport at the reference's paths
+    from inferix.models.magi.dit.dit_model import VideoDiTModel
+    from inferix.models.magi.dit.dit_module import TransformerBlock, TransformerLayer  # noqa: F401
+    from inferix.pipeline.magi.video_generate import ChunkSchedule, find_dit_model, generate_sequences, init_intervel, init_t  # noqa: F401
+    import inferix_amd.magi.model as MM_
+    assert VideoDiTModel is MM_.HipVideoDiTModel and generate_sequences(4, 4, 0)[0] == [0, 0, 0, 0, 1, 2, 3]
+    wrapped = type("DDP", (), {})()
+    wrapped.module = type("M", (), {"forward_dispatcher": lambda self: None})()
+    assert find_dit_model(wrapped) is wrapped.module
