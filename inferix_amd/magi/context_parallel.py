@@ -141,6 +141,10 @@ def gather_from_context_parallel_region(input_: torch.Tensor, cp_split_sizes: Se
             piece[:n].copy_(input_[:n])
             if n < piece.shape[0]:
                 piece[n:].copy_(input_[:piece.shape[0] - n])
+    elif input_.is_cuda and dist.get_backend(get_cp_group()) == "gloo":          # as _a2a: gloo moves host tensors
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather(list(torch.split(host, list(cp_split_sizes), dim=0)), input_.cpu(), group=get_cp_group())
+        out.copy_(host)
     else:
         dist.all_gather(list(torch.split(out, list(cp_split_sizes), dim=0)), input_, group=get_cp_group())
     if cp_shuffle_num > 1:

@@ -265,3 +265,73 @@ def test_forward_dispatcher_vs_reference_golden():
                 assert r < 2e-2, (tag, ci, r)            # measured 5.0-6.7e-3: the component errors are correlated and do not add up to the 14x
             else:
                 assert r < 1e-2, (tag, ci, r)
+
+
+# ---- the whole model under context parallelism: 2 ranks on one GPU (gloo rendezvous, exchanges staged through the host) ----------------
+def _model_cp_worker(rank, world, port, strategy, ret):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from inferix_amd.magi import context_parallel as cpl
+        from inferix_amd.magi.model import HipVideoDiTModel
+        from inferix_amd.magi.types import InferenceParams
+        cpl.set_cp_group(dist.group.WORLD)
+        fx = golden("magi_model_tiny.npz")
+        n_layers, clip, n_calls, wseed, eseed, max_tokens = [int(v) for v in fx["geom"]]
+        cfg = MM.tiny_model_config()
+        sd = dict(MM.init_embedder_weights(cfg, eseed))
+        for li in range(n_layers):
+            sd.update({f"videodit_blocks.layers.{li}.{k}": v for k, v in MB.init_layer_weights(cfg.layer, wseed + li).items()})
+        config = _config(cfg)
+        config.engine_config.cp_size, config.engine_config.cp_strategy = world, strategy
+        model = HipVideoDiTModel(config, "cuda")
+        model.load_state_dict(sd)
+        ip = InferenceParams(1, max_tokens)
+        outs = []
+        for ci in range(n_calls):
+            range_num, dn, sp, fe, di, upd = [int(v) for v in fx[f"c{ci}_flags"]]
+            kw = dict(range_num=range_num, denoising_range_num=dn, slice_point=sp, fwd_extra_1st_chunk=bool(fe), distill_nearly_clean_chunk=bool(di))
+            args = [fx[f"c{ci}_in_{k}"].cuda() for k in ("x", "t", "y", "drop", "mask", "kv_range")]
+            ip.update_kv_cache = bool(upd)
+            outs.append(model(*args, inference_params=ip, **kw).cpu())
+        torch.cuda.synchronize()
+        ret[rank] = outs
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strategy", ["cp_ulysses", "cp_shuffle_overlap"])
+def test_model_under_context_parallelism_two_ranks_vs_reference_golden(strategy):
+    """`HipVideoDiTModel.forward` with `engine_config.cp_size = 2` under both strategies: cp_pre_process shards the patch tokens (and the
+    rope rows, the condition map, the cross-attention ranges), the layers exchange heads for tokens, cp_post_process gathers the head's
+    output — every rank must hold the single-device model output of the golden (the reference's `VideoDiTModel.forward`), at the same
+    bf16 floor as the unsharded test above."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    fx = golden("magi_model_tiny.npz")
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_model_cp_worker, args=(world, port, strategy, ret), nprocs=world, join=True)
+        outs = [ret[r] for r in range(world)]
+    for ci in range(int(fx["geom"][2])):
+        ref = fx[f"c{ci}_out"]
+        for r in range(world):
+            got = outs[r][ci]
+            assert got.shape == ref.shape
+            e = rel_l2(got, ref)
+            print(f"magi model under {strategy}, call {ci}, rank {r}: vs reference {e:.3e}")
+            assert e < 1e-2, (strategy, ci, r, e)
+        assert torch.equal(outs[0][ci], outs[1][ci]), "the ranks hold different gathered outputs"
