@@ -718,6 +718,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
 #endif
 }
 
+// (Row invariance holds up to 1024 tiles of a launch — 43 690 rows at N = 1536, five times the largest block of the path — which is what
+//  the flag page and a workspace of at most 256 MiB cover; a larger launch runs unsplit, i.e. with the other summation order.)
 // Split K in two for long-K launches with few column tiles (the block's FFN down-projection, 1536 x 8960: 114 tiles of 256 x 256 for
 // 256 CUs).  Depends on (N, K) ONLY: a row's summation order must not change with the number of rows in the launch.
 bool gemm_pp_split(int N, int K) {
