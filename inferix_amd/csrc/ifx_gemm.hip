@@ -205,17 +205,20 @@ static int pick_pp(int M, int N, int K, int mode, bool have_ws) {
   // the split shapes at ANY row count (a row's summation order must not depend on it) unless the caller opted into the row-count
   // dependent in-workgroup splits for small launches
   if (have_ws && gemm_pp_split(N, K) && ((M + 255) / 256) * ((N + 255) / 256) <= 1024 && !(gemm_small_split() && M < 2048)) return 4;
-  if (M < 2048) return 0;
+  if (M < 1024) return 0;
   static const float step_us[5] = {0.f, 0.f, 1.2f, 1.4f, 1.6f};
   const float tile_us = (mode == IFX_EPI_GELU_TANH ? 8.f : 3.f);
-  int best = 0;
+  int best = 0, best_tiles = 0;
   float best_t = 1e30f;
   for (int tj = 4; tj >= 2; --tj) {
     const int tiles = ((M + 64 * tj - 1) / (64 * tj)) * ((N + 255) / 256);
     const int rounds = (tiles + 255) / 256;
     const float t = rounds * ((K / 64) * step_us[tj] + tile_us);
-    if (t < best_t) best_t = t, best = tj;
+    if (t < best_t) best_t = t, best = tj, best_tiles = tiles;
   }
+  // 1024 .. 2047 rows (one MAGI chunk of a cp rank, 1519 rows): only where the chosen tile still gives most CUs a tile — 1519 x 8192 x
+  // 3072 99 -> 70 us, x 12288 153 -> 128; with fewer tiles the LDS-DMA tiles with several workgroups per CU are ahead (1170 x 1536^2: 15 vs 27 us)
+  if (M < 2048 && best_tiles < 160) return 0;
   return best;
 }
 
