@@ -1095,16 +1095,36 @@ __global__ __launch_bounds__(256) void attn_split_merge_kernel(const float* __re
   const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);      // (row, head) pair, 32 lanes x 4 channels
   if (pair >= q_rows * heads) return;
   const int row = pair / heads, head = pair - row * heads, c = (threadIdx.x & 31) * 4;
+  // four slots per pass: their LSE values and partial rows are requested together (a run-time loop of dependent load -> use steps pays
+  // one memory latency per slot: 12.9 us for 585 rows x 12 heads x 5 slots); the accumulation order stays slot 0, 1, 2, ...
   float mx = -INFINITY;
-  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, part_lse[((size_t)s * heads + head) * q_rows + row]);
+  for (int s0 = 0; s0 < splits; s0 += 4) {
+    float l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) l[u] = s0 + u < splits ? part_lse[((size_t)(s0 + u) * heads + head) * q_rows + row] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, l[u]);
+  }
   float den = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < splits; ++s) {
-    const float w = __expf(part_lse[((size_t)s * heads + head) * q_rows + row] - mx);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + (((size_t)s * q_rows + row) * heads + head) * 128 + c);
-    den += w;
+  for (int s0 = 0; s0 < splits; s0 += 4) {
+    float l[4];
+    f32x4 v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+    for (int u = 0; u < 4; ++u) {
+      const int s = min(s0 + u, splits - 1);
+      l[u] = part_lse[((size_t)s * heads + head) * q_rows + row];
+      v[u] = *reinterpret_cast<const f32x4*>(part_o + (((size_t)s * q_rows + row) * heads + head) * 128 + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + u < splits) {
+        const float w = __expf(l[u] - mx);
+        den += w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * v[u][e];
+      }
+    }
   }
   const float inv = 1.0f / den;
   u16x4 w4;
