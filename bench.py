@@ -486,7 +486,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if a.magi_leg:
         sub = [st * 16 + i for st in range(7) for i in range(a.magi_steps)] if a.magi_steps else None
-        print(json.dumps(magi_cp8_emulated_leg(device, fp8_quant=a.magi_leg == "fp8", steps=sub)), flush=True)
+        print(json.dumps(magi_cp8_emulated_leg(device, layers=a.layers or 34, fp8_quant=a.magi_leg == "fp8", steps=sub)), flush=True)
         return
     import torch.distributed as dist
     pc = None

@@ -52,3 +52,16 @@ def test_bench_two_ranks_report_the_ranks_an_all_gather_saw_and_the_exchange_use
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0
     assert r["rccl_ranks"] == 2 and r["sp_exchange"] == "peer_store", (r["rccl_ranks"], r["sp_exchange"])
+
+
+def test_bench_magi_leg_runs_the_schedule_through_the_model():
+    """`bench.py --magi-leg fp8` (the config 5 leg alone) on a cut-down stack: four layers, the first step of every schedule stage —
+    seven forwards of 1 .. 4 chunks, three of them with the clean chunk in front — through HipVideoDiTModel under the emulated cp = 8
+    rank; the JSON carries the counts the schedule implies and says INVALID."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--magi-leg", "fp8", "--magi-steps", "1", "--layers", "4"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["denoise_forwards"] == 7 and d["chunk_forwards"] >= 1 + 2 + 3 + 4 + 4 + 3 + 2
+    assert "INVALID" in d and "partial schedule" in d["INVALID"] and d["fp8_quant"] is True
+    assert d["roofline"]["launches"] > 0 and d["gemm_fp8_ms"] > 0 and d["ms_clip_rank"] > 0
