@@ -45,6 +45,16 @@ if "w4" in which:
         ops.set_option("gemm_variant", 5)
         ops.linear(a, w1, None)
     ops.set_option("gemm_variant", 0)
+if "q8" in which:
+    # FP8 launches on the 8-bit instantiations of the ping-pong tile: the block's shapes and MAGI's long-K ones
+    FP8 = _hip.IFX_Q_FP8_E4M3
+    for M, Nn, K in ((4680, 4608, 1536), (4680, 8960, 1536), (4680, 1536, 8960), (6075, 3072, 12288), (6075, 12288, 3072)):
+        xq = torch.randn(M, K, generator=g, device=dev).to(torch.float8_e4m3fn).view(torch.uint8)
+        wq = (torch.randn(Nn, K, generator=g, device=dev) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
+        sx = torch.full((M,), 0.02, device=dev)
+        sw = torch.full((Nn,), 0.002, device=dev)
+        for _ in range(reps):
+            ops.linear_q8(xq, sx, wq, sw, None, FP8)
 if "norm" in which:
     x = rnd(N, d)
     mod = rnd(3, 6, d)
