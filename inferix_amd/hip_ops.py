@@ -258,11 +258,37 @@ def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[tor
     return q_out
 
 
+_OPTIONS: dict = {}          # key -> value last set through set_option in this process (unset = the library's default, 0)
+
+
 def set_option(key: str, value: int) -> None:
-    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..20, 'attn_variant' 0..7 (include/inferix_hip.h); 0 = choose by shape."""
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..26, 'attn_variant' 0..7, 'gemm_small_split' 0/1
+    (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
-    _SPLIT_PLAN.clear()          # the split plan depends on the attention schedule
-    _GEMM_WS_NEED.clear()        # ... and the workspace a GEMM shape asks for on the tile selection
+    _OPTIONS[key] = int(value)
+    if key == "attn_variant":
+        _SPLIT_PLAN.clear()      # the split plan depends on the attention schedule
+    if key == "gemm_variant":
+        _GEMM_WS_NEED.clear()    # the workspace a GEMM shape asks for depends on the tile selection (small_split is part of the key)
+
+
+class option_scope:
+    """`with option_scope("gemm_small_split", 1): ...` — set a kernel-selection option for the launches enqueued inside and put the
+    previous value back afterwards (the selection happens on the host at enqueue time, so the scope covers exactly those launches)."""
+
+    def __init__(self, key: str, value: int):
+        self.key, self.value, self.prev = key, int(value), 0
+
+    def __enter__(self):
+        self.prev = _OPTIONS.get(self.key, 0)
+        if self.prev != self.value:
+            set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.value:
+            set_option(self.key, self.prev)
+        return False
 
 
 _ATTN_WS: dict = {}      # (device index, stream) -> fp32 split-KV workspace, grown on demand
@@ -466,9 +492,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
         assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
-    need = _GEMM_WS_NEED.get((M, N, K))
+    wkey = (M, N, K, _OPTIONS.get("gemm_small_split", 0))
+    need = _GEMM_WS_NEED.get(wkey)
     if need is None:
-        need = _GEMM_WS_NEED[(M, N, K)] = int(lib.ifx_gemm_workspace_bytes(M, N, K))
+        need = _GEMM_WS_NEED[wkey] = int(lib.ifx_gemm_workspace_bytes(M, N, K))
     with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         if need:
             ws = _gemm_workspace(x.device, need)
@@ -481,7 +508,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
     return out
 
 
-_GEMM_WS_NEED: dict = {}     # (M, N, K) -> bytes ifx_gemm_workspace_bytes asks for (0 = none)
+_GEMM_WS_NEED: dict = {}     # (M, N, K, small_split) -> bytes ifx_gemm_workspace_bytes asks for (0 = none)
 _GEMM_WS: dict = {}          # (device index, stream) -> zero-initialised scratch for the split-K tiles, grown on demand
 
 

@@ -17,8 +17,9 @@ MI355X-first differences (all behind the same API):
 """
 from __future__ import annotations
 
+import itertools
 from dataclasses import dataclass, field
-from typing import Dict, KeysView, List, Optional, Sequence, Union
+from typing import Callable, Dict, KeysView, List, Optional, Sequence, Union
 
 import torch
 
@@ -85,8 +86,15 @@ class PageTable:
 
 
 class KVCacheManager:
+    # managers constructed so far in this process.  The pipelines build a fresh manager per call and reuse request ids ("req_0",
+    # "stream_req_0": pipeline/self_forcing.py), so an allocation is only named uniquely together with its manager's serial — which,
+    # like the per-layer generation, is a pure function of the call sequence and therefore the same on every rank of an SPMD run.
+    _serials = itertools.count(1)
+
     def __init__(self, device: Union[str, torch.device, int]):
         self.device = torch.device(device)
+        self.serial = next(KVCacheManager._serials)
+        self._free_listeners: List[Callable[[str], None]] = []   # called with the request id on `free` (peer-mapping owners)
         self.offload_device = torch.device("cpu")
         self.request_to_kv_caches: Dict[str, KVCaches] = {}
         self._generation: Dict[tuple, int] = {}      # (request id, layer) -> how many times that layer has been allocated
@@ -113,6 +121,17 @@ class KVCacheManager:
 
     def free(self, req: KVCacheRequest) -> None:
         del self.request_to_kv_caches[req.request_id]
+        self._notify_free(req.request_id)
+
+    def add_free_listener(self, fn: Callable[[str], None]) -> None:
+        """`fn(request_id)` runs whenever a request (or one of its layers) is freed: the sequence-parallel peer-store exchange drops
+        its IPC address book for that request there (inferix_amd.sequence_parallel.PeerStoreExchange.forget)."""
+        if fn not in self._free_listeners:
+            self._free_listeners.append(fn)
+
+    def _notify_free(self, request_id: str) -> None:
+        for fn in list(self._free_listeners):
+            fn(request_id)
 
     def free_layer(self, req: KVCacheRequest, layer_name: str) -> None:
         c = self.request_to_kv_caches[req.request_id]
@@ -120,14 +139,16 @@ class KVCacheManager:
         del c.specs[layer_name]
         c.page_tables.pop(layer_name, None)
         c.views.pop(layer_name, None)
+        self._notify_free(req.request_id)
 
     def allocation_id(self, req: KVCacheRequest, layer_name: str) -> tuple:
-        """(request id, layer, generation): names ONE allocation of a layer's cache.  A data pointer does not — the caching
-        allocator hands a freed address out again — and the generation is a pure function of the call sequence, so the ranks of an
-        SPMD run agree on it (what inferix_amd.sequence_parallel keys its peer mappings by)."""
+        """(request id, layer, (manager serial, generation)): names ONE allocation of a layer's cache in this process.  A data pointer
+        does not — the caching allocator hands a freed address out again — and neither does (request, layer, generation) alone: the
+        pipelines make a new manager per call with the same request ids.  Serial and generation are pure functions of the call
+        sequence, so the ranks of an SPMD run agree on them (what inferix_amd.sequence_parallel keys its peer mappings by)."""
         if layer_name not in self.request_to_kv_caches[req.request_id].tensors:
             raise KeyError(layer_name)
-        return (req.request_id, layer_name, self._generation[(req.request_id, layer_name)])
+        return (req.request_id, layer_name, (self.serial, self._generation[(req.request_id, layer_name)]))
 
     # ---- lookup -----------------------------------------------------------
     def layers(self, req: KVCacheRequest) -> Union[KeysView[str], Sequence[str]]:

@@ -47,6 +47,24 @@ def _load_config(path_or_dict, default=None) -> SimpleNamespace:
     return SimpleNamespace(**merge(read(default), read(path_or_dict)))
 
 
+def decode_image_file(image_path: str, height: int, width: int) -> torch.Tensor:
+    """`[3, height, width]` fp32 in [-1, 1] from an image file: the reference's `Resize((480, 832))` -> `ToTensor` -> `Normalize(.5, .5)`
+    on a PIL image (pipeline/self_forcing/pipeline.py:212-221).  torchvision's `Resize` of a PIL image IS `Image.resize(size[::-1],
+    BILINEAR)`, `ToTensor` is uint8 / 255 and the normalisation `(x - 0.5) / 0.5` in fp32 — the same three steps on Pillow + torch give
+    the same bits without torchvision (which this image does not have)."""
+    try:
+        from PIL import Image
+    except ImportError as exc:               # host-side decoder only; the tensor route of run_image_to_video needs none
+        raise RuntimeError("load_image needs Pillow to decode an image file; pass image=tensor [1, 3, 1, H, W] in [-1, 1] to "
+                           "run_image_to_video instead") from exc
+    import numpy as np
+    with Image.open(image_path) as im:
+        im = im.convert("RGB").resize((width, height), Image.BILINEAR)
+        px = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy())              # [H, W, 3]
+    x = px.permute(2, 0, 1).to(torch.float32).div(255)
+    return (x - 0.5) / 0.5
+
+
 class SelfForcingPipeline(AbstractInferencePipeline):
     def __init__(self, config_path, default_config_path: Optional[str] = None, parallel_config=None,
                  profiling_config=None, *, text_encoder=None, vae=None, generator=None, device=None):
@@ -157,8 +175,10 @@ class SelfForcingPipeline(AbstractInferencePipeline):
                                    save_with_index=save_with_index, use_ema=use_ema, low_memory=low_memory, **kwargs)
 
     def load_image(self, image_path: str) -> torch.Tensor:
-        raise NotImplementedError("image decoding (PIL / torchvision upstream) is outside this build: pass image=tensor "
-                                  "[1, 3, 1, H, W] in [-1, 1] to run_image_to_video")
+        """Image file -> `[1, 3, 1, H, W]` bf16 in [-1, 1] on the device (pipeline.py:212-221).  The target size follows `latent_shape`
+        (8x the latent grid: 480 x 832 for the stock config, which upstream hard-codes)."""
+        x = decode_image_file(image_path, int(self.latent_shape[1]) * 8, int(self.latent_shape[2]) * 8)
+        return x.unsqueeze(0).unsqueeze(2).to(device=self.device, dtype=torch.bfloat16)
 
     def _run_inference(self, prompts: List[str], num_output_frames: int, num_samples: int,
                        initial_latent: Optional[torch.Tensor] = None, output_folder: Optional[str] = None,

@@ -201,7 +201,7 @@ class PeerStoreExchange:
     def cache_addresses(self, view, ident: Optional[Tuple] = None) -> Tuple[List[int], List[int]]:
         """(K base, V base) of this (request, layer) cache on every rank; exchanged the first time an ALLOCATION is seen (a
         collective: every rank reaches it at the same call).  `ident` = `KVCacheManager.allocation_id(req, layer)` — (request, layer,
-        generation), on which the ranks of an SPMD run agree.  Keying by data pointers (round 2) was wrong twice over: a freed cache's
+        (manager serial, generation)), on which the ranks of an SPMD run agree.  Keying by data pointers (round 2) was wrong twice over: a freed cache's
         address can come back on one rank and not on its peers (stale mapping -> stores into freed peer memory), and ranks that
         disagree on hit / miss deadlock in the exchange.  Without an `ident` (the self test's scratch cache) nothing is remembered.
         Raises — on every rank together — if the ranks' cache geometries or page tables differ."""
@@ -382,6 +382,8 @@ class HipSequenceParallel:
         have_prefix = step.local_start > 0
         ident = mgr.allocation_id(req, name) if hasattr(mgr, "allocation_id") else None
         if self.peer is not None:
+            if hasattr(mgr, "add_free_listener"):           # the manager's free / free_layer drop this request's address book
+                mgr.add_free_listener(self.peer.forget)
             try:                                            # first use of an allocation: handles travel (collective, main stream)
                 self.peer.cache_addresses(view, ident)
             except RuntimeError as exc:                     # raised on every rank together: all fall back to the collective
@@ -559,10 +561,11 @@ def attach_sequence_parallel(model, group=None, overlap: bool = True,
                              kv_first: Optional[bool] = None) -> HipSequenceParallel:
     """Enable sequence parallelism on a HipCausalWanModel whose ParallelConfig has world_size > 1."""
     sp = HipSequenceParallel(group, overlap, exchange, peer, kv_first)
-    # a rank's launches have 4680 / P rows: let the GEMM tile choice split K inside a workgroup for them (row-count dependent bits,
-    # which the default choice avoids; the row count of a rank is fixed by P)
-    from . import hip_ops as ops
-    ops.set_option("gemm_small_split", 1)
+    # a rank's launches have 4680 / P rows: the GEMM tile choice may split K inside a workgroup for them (row-count dependent bits,
+    # which the default choice avoids; the row count of a rank is fixed by P).  The option is process-global in the library, so it is
+    # scoped to THIS model's forwards (HipCausalWanModel.forward: hip_ops.option_scope) and every other GEMM of the process — a
+    # second, unsharded model, the umT5 encoder, the VAE — keeps its row-count-invariant summation order.
+    sp.gemm_small_split = True
     pc = model.parallel_config
     if pc.world_size != sp.ex.world or pc.rank != sp.ex.rank:
         raise ValueError(f"ParallelConfig (rank {pc.rank}/{pc.world_size}) does not match the process group "

@@ -44,13 +44,18 @@ class ParallelConfig:
     def __init__(self, ulysses_size=1, ring_size=1, local_rank=0, rank=0, world_size=1,
                  ring_strategy="pass-kv", attn_backend=None):
         from ..attention import collect_supported_attn
-        if ulysses_size != 1 or ring_size != 1:
-            # the reference sizes each rank's cache 32760 / ring x heads / ulysses (self_forcing_kv_cache_manager.py:45-57) and runs
-            # CoreAttention's all-to-all + ring (attention/distributed.py:53-281).  This build shards the SEQUENCE only
-            # (inferix_amd/sequence_parallel.py: hw-slice per frame, K/V all-gather, replicated cache; 12 heads do not divide by 8)
-            # and takes its degree from world_size: a caller asking for a Ulysses / ring degree must hear that, not be ignored.
-            raise ValueError(f"ulysses_size={ulysses_size} / ring_size={ring_size}: this build has no Ulysses or ring attention; "
-                             "sequence parallelism is selected by world_size (see inferix_amd/sequence_parallel.py)")
+        ulysses_size, ring_size, world_size = int(ulysses_size), int(ring_size), int(world_size)
+        if ulysses_size < 1 or ring_size < 1:
+            raise ValueError(f"ulysses_size={ulysses_size} / ring_size={ring_size}: degrees must be >= 1")
+        if ulysses_size * ring_size not in (1, world_size):
+            # The reference's launcher passes degrees whose product is the world size (example/self_forcing/self_forcing.sh:12-13,
+            # run_self_forcing.py:58-67) and shards its cache tokens / ring x heads / ulysses (self_forcing_kv_cache_manager.py:45-57)
+            # for CoreAttention's all-to-all + ring (attention/distributed.py:53-281).  Here BOTH degrees select the same thing:
+            # the sequence-parallel exchange of inferix_amd/sequence_parallel.py at degree world_size (hw slice per frame, K/V
+            # exchange, replicated cache — the same function of the inputs; 12 heads do not divide by 8).  A product that is not
+            # the world size names a process-group layout no launcher of the reference produces.
+            raise ValueError(f"ulysses_size={ulysses_size} x ring_size={ring_size} != world_size={world_size}: the sequence-parallel "
+                             "degree is ulysses_size * ring_size and must equal the number of ranks")
         self.ulysses_size, self.ring_size = ulysses_size, ring_size
         self.local_rank, self.rank, self.world_size = local_rank, rank, world_size
         self.ring_strategy = ring_strategy
@@ -127,9 +132,11 @@ class HipCausalWanModel(torch.nn.Module):
         self.qk_norm, self.cross_attn_norm = qk_norm, cross_attn_norm
         self.enable_kv_offload = enable_kv_offload
         self.parallel_config = parallel_config if parallel_config is not None else ParallelConfig()
-        if getattr(self.parallel_config, "ulysses_size", 1) != 1 or getattr(self.parallel_config, "ring_size", 1) != 1:
-            raise ValueError("CausalWanModel: ulysses_size / ring_size != 1 are not supported by this build (sequence parallelism "
-                             "follows world_size; see ParallelConfig)")      # also catches duck-typed configs (SimpleNamespace)
+        pc = self.parallel_config
+        u, r = int(getattr(pc, "ulysses_size", 1)), int(getattr(pc, "ring_size", 1))
+        if u * r not in (1, int(getattr(pc, "world_size", 1))):   # also catches duck-typed configs (SimpleNamespace)
+            raise ValueError(f"CausalWanModel: ulysses_size={u} x ring_size={r} must equal world_size={getattr(pc, 'world_size', 1)} "
+                             "(both degrees map onto the one sequence-parallel exchange; see ParallelConfig)")
         self.num_frame_per_block = 1
         self.independent_first_frame = False
         self.device_ = torch.device(device)
@@ -486,9 +493,12 @@ class HipCausalWanModel(torch.nn.Module):
 
         st = dict(B=B, N=N, F_=F_, fs=fs, rows_per_group=rows_per_group, rope=rope, sink_tokens=sink_tokens,
                   current_start=current_start, ctx=ctx, explicit_slots=explicit, attn_scale=attn_scale)
-        for l in range(L):
-            self._run_block(l, xact, E[l], st, kv_cache_meta[l], crossattn_cache_meta[l], kv_cache_manager,
-                            kv_cache_requests)
+        import contextlib
+        small = ops.option_scope("gemm_small_split", 1) if getattr(self.cp, "gemm_small_split", False) else contextlib.nullcontext()
+        with small:                                   # shard-sized launches of a sequence-parallel rank only (attach_sequence_parallel)
+            for l in range(L):
+                self._run_block(l, xact, E[l], st, kv_cache_meta[l], crossattn_cache_meta[l], kv_cache_manager,
+                                kv_cache_requests)
 
         # ---- head -------------------------------------------------------------------------
         ops.layernorm(xact, self.eps, mod=eh, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)

@@ -269,16 +269,21 @@ def test_no_transcendental_to_valu_hazard_in_the_built_kernels():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-500:]
 
 
-def test_parallel_config_rejects_ulysses_and_ring_degrees():
-    """reference ParallelConfig (wan_base/utils/parallel_config.py:3-30) carries ulysses_size / ring_size into CoreAttention and the
-    cache sizing; this build has neither and must say so instead of accepting and ignoring them (round-2 verdict, missing #4)."""
+def test_parallel_config_maps_ulysses_and_ring_degrees_onto_world_size():
+    """reference ParallelConfig (wan_base/utils/parallel_config.py:3-30) takes any degrees; its launcher passes ulysses x ring ==
+    world_size (example/self_forcing/self_forcing.sh:12-13 defaults RING_SIZE=2; run_self_forcing.py:58-67).  Here both degrees select
+    the one sequence-parallel exchange at degree world_size; only a product that is not the world size is refused."""
     import pytest
     from inferix_amd.wan.causal_model import ParallelConfig
     pc = ParallelConfig()
     assert (pc.ulysses_size, pc.ring_size, pc.attn_backend) == (1, 1, "HipPagedFA")
     assert ParallelConfig(rank=3, world_size=8, local_rank=3).world_size == 8
-    for kw in (dict(ulysses_size=2), dict(ring_size=4), dict(ulysses_size=2, ring_size=4)):
-        with pytest.raises(ValueError, match="no Ulysses or ring"):
+    for u, r, w in ((1, 2, 2), (2, 1, 2), (2, 4, 8), (1, 8, 8), (4, 1, 4)):
+        pc = ParallelConfig(local_rank=1, rank=1, world_size=w, ulysses_size=u, ring_size=r)     # the launcher's keyword order
+        assert (pc.ulysses_size, pc.ring_size, pc.world_size, pc.rank) == (u, r, w, 1)
+    for kw in (dict(ulysses_size=2), dict(ring_size=4), dict(ulysses_size=2, ring_size=4, world_size=4), dict(ring_size=2, world_size=8),
+               dict(ring_size=0)):
+        with pytest.raises(ValueError, match="world_size|>= 1"):
             ParallelConfig(**kw)
     with pytest.raises(ValueError, match="not available"):
         ParallelConfig(attn_backend="FA3")

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend="gloo", quant=None):
+def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend="gloo", quant=None, degrees=None, second_call=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -47,7 +47,10 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend
         torch.cuda.set_device(rank if backend == "nccl" else 0)
         fx = golden(name)
         cfg = O.tiny_config(local_attn_size=6, sink_size=1) if "local" in name else O.tiny_config()
-        pc = ParallelConfig(rank=rank, world_size=world)
+        if degrees is None:
+            pc = ParallelConfig(rank=rank, world_size=world)
+        else:       # exactly the call of the reference's launcher (example/self_forcing/run_self_forcing.py:58-67; self_forcing.sh: RING_SIZE=2)
+            pc = ParallelConfig(local_rank=rank, rank=rank, world_size=world, ulysses_size=degrees[0], ring_size=degrees[1])
         m = HipCausalWanModel(patch_size=cfg.patch_size, text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
                               ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
                               num_heads=cfg.num_heads, num_layers=cfg.num_layers, local_attn_size=cfg.local_attn_size,
@@ -110,6 +113,28 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend
         torch.cuda.synchronize()
         ok_trace = trace == fx["trace"].tolist()
         r = rel_l2(out.cpu(), fx["out"])
+        if degrees is not None:      # the replicated cache: every rank holds the full-size tensor whatever the degrees say
+            t0 = KVCacheManager("cuda")
+            pipe._initialize_kv_cache(t0, [KVCacheRequest("shape")], torch.bfloat16)
+            shp = tuple(t0.get_raw(KVCacheRequest("shape"), "layer_0").shape)
+            assert shp == (2, 21 * cfg.frame_seqlen, 1, cfg.num_heads, cfg.dim // cfg.num_heads), shp
+        if second_call:
+            # the pipelines make a NEW manager per call and reuse the request id; the peer address book must not hand the
+            # second call the first call's (freed, still IPC-mapped) caches.  Same request id, fresh manager, caches of the first call
+            # dropped in between: the rollout has to come out again, bit for bit.
+            del trace[:]
+            torch.cuda.empty_cache()
+            mgr2 = KVCacheManager("cuda")
+            out2 = pipe.inference(noise=fx["noise"].cuda(), text_prompts=["x"], kv_cache_manager=mgr2,
+                                  kv_cache_requests=[KVCacheRequest("r")], decode_mode=DecodeMode.NO_DECODE, renoise=renoise)
+            torch.cuda.synchronize()
+            assert trace == fx["trace"].tolist()
+            assert torch.equal(out2, out), f"second call through a fresh manager differs: {rel_l2(out2.cpu(), out.cpu()):.3e}"
+            if peer is not None:
+                idents = {k[2] for k in peer._views}
+                assert len(idents) >= 1 and all(i[0] == mgr2.serial for i in idents), idents     # only the live manager's allocations
+                mgr2.free(KVCacheRequest("r"))
+                assert not peer._views, "KVCacheManager.free did not drop the peer address book"
         if single is not None:
             _ops.linear = lin0
             block_shapes = {(3 * cfg.dim, cfg.dim), (2 * cfg.dim, cfg.dim), (cfg.ffn_dim, cfg.dim), (cfg.dim, cfg.ffn_dim)}
@@ -179,6 +204,20 @@ def test_sequence_parallel_rollout_over_rccl(exchange):
     world = 2
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), True, "rollout_tiny.npz", ret, exchange, "nccl"), nprocs=world, join=True)
+    for rank in range(world):
+        ok_trace, r = ret[rank]
+        assert ok_trace and r < 1e-2, (rank, ok_trace, r)
+
+
+@pytest.mark.parametrize("exchange,degrees", [("allgather", (1, 2)), ("peer", (1, 2)), ("peer", (2, 1))])
+def test_reference_launcher_parallel_config_runs_the_sequence_parallel_exchange(exchange, degrees):
+    """The reference's stock launch line (`self_forcing.sh`: ULYSSES_SIZE=1 RING_SIZE=2 -> `ParallelConfig(local_rank, rank,
+    world_size, ulysses_size, ring_size)`, run_self_forcing.py:58-67) on two ranks: both degrees map onto the sequence-parallel
+    exchange with a replicated full-size cache, the rollout equals the single-device golden, and a second call through a fresh
+    manager with the same request id (what the pipelines do) reproduces it bit for bit."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), True, "rollout_tiny.npz", ret, exchange, "gloo", None, degrees, True), nprocs=world, join=True)
     for rank in range(world):
         ok_trace, r = ret[rank]
         assert ok_trace and r < 1e-2, (rank, ok_trace, r)

@@ -218,3 +218,32 @@ def test_reference_import_paths_resolve_to_the_hip_implementation():
     wrapped = type("DDP", (), {})()
     wrapped.module = type("M", (), {"forward_dispatcher": lambda self: None})()
     assert find_dit_model(wrapped) is wrapped.module
+
+
+def test_load_image_decode_matches_the_reference_transform(tmp_path):
+    """`SelfForcingPipeline.load_image` (reference pipeline.py:212-221: Resize((480, 832)) -> ToTensor -> Normalize(.5, .5) on a PIL
+    image).  torchvision is not in this image, so the three steps are checked one by one: at the target size the resize is the
+    identity and the result is exactly (px / 255 - 0.5) / 0.5; a constant image stays constant under the bilinear resize; the file
+    route works for PNG and JPEG containers and palette / RGBA inputs are converted to RGB."""
+    import numpy as np
+    import pytest
+    Image = pytest.importorskip("PIL.Image")
+    from inferix_amd.pipeline.self_forcing import decode_image_file
+    rng = np.random.default_rng(0)
+    px = rng.integers(0, 256, size=(48, 80, 3), dtype=np.uint8)
+    p = tmp_path / "a.png"
+    Image.fromarray(px).save(p)
+    x = decode_image_file(str(p), 48, 80)
+    assert x.shape == (3, 48, 80) and x.dtype == torch.float32
+    want = (torch.from_numpy(px).permute(2, 0, 1).float() / 255 - 0.5) / 0.5
+    assert torch.equal(x, want)
+    y = decode_image_file(str(p), 96, 160)                      # upscale: stays inside the source range
+    assert y.shape == (3, 96, 160) and float(y.min()) >= float(want.min()) and float(y.max()) <= float(want.max())
+    flat = np.full((30, 50, 4), 200, dtype=np.uint8)            # RGBA, constant colour
+    q = tmp_path / "b.png"
+    Image.fromarray(flat, "RGBA").save(q)
+    z = decode_image_file(str(q), 60, 104)
+    assert z.shape == (3, 60, 104) and torch.equal(z, torch.full_like(z, (200 / 255 - 0.5) / 0.5))
+    j = tmp_path / "c.jpg"
+    Image.fromarray(flat[..., :3]).save(j)
+    assert decode_image_file(str(j), 60, 104).shape == (3, 60, 104)

@@ -83,3 +83,73 @@ def test_exchange_equals_single_device_cache(world, paged):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), paged, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def _launcher_worker(rank, world, port, ret):
+    """What the reference's `run_self_forcing.py:49-70` does on every rank, with gloo standing in for nccl: ParallelConfig from
+    (LOCAL_RANK, RANK, world size, --ulysses_size, --ring_size), then the pipeline sizes its caches from it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+        from inferix_amd.kvcache_manager.model import SelfForcingKVCacheManagerFactory
+        from inferix_amd.pipeline import CausalInferencePipeline
+        from inferix_amd.schedulers import FlowMatchScheduler
+        from inferix_amd.sequence_parallel import SequenceParallelExchange, attach_sequence_parallel
+        from inferix_amd.wan import ParallelConfig
+        pc = ParallelConfig(local_rank=rank, rank=rank, world_size=dist.get_world_size(), ulysses_size=1, ring_size=world)
+        ok = (pc.ring_size, pc.ulysses_size, pc.world_size, pc.rank) == (world, 1, world, rank)
+        heads, hd, layers, fs = 2, 8, 2, 24
+        sched = FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+        sched.set_timesteps(1000, training=True)
+        model = SimpleNamespace(num_layers=layers, local_attn_size=-1, parallel_config=pc, cp=None, text_len=8,
+                                blocks=[SimpleNamespace(kv_cache_manager=SelfForcingKVCacheManagerFactory.create_manager(i, heads, hd))
+                                        for i in range(layers)])
+        gen = SimpleNamespace(model=model, parallel_config=pc, get_scheduler=lambda: sched)
+        args = SimpleNamespace(denoising_step_list=[1000, 500], warp_denoising_step=True, num_frame_per_block=3,
+                               frame_seq_length=fs, kv_cache_tokens=6 * fs)
+        pipe = CausalInferencePipeline(args, "cpu", generator=gen, parallel_config=pc)
+        mgr, req = KVCacheManager("cpu"), KVCacheRequest("req_0")
+        pipe._initialize_kv_cache(mgr, [req], torch.float32)
+        # replicated, full size on every rank: NOT tokens / ring x heads / ulysses (reference self_forcing_kv_cache_manager.py:45-57)
+        ok = ok and tuple(mgr.get_raw(req, "layer_0").shape) == (2, 6 * fs, 1, heads, hd)
+        # the attach accepts the launcher's config (rank / world are checked against the process group, the degrees are not)
+        sp = attach_sequence_parallel(model, exchange=SequenceParallelExchange())
+        ok = ok and model.cp is sp and sp.ex.world == world and sp.gemm_small_split
+        # and the exchange at that degree fills the manager's cache exactly as one device would
+        frames, local_start, n = 3, 2 * fs, 3 * fs
+        g = torch.Generator().manual_seed(3)
+        new_k, new_v = torch.randn(n, heads, hd, generator=g), torch.randn(n, heads, hd, generator=g)
+        hw = fs // world
+        mine = torch.stack([new_k.view(frames, fs, heads, hd)[:, rank * hw:(rank + 1) * hw].reshape(-1, heads, hd),
+                            new_v.view(frames, fs, heads, hd)[:, rank * hw:(rank + 1) * hw].reshape(-1, heads, hd)], dim=1)
+        t = mgr.get_raw(req, "layer_0")
+        t.zero_()
+        kc, vc = t[0].view(-1, heads, hd), t[1].view(-1, heads, hd)
+        sp.ex.exchange_new_block(mine, kc, vc, local_start, frames, fs)
+        ok = ok and torch.equal(kc[local_start:local_start + n], new_k) and torch.equal(vc[local_start:local_start + n], new_v)
+        # allocation identity: a second manager reusing the request id names a different allocation (ADVICE r3), identically on all ranks
+        mgr2 = KVCacheManager("cpu")
+        pipe._initialize_kv_cache(mgr2, [req], torch.float32)
+        a, b = mgr.allocation_id(req, "layer_0"), mgr2.allocation_id(req, "layer_0")
+        both = [None] * world
+        dist.all_gather_object(both, (a, b))
+        ok = ok and a != b and a[:2] == b[:2] and all(x == both[0] for x in both)
+        seen = []
+        mgr2.add_free_listener(seen.append)
+        mgr2.free(req)
+        ok = ok and seen == ["req_0"]
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_launcher_parallel_config_two_ranks():
+    """`self_forcing.sh` defaults (ULYSSES_SIZE=1, RING_SIZE=2) through `run_self_forcing.py:58-67`'s ParallelConfig call on two gloo
+    ranks: accepted, cache replicated at full size, sequence-parallel exchange attached at degree world_size."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_launcher_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
