@@ -131,10 +131,16 @@ _BLOCK_LINEARS = (("self_attn.qkv", "qkv"), ("self_attn.o", "o"), ("cross_attn.q
                   ("cross_attn.v", "cv"), ("cross_attn.o", "co"), ("ffn.0", "f0"), ("ffn.2", "f2"))
 
 
+# linears outside the blocks: (reference module name, key prefix in the model's `g` dict)
+_GLOBAL_LINEARS = (("time_embedding.0", "time0"), ("time_embedding.2", "time2"), ("time_projection.1", "tproj"),
+                   ("text_embedding.0", "text0"), ("text_embedding.2", "text2"), ("head.head", "head"))
+
+
 def quantize_dynamic(module, qconfig_dict: Dict[str, Optional[QConfig]]):
-    """Quantise, in place, the linears of a HipCausalWanModel (or a wrapper / pipeline holding one).  Linears whose
-    K is not a multiple of 128 stay bf16 (kernel constraint), as do the O(frames)-row timestep MLPs that run as
-    PyTorch glue; `text_embedding`, `proj_out`, `head` are excluded by the caller's dict as upstream."""
+    """Quantise, in place, the linears of a HipCausalWanModel (or a wrapper / pipeline holding one): every nn.Linear of the
+    reference's transformer that the dict does not exclude — the eight per block and the three timestep-MLP linears; with the
+    example's dict (`text_embedding`, `proj_out`, `head`: None) exactly the set `oracle/quant_oracle.py::model_hook` quantises.
+    Linears whose K is not a multiple of 128 stay bf16 (kernel constraint; none in the Wan configs)."""
     model = module
     for attr in ("generator", "model"):
         while hasattr(model, attr) and not hasattr(model, "blocks"):
@@ -158,7 +164,20 @@ def quantize_dynamic(module, qconfig_dict: Dict[str, Optional[QConfig]]):
             blk.w[key + "_fmt"] = qc.fmt
             blk.w[key + "_act"] = qc.act
             n += 1
+    # the timestep MLPs (time_embedding.{0,2}, time_projection.1: nn.Linear children of the transformer, causal_model.py:615-618)
+    # fall under the dict's default like every other Linear; text_embedding / head are the caller's exclusions, the patch
+    # embedding is a Conv3d upstream and is no Linear
+    ng = 0
+    for ref_name, key in _GLOBAL_LINEARS:
+        qc = _config_for(ref_name, qconfig_dict)
+        w = model.g.get(key + "_w")
+        if qc is None or w is None or w.shape[1] % 128:
+            continue
+        model.g[key + "_q"], model.g[key + "_s"] = quantize_weight(w, qc)
+        model.g[key + "_fmt"], model.g[key + "_act"] = qc.fmt, qc.act
+        ng += 1
     model.quantized_linears = n
+    model.quantized_global_linears = ng
     return module
 
 
@@ -168,8 +187,8 @@ def dequantize(module):
     for attr in ("generator", "model"):
         while hasattr(model, attr) and not hasattr(model, "blocks"):
             model = getattr(model, attr)
-    for blk in model.blocks:
-        for k in [k for k in blk.w if k.endswith(("_q", "_s", "_fmt", "_act"))]:
-            del blk.w[k]
-    model.quantized_linears = 0
+    for d in [blk.w for blk in model.blocks] + [model.g]:
+        for k in [k for k in d if k.endswith(("_q", "_s", "_fmt", "_act"))]:
+            del d[k]
+    model.quantized_linears = model.quantized_global_linears = 0
     return module

@@ -449,8 +449,8 @@ class HipCausalWanModel(torch.nn.Module):
         t = t.to(dev)
         emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]
         # time_embedding / time_projection (a handful of rows): the same MFMA GEMM as the block linears, SiLU is elementwise glue
-        e = ops.linear(F.silu(ops.linear(emb.contiguous(), self.g["time0_w"], self.g["time0_b"])), self.g["time2_w"], self.g["time2_b"])
-        e0 = ops.linear(F.silu(e), self.g["tproj_w"], self.g["tproj_b"]).unflatten(1, (6, d))   # [B*Ft, 6, d]
+        e = self._lin(self.g, "time2", F.silu(self._lin(self.g, "time0", emb.contiguous())))
+        e0 = self._lin(self.g, "tproj", F.silu(e)).unflatten(1, (6, d))                         # [B*Ft, 6, d]
         Ft = t.shape[1]                                                          # frames carrying a timestep (F or 1)
         rows_per_group = (F_ // Ft) * fs_l
         E = (self.mod_all + e0.unsqueeze(0)).contiguous()                        # [L, B*Ft, 6, d] bf16
@@ -477,9 +477,8 @@ class HipCausalWanModel(torch.nn.Module):
                 for b, req in enumerate(kv_cache_requests or []):
                     j0 = min(int(first[b]), self.text_len - 1)
                     self._cross_dedup[req.request_id] = (j0 + 1, self.text_len - j0)
-            c0 = ops.linear(padded.view(B * self.text_len, -1), self.g["text0_w"], self.g["text0_b"],
-                            epilogue=_hip.IFX_EPI_GELU_TANH)
-            ctx = ops.linear(c0, self.g["text2_w"], self.g["text2_b"])           # [B*text_len, d]
+            c0 = self._lin(self.g, "text0", padded.view(B * self.text_len, -1), epilogue=_hip.IFX_EPI_GELU_TANH)
+            ctx = self._lin(self.g, "text2", c0)                                 # [B*text_len, d]
 
         # ---- scratch ---------------------------------------------------------------------
         h = self._buf("h", B * N, d)
@@ -502,7 +501,7 @@ class HipCausalWanModel(torch.nn.Module):
 
         # ---- head -------------------------------------------------------------------------
         ops.layernorm(xact, self.eps, mod=eh, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
-        yv = ops.linear(h, self.g["head_w"], self.g["head_b"])                   # [B*N, out*prod(patch)]
+        yv = self._lin(self.g, "head", h)                                         # [B*N, out*prod(patch)]
         if self.cp is not None:
             yv = self.cp.gather_head(yv, B, F_)
         return C.unpatchify(yv, B, grid, self.patch_size, self.out_dim)

@@ -381,9 +381,16 @@ def gen_rollout(cm, name, cfg, num_blocks, steps, shift, batch=1, with_initial=F
         fx["initial_latent"] = init
     for i, d in enumerate(drawn):
         fx[f"renoise_{i}"] = d
+    # teacher-forced yardstick: every generator forward again on the REFERENCE's own input of that call (own cache evolution), with
+    # exact attention — per-forward floor of tests/test_hip_model.py::test_teacher_forced_forwards (round-3 verdict: no fixed 5e-3)
+    sched = O.FlowMatchSchedule(shift=shift)
+    state_tf = O.CacheState.allocate(cfg, batch, BF, cache_tokens=cache_tokens)
+    state_tf.reset()
     for i, c in enumerate(calls):
         fx[f"call{i}_x_in"], fx[f"call{i}_t"] = c["x_in"], c["timestep"]
         fx[f"call{i}_flow"], fx[f"call{i}_x0"] = c["flow"], c["x0"]
+        flow_x, x0_x = O.generator_forward(W, cfg, sched, c["x_in"], list(pe), c["timestep"], state_tf, c["current_start"], "math")
+        fx[f"call{i}_flow_exact"], fx[f"call{i}_x0_exact"] = flow_x.to(BF), x0_x.to(BF)
     fx["num_calls"] = torch.tensor(len(calls))
     fx["num_renoise"] = torch.tensor(len(drawn))
     save_npz(os.path.join(GOLDEN_DIR, name), fx)
@@ -470,6 +477,14 @@ def gen_causvid():
         check(f"causvid segment {seg} cache K", raw[0, :n_tok, 0], st.layers[0].k[0, :n_tok])
         fx[f"seg{seg}_noise"], fx[f"seg{seg}_out"] = noise, lat
         fx[f"seg{seg}_cache_k"], fx[f"seg{seg}_cache_v"] = raw[0, :n_tok, 0], raw[1, :n_tok, 0]
+        # the same segment (same drawn noise, same start latents) with exact attention: the floor of the rollover test
+        exact, stx = O.causvid_inference(W, cfg, noise, list(pe), steps, renoise=drawn, shift=8.0, num_frame_per_block=nfb,
+                                         start_latents=start, state=O.CacheState.allocate(cfg, 1, BF, cache_tokens=32760),
+                                         attn_impl="math")
+        fx[f"seg{seg}_out_exact"] = exact.to(BF)
+        fx[f"seg{seg}_cache_k_exact"], fx[f"seg{seg}_cache_v_exact"] = stx.layers[0].k[0, :n_tok].to(BF), stx.layers[0].v[0, :n_tok].to(BF)
+        print(f"   segment {seg}: floor (reference vs exact attention) "
+              f"{float((lat.double() - exact.double()).norm() / exact.double().norm()):.3e}")
         fx[f"seg{seg}_slots"] = torch.tensor([[c["kv_start"], c["kv_end"]] for c in calls])
         fx[f"seg{seg}_t"] = torch.stack([c["t"].flatten()[0].float() for c in calls])
         fx[f"seg{seg}_num_renoise"] = torch.tensor(len(drawn))

@@ -50,3 +50,40 @@ def linear_q8(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], fm
     if bias is not None:
         y = y + bias.float()
     return y.to(torch.bfloat16)
+
+
+# --------------------------------------------------------------------------
+# the quantised MODEL: which linears, under the reference's exclusion dict
+# --------------------------------------------------------------------------
+def reference_qconfig_dict(fmt: int) -> dict:
+    """The dict of example/quantization/run_self_forcing_quantized.py:57-62: every nn.Linear of the transformer is quantised
+    (the empty key) except the modules named `text_embedding`, `proj_out` (no such module in the Wan DiT) and `head`."""
+    return {"": fmt, "text_embedding": None, "proj_out": None, "head": None}
+
+
+def config_for(name: str, qconfig_dict: dict):
+    """Module-name resolution of a `qconfig_dict`: the longest key that is the module's name or one of its ancestors wins, the
+    empty key is the default (torch.ao.quantization's propagate rule, which DAX's `quantize_dynamic(module, qconfig_dict)`
+    signature follows; DAX itself is not in the tree — parity unpinned)."""
+    best, best_len = qconfig_dict.get("", None), -1
+    for k, v in qconfig_dict.items():
+        if k and (name == k or name.startswith(k + ".")) and len(k) > best_len:
+            best, best_len = v, len(k)
+    return best
+
+
+def model_hook(qconfig_dict: dict, log: Optional[list] = None):
+    """`wan_oracle.linear_override` callback = the model after `quantize_dynamic(transformer, qconfig_dict)`: a Linear whose
+    resolved config is a format runs `linear_q8` on its 2-D rows, one whose config is None stays `F.linear`.
+    Quantised with the reference's dict: blocks.*.self_attn.{q,k,v,o}, blocks.*.cross_attn.{q,k,v,o}, blocks.*.ffn.{0,2},
+    time_embedding.{0,2}, time_projection.1 (all nn.Linear: models/self_forcing/causal_model.py:125-128,378-379,615-618); kept: text_embedding.{0,2}, head.head;
+    patch_embedding is a Conv3d and is not a Linear."""
+    def fn(x, weight, bias, name):
+        fmt = config_for(name, qconfig_dict)
+        if log is not None:
+            log.append((name, fmt))
+        if fmt is None:
+            return None
+        y = linear_q8(x.reshape(-1, x.shape[-1]), weight, bias, fmt)
+        return y.view(*x.shape[:-1], weight.shape[0]).to(x.dtype)
+    return fn

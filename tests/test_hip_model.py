@@ -188,9 +188,17 @@ def test_teacher_forced_forwards_vs_reference_golden():
                        crossattn_cache_meta=pipe.crossattn_cache_meta, current_start=cs, kv_cache_manager=kvm,
                        kv_cache_requests=reqs)
         assert (int(pipe.kv_cache_meta[0]["global_end_index"]), int(pipe.kv_cache_meta[-1]["local_end_index"])) == (ge, le)
-        worst = max(worst, rel_l2(flow.cpu(), fx[f"call{i}_flow"]), rel_l2(x0.cpu(), fx[f"call{i}_x0"]))
-    # stated tolerance for one 2-layer forward in bf16 on identical inputs
-    assert worst < 5e-3, f"teacher-forced forward rel-L2 {worst:.3e}"
+        # yardstick per forward: the same forward (the reference's input, own cache evolution) with exact attention, generated next
+        # to the reference's result in oracle/gen_golden.py; the reference sits `floor` from it and the HIP forward must be as close
+        # to it — and to the reference — as 1.25 x floor + 5e-4 (round-3 verdict: no fixed 5e-3)
+        for what, got in (("flow", flow), ("x0", x0)):
+            ref, exact = fx[f"call{i}_{what}"], fx[f"call{i}_{what}_exact"]
+            floor = rel_l2(ref, exact)
+            r_ref, r_exact = rel_l2(got.cpu(), ref), rel_l2(got.cpu(), exact)
+            worst = max(worst, r_ref / (1.25 * floor + 5e-4), r_exact / (1.25 * floor + 5e-4))
+            assert r_ref <= 1.25 * floor + 5e-4 and r_exact <= 1.25 * floor + 5e-4, \
+                f"forward {i} {what}: floor {floor:.3e}, HIP vs reference {r_ref:.3e}, HIP vs exact {r_exact:.3e}"
+    print(f"teacher-forced forwards: worst distance / bound = {worst:.2f}")
 
 
 def test_attention_registry_contract():
@@ -267,11 +275,15 @@ def test_causvid_rollover_vs_reference_golden():
                              kv_cache_requests=req, decode=False, renoise=renoise[seg])
         torch.cuda.synchronize()
         assert slots == fx[f"seg{seg}_slots"].tolist(), "cache slot schedule differs from the reference"
-        assert rel_l2(lat.cpu(), fx[f"seg{seg}_out"]) < 1e-2
         n = fx[f"seg{seg}_cache_k"].shape[0]
         raw = kvm.get_raw(req[0], "layer_0")
-        assert rel_l2(raw[0, :n, 0].cpu(), fx[f"seg{seg}_cache_k"]) < 1e-2
-        assert rel_l2(raw[1, :n, 0].cpu(), fx[f"seg{seg}_cache_v"]) < 1e-2
+        # floor rule (round-3 verdict: no fixed 1e-2): the reference's own distance from the exact-attention evaluation of the
+        # same segment (oracle/gen_golden.py::gen_causvid) is the yardstick, for the latents and for layer 0's cache rows
+        for what, got, key in (("latents", lat.cpu(), "out"), ("cache K", raw[0, :n, 0].cpu(), "cache_k"), ("cache V", raw[1, :n, 0].cpu(), "cache_v")):
+            ref, exact = fx[f"seg{seg}_{key}"], fx[f"seg{seg}_{key}_exact"]
+            floor, r_ref, r_exact = rel_l2(ref, exact), rel_l2(got, ref), rel_l2(got, exact)
+            print(f"causvid segment {seg} {what}: floor {floor:.3e}; HIP vs exact {r_exact:.3e}; HIP vs reference {r_ref:.3e}")
+            assert r_ref <= 1.25 * floor + 5e-4 and r_exact <= 1.25 * floor + 5e-4, (seg, what, floor, r_ref, r_exact)
         pipe.clear_cache(kvm, req)
         kvm.free(req[0])
         start = fx["seg1_start"].cuda() if seg == 0 else None
@@ -307,8 +319,11 @@ def test_other_resolutions_vs_oracle(lat_h, lat_w, frames):
                          kv_cache_requests=[KVCacheRequest("r")], decode_mode=DecodeMode.NO_DECODE, renoise=list(eps))
     torch.cuda.synchronize()
     ref, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=8.0, num_frame_per_block=3)
-    r = rel_l2(out.cpu(), ref)
-    assert torch.isfinite(out.float()).all() and r < 1e-2, f"{lat_h}x{lat_w}: rollout rel-L2 {r:.3e}"
+    exact, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=8.0, num_frame_per_block=3, attn_impl="math")
+    floor, r, rx = rel_l2(ref, exact), rel_l2(out.cpu(), ref), rel_l2(out.cpu(), exact)
+    print(f"{lat_h}x{lat_w}: floor (oracle bf16 SDPA vs exact attention) {floor:.3e}; HIP vs exact {rx:.3e}; HIP vs oracle {r:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert r <= 1.25 * floor + 5e-4 and rx <= 1.25 * floor + 5e-4, f"{lat_h}x{lat_w}: floor {floor:.3e}, vs oracle {r:.3e}, vs exact {rx:.3e}"
 
 
 def test_wan_14b_channel_geometry_vs_oracle():
@@ -333,8 +348,11 @@ def test_wan_14b_channel_geometry_vs_oracle():
                          kv_cache_requests=[KVCacheRequest("r")], decode_mode=DecodeMode.NO_DECODE, renoise=list(eps))
     torch.cuda.synchronize()
     ref, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=5.0, num_frame_per_block=3)
-    r = rel_l2(out.cpu(), ref)
-    assert torch.isfinite(out.float()).all() and r < 1e-2, f"14B geometry: rollout rel-L2 {r:.3e}"
+    exact, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=5.0, num_frame_per_block=3, attn_impl="math")
+    floor, r, rx = rel_l2(ref, exact), rel_l2(out.cpu(), ref), rel_l2(out.cpu(), exact)
+    print(f"14B geometry: floor (oracle bf16 SDPA vs exact attention) {floor:.3e}; HIP vs exact {rx:.3e}; HIP vs oracle {r:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert r <= 1.25 * floor + 5e-4 and rx <= 1.25 * floor + 5e-4, f"14B geometry: floor {floor:.3e}, vs oracle {r:.3e}, vs exact {rx:.3e}"
 
 
 @pytest.mark.parametrize("case", [0, 1])

@@ -186,3 +186,100 @@ def test_quantize_dynamic_model_rollout(which):
     assert torch.isfinite(out.float()).all()
     r = rel_l2(out.cpu(), fx["out"])
     assert r < (0.15 if which == "fp8" else 0.08), f"{which} rollout drifted {r:.3f} from the bf16 reference latents"
+
+
+def _quantised(cfg, W, which, **kw):
+    from inferix_amd.quant import (get_dynamic_fp8_per_token_act_per_channel_weight_qconfig,
+                                   get_dynamic_int8_per_token_act_per_channel_weight_qconfig, quantize_dynamic)
+    from inferix_amd.wan import HipCausalWanModel, HipWanDiffusionWrapper
+    m = HipCausalWanModel(patch_size=cfg.patch_size, text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
+                          ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
+                          num_heads=cfg.num_heads, num_layers=cfg.num_layers, eps=cfg.eps, **kw)
+    m.load_state_dict(W)
+    gen = HipWanDiffusionWrapper(model=m, timestep_shift=5.0)
+    qc = (get_dynamic_fp8_per_token_act_per_channel_weight_qconfig() if which == "fp8"
+          else get_dynamic_int8_per_token_act_per_channel_weight_qconfig())
+    # the dict of example/quantization/run_self_forcing_quantized.py:57-62
+    quantize_dynamic(gen, {"": qc, "text_embedding": None, "proj_out": None, "head": None})
+    return m, gen
+
+
+@pytest.mark.parametrize("which", ["fp8", "int8"])
+def test_quantized_rollout_vs_quantised_model_oracle(which):
+    """Config 4 as a MODEL (round-3 verdict, missing #2): the HIP rollout with `quantize_dynamic` under the reference's exclusion
+    dict against the quantised oracle — `wan_oracle` with `quant_oracle.linear_q8` at every nn.Linear that dict leaves quantised
+    (tests/golden/quant_model_tiny.npz, oracle/gen_golden_quant_model.py).  This pins the WIRING (which linears, where the
+    quantiser sits relative to norms / epilogues / the fused qkv); the floor rule of the bf16 rollouts applies: the oracle's own
+    distance between bf16-SDPA and exact attention is the yardstick, HIP within 1.25 x floor + 5e-4 of both.  (DAX: unpinned.)"""
+    import gen_golden_quant_model as G
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausalInferencePipeline
+    from fixture_io import golden
+    fx = golden("quant_model_tiny.npz")
+    rfx, cfg, W = G.rollout_inputs()
+    m, gen = _quantised(cfg, W, which)
+    assert m.quantized_linears == cfg.num_layers * 8 and m.quantized_global_linears == 3      # 8 = q|k|v fused + 7; time MLPs
+    assert "text0_q" not in m.g and "head_q" not in m.g
+    args = SimpleNamespace(denoising_step_list=rfx["steps"].tolist(), warp_denoising_step=True, num_frame_per_block=3,
+                           independent_first_frame=False, context_noise=0, frame_seq_length=cfg.frame_seqlen,
+                           kv_cache_tokens=21 * cfg.frame_seqlen)
+    pe = rfx["prompt_embeds"].cuda()
+    pipe = CausalInferencePipeline(args, "cuda", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe}, vae=None)
+    renoise = [rfx[f"renoise_{i}"] for i in range(int(rfx["num_renoise"]))]
+    kvm, req = KVCacheManager("cuda"), KVCacheRequest("r")
+    out = pipe.inference(noise=rfx["noise"].cuda(), text_prompts=["x"], kv_cache_manager=kvm, kv_cache_requests=[req],
+                         decode_mode=DecodeMode.NO_DECODE, renoise=renoise, free_cache_before_vae=False)
+    torch.cuda.synchronize()
+    ref, exact = fx[f"out_{which}"], fx[f"out_{which}_exact"]
+    floor = rel_l2(ref, exact)
+    r_ref, r_exact, r_bf16 = rel_l2(out.cpu(), ref), rel_l2(out.cpu(), exact), rel_l2(out.cpu(), rfx["out"])
+    print(f"{which} rollout: floor (q8 oracle, bf16 SDPA vs exact attention) {floor:.3e}; HIP vs exact {r_exact:.3e}; "
+          f"HIP vs q8 oracle {r_ref:.3e}; (HIP vs the bf16 reference latents {r_bf16:.3e})")
+    assert r_ref <= 1.25 * floor + 5e-4 and r_exact <= 1.25 * floor + 5e-4, (floor, r_ref, r_exact)
+    le = fx[f"cache_k_layer0_{which}"].shape[0]
+    k = kvm.get_raw(req, "layer_0")[0, :le, 0].cpu()
+    kf = rel_l2(fx[f"cache_k_layer0_{which}"], fx[f"cache_k_layer0_{which}_exact"])
+    k_ref, k_exact = rel_l2(k, fx[f"cache_k_layer0_{which}"]), rel_l2(k, fx[f"cache_k_layer0_{which}_exact"])
+    print(f"{which} layer-0 cache K: floor {kf:.3e}; HIP vs exact {k_exact:.3e}; HIP vs q8 oracle {k_ref:.3e}")
+    assert k_ref <= 1.25 * kf + 5e-4 and k_exact <= 1.25 * kf + 5e-4, (kf, k_ref, k_exact)
+
+
+@pytest.mark.parametrize("which", ["fp8", "int8"])
+def test_quantized_block_real_dims_vs_quantised_model_oracle(which):
+    """One block at the real channel geometry (dim 1536, 12 heads, ffn 8960; the inputs of block_real_dims.npz) with all ten of
+    its linears on the 8-bit path — norm+quantise -> fused qkv GEMM, O / cross / FFN GEMMs with their gate / residual / GELU
+    epilogues — against the quantised oracle's block, two consecutive frame blocks; floor rule as above."""
+    import gen_golden_quant_model as G
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from fixture_io import golden
+    fx = golden("quant_model_tiny.npz")
+    bfx, cfg, W = G.block_inputs()
+    m, _ = _quantised(cfg, W, which)
+    fs, nf = cfg.frame_seqlen, 3
+    n = nf * fs
+    kvm, req = KVCacheManager("cuda"), [KVCacheRequest("r")]
+    ad = m.blocks[0].kv_cache_manager
+    ad.allocate_kv_cache(kv_cache_manager=kvm, kv_cache_request=req[0], sequence_length=6 * fs, dtype=BF)
+    ad.allocate_crossattn_cache(kv_cache_manager=kvm, kv_cache_request=req[0], crossattn_length=cfg.text_len, dtype=BF)
+    meta = {"global_end_index": torch.tensor([0]), "local_end_index": torch.tensor([0])}
+    cmeta = {"is_init": False}
+    ctx = bfx["context"][0].cuda()
+    for b in range(2):
+        ref, exact = fx[f"block_out{b}_{which}"], fx[f"block_out{b}_{which}_exact"]
+        floor = rel_l2(ref, exact)
+        x = bfx[f"x{b}"][0].cuda().clone()
+        El = (m.mod_all[0] + bfx[f"e0_{b}"][0].cuda()).contiguous()
+        rope = ops.RopeGridSpec(m.freqs, b * nf, 4, 6)
+        st = dict(B=1, N=n, F_=nf, fs=fs, rows_per_group=fs, rope=rope, sink_tokens=0, current_start=b * n, ctx=ctx)
+        m._run_block(0, x, El, st, meta, cmeta, kvm, req)
+        r_ref, r_exact = rel_l2(x.cpu(), ref[0]), rel_l2(x.cpu(), exact[0])
+        print(f"{which} real-dims block #{b}: floor {floor:.3e}; HIP vs exact {r_exact:.3e}; HIP vs q8 oracle {r_ref:.3e}")
+        assert r_ref <= 1.25 * floor + 5e-4 and r_exact <= 1.25 * floor + 5e-4, (b, floor, r_ref, r_exact)
+    raw = kvm.get_raw(req[0], "layer_0")
+    # K / V rows are single quantised projections of the block input (+ norm, RoPE).  A one-ULP flip of the LayerNorm output in
+    # front of the quantiser moves an 8-bit code by a whole step (row max / 127 for int8, i.e. several bf16 ULPs of a small element), so
+    # the per-element bound is taken at the tensor's scale; the tensors as a whole agree to 1e-3 (measured 1.7e-4)
+    assert_bf16_parity(raw[0, :2 * n, 0], fx[f"block_cache_k_{which}"], max_ulp=4, max_mismatch_frac=0.02, floor=1.0, what="cache K")
+    assert_bf16_parity(raw[1, :2 * n, 0], fx[f"block_cache_v_{which}"], max_ulp=4, max_mismatch_frac=0.02, floor=1.0, what="cache V")

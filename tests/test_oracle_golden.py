@@ -196,3 +196,34 @@ def test_causvid_golden():
         n_tok = 3 * cfg.frame_seqlen
         assert [[r["block"] * n_tok, (r["block"] + 1) * n_tok] for r in rec] == fx[f"seg{seg}_slots"].tolist()
         assert [round(float(r["timestep"].flatten()[0]), 3) for r in rec] == [round(float(t), 3) for t in fx[f"seg{seg}_t"]]
+
+
+def test_quantised_model_oracle_golden():
+    """The quantised MODEL (BASELINE config 4; oracle/gen_golden_quant_model.py): `wan_oracle.linear_override` +
+    `quant_oracle.model_hook` under the reference's exclusion dict (example/quantization/run_self_forcing_quantized.py:57-62)
+    reproduce the committed fixture bit for bit, and the dict resolves as upstream: every nn.Linear quantised except
+    text_embedding.* and head.head.  (DAX is not in the reference tree: the fixture comes from the oracle, parity with DAX unpinned.)"""
+    import gen_golden_quant_model as G
+    import quant_oracle as Q
+    fx = golden("quant_model_tiny.npz")
+    rfx, cfg, W = G.rollout_inputs()
+    for fmt, nm in G.NAMES.items():
+        log = []
+        q, st = G.run_rollout(rfx, cfg, W, fmt, "sdpa", log)
+        same(fx[f"out_{nm}"], q)
+        assert [[s.local_start, s.local_end, s.global_end] for s in st.trace] == fx[f"trace_{nm}"].tolist()
+        assert fx[f"trace_{nm}"][:, 1:].tolist() == golden("rollout_tiny.npz")["trace"][:, [2, 1]].tolist()   # quantisation moves no slot
+        one = log[:log.index(("head.head", None)) + 1]
+        assert {n for n, f in one if f is None} == {"text_embedding.0", "text_embedding.2", "head.head"}
+        assert {n for n, f in one if f is not None} == (
+            {f"blocks.{i}.{a}.{p}" for i in range(cfg.num_layers) for a in ("self_attn", "cross_attn") for p in "qkvo"}
+            | {f"blocks.{i}.ffn.{j}" for i in range(cfg.num_layers) for j in (0, 2)}
+            | {"time_embedding.0", "time_embedding.2", "time_projection.1"})
+        assert all(f == fmt for _, f in one if f is not None)
+    bfx, bcfg, bW = G.block_inputs()
+    (o0, o1), _ = G.run_block(bfx, bcfg, bW, Q.FP8, "sdpa")
+    same(fx["block_out0_fp8"], o0)
+    same(fx["block_out1_fp8"], o1)
+    # the hook is scoped: outside the `with` the restated model is the bf16 one again
+    assert O._LINEAR_OVERRIDE is None
+    assert Q.config_for("blocks.3.ffn.0", {"": 1, "blocks.3": None}) is None and Q.config_for("blocks.30.ffn.0", {"": 1, "blocks.3": None}) == 1
