@@ -217,3 +217,14 @@ def test_all_to_all_async_over_rccl_is_ordered_before_its_consumer():
     ret = mp.Manager().dict()
     mp.spawn(_a2a_order_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_all_to_all_async_over_rccl_one_rank_twin():
+    """1-GPU twin of the test above (round-3 verdict #8).  RCCL refuses two ranks on one device ("Duplicate GPU detected", with or
+    without NCCL_IGNORE_DUPLICATE_GPU — tools/probe_rccl_one_gpu.py), so the only RCCL group a 1-GPU box can build has ONE rank: the
+    same `cp._a2a` (`dist.all_to_all_single(async_op=True)` on the RCCL backend, its internal stream, `wait()` as a stream-level
+    dependency) with a GEMM in front and the consumer enqueued right behind the wait, six rounds with changing payloads.  What this
+    does not cover is bytes between two devices; everything on this side of the wire — backend call, work handle, stream ordering — runs."""
+    ret = mp.Manager().dict()
+    mp.spawn(_a2a_order_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0] is True, dict(ret)

@@ -13,7 +13,7 @@ BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config-leg
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 DB=$(ls $OUT/${TAG}_trace/*/*.db $OUT/${TAG}_trace/*.db 2>/dev/null | head -1)
 python $R/tools/rocpd_summary.py $DB > $OUT/${TAG}_kernel_stats.md
-MICRO="python $R/tools/pmc_micro.py attn,gemm,w4 18720 3"
+MICRO="python $R/tools/pmc_micro.py attn,gemm 18720 3"   # (the MAGI long-K launches, "w4", have their own table in profiles/r3_pmc_attn_gemm.md)
 RX="attn_fwd|gemm_"
 : > $OUT/${TAG}_pmc.md
 pass() {  # name counters...
