@@ -191,31 +191,32 @@ def roofline_gemm(records, rows, forwards, layers, shards):
     region, grouped by shape.  Algorithmic FLOPs 2*N*(6*d^2 + 2*d*ffn) per layer and forward; algorithmic bytes x + W + y
     (+ the residual row an epilogue reads), each once.  MFMA busy and fabric traffic come from the PMC stamp (null when stale)."""
     by = {}
-    for name, s, e, fl, _ in records:
+    for name, s, e, fl, nb in records:
         if name == "gemm":
-            d = by.setdefault(round(fl), [0, 0.0])
+            d = by.setdefault((round(fl), round(nb)), [0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e)
+    keyof = lambda g: (round(2.0 * rows * g[1] * g[2]), round(2.0 * (rows * g[2] + g[1] * g[2] + rows * g[1] * (1 + g[3]))))
     per, tot_us, tot_fl, tot_by = {}, 0.0, 0.0, 0.0
-    for nm, n_out, n_in, res in BLOCK_GEMMS:
-        fl = 2.0 * rows * n_out * n_in
-        key = round(fl)
+    for g in BLOCK_GEMMS:
+        nm, n_out, n_in, res = g
+        fl, key = 2.0 * rows * n_out * n_in, keyof(g)
         if key not in by:
             return None
         cnt, ms = by[key]
-        same = sum(1 for g in BLOCK_GEMMS if round(2.0 * rows * g[1] * g[2]) == key)     # the three 1536^2 launches share a bucket
+        same = sum(1 for h in BLOCK_GEMMS if keyof(h) == key)    # O + gate and cross-o + residual: same FLOPs and bytes, one bucket
         us = ms * 1e3 / cnt
         per[nm] = {"us": round(us, 2), "tflops": round(fl / us / 1e6, 1), "frac": round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4),
                    "launches": cnt // same}
         tot_us += us
         tot_fl += fl
-        tot_by += 2.0 * (rows * n_in + n_out * n_in + rows * n_out * (1 + res))
+        tot_by += key[1]
     tf = tot_fl / tot_us / 1e6
     out = {"kernel": "ifx::gemm_pp_kernel (persistent ping-pong tile; the six linear projections of a block, epilogues fused)",
            "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
            "us_per_layer": round(tot_us, 1), "ms_per_clip": round(tot_us * forwards * layers / 1e3, 1), "per_launch": per,
            "algorithmic_flops_per_layer": tot_fl, "algorithmic_bytes_per_layer": tot_by,
-           "note": "the three 1536 x 1536 launches are timed as one bucket (same FLOPs): their rows carry the bucket's mean",
+           "note": "O + gate and cross-o + residual have the same FLOPs and bytes and are timed as one bucket: both rows carry its mean",
            "measured_on": "HIP events around every GEMM launch of ONE clip behind the timed region (kept out of `value`)"}
     t, why = _pmc_section("gemm_block") if shards == 1 else (None, "sharded run")
     if t is None:

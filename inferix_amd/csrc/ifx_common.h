@@ -64,6 +64,31 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + e);
 }
 
+// x / s for the per-token quantisers, three VALU operations per element instead of the ~10 of the IEEE sequence (v_div_scale x2,
+// v_rcp, four FMAs, v_div_fmas, v_div_fixup):  q0 = x r;  e = fma(-q0, s, x) (exact residual);  q = fma(e, r, q0)  with r = rcp(s)
+// computed once per row.  CORRECTLY ROUNDED for the operands this is used on — x a bf16 value, s = RN(amax / QMAX) with amax a bf16
+// value, QMAX 448 or 127 — for r anywhere within one ulp of 1 / s: checked exhaustively over every (x significand, amax significand)
+// pair and r in {RN(1/s), its two neighbours} (3.5 M quotients per QMAX, 0 mismatches against RN(x / s); the result does not depend
+// on the exponents while everything stays normal).  Callers take the IEEE division for rows whose scale is outside [2^-60, 2^60]
+// (wave-uniform test), where v_rcp_f32 or the residual could leave the normal range.
+struct RowDivisor {
+  float s, r;
+  // `scale` is the same in every lane of the wave (it comes out of a wave reduction); readfirstlane tells the compiler so, and
+  // `fast()` becomes a scalar branch the caller takes ONCE around its loops (a per-element test would be an exec-mask branch each)
+  __device__ __forceinline__ explicit RowDivisor(float scale)
+      : s(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale)))), r(__builtin_amdgcn_rcpf(s)) {}
+  __device__ __forceinline__ bool fast() const { return s > 8.67361738e-19f && s < 1.15292150e18f; }
+  template <bool FAST>
+  __device__ __forceinline__ float div(float x) const {
+    if (FAST) {
+      const float q0 = x * r;
+      const float e = __builtin_fmaf(-q0, s, x);
+      return __builtin_fmaf(e, r, q0);
+    }
+    return x / s;
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -21,6 +21,8 @@
 //                       half the operand bytes of the bf16 kernel per FLOP.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ifx_common.h"
 
 namespace ifx {
@@ -57,13 +59,17 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const unsigned short* _
   };
   unsigned char* qr = q + (size_t)r * ldq;
   if constexpr (NCH > 0) {
+    // branch-free: a lane beyond K reads the row's first chunk (a valid address) and is zeroed afterwards — with the load inside
+    // `if (col < K)` hipcc waited for every chunk before requesting the next (ifx_norm.hip::load_chunks)
     u16x8 u[NCH > 0 ? NCH : 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
-      if (col < K) u[c] = *reinterpret_cast<const u16x8*>(xr + col);
-      else u[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      u[c] = *reinterpret_cast<const u16x8*>(xr + (col < K ? col : 0));
     }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c * 512 + lane * 8 >= K) u[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
     float amax = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -72,15 +78,20 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const unsigned short* _
     amax = wave_max(amax);
     const float s = amax > 0.f ? amax / QMAX : 1.0f;
     if (lane == 0) scale[r] = s;
+    const RowDivisor rdiv(s);        // the exact three-operation x / s (ifx_common.h); 8960-wide rows: 140 quotients per lane
+    auto emit = [&](auto fastc) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 512 + lane * 8;
-      if (col >= K) continue;
-      float v[8];
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(bf2f(u[c][i]) / s, -QMAX), QMAX);
-      *reinterpret_cast<u32x2*>(qr + col) = pack(v);
-    }
+        for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(rdiv.template div<decltype(fastc)::value>(bf2f(u[c][i])), -QMAX), QMAX);
+        const u32x2 pk = pack(v);
+        if (col < K) *reinterpret_cast<u32x2*>(qr + col) = pk;
+      }
+    };
+    if (rdiv.fast()) emit(std::true_type{});
+    else emit(std::false_type{});
     return;
   }
   float amax = 0.f;

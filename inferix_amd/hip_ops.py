@@ -496,7 +496,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
     need = _GEMM_WS_NEED.get(wkey)
     if need is None:
         need = _GEMM_WS_NEED[wkey] = int(lib.ifx_gemm_workspace_bytes(M, N, K))
-    with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+    with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))):   # x + W + y (+ the residual rows)
         if need:
             ws = _gemm_workspace(x.device, need)
             _hip.check(lib.ifx_gemm_bf16_ws(_dev(x, "x"), ldx, _dev(w, "w"), _dev(bias, "bias") if bias is not None else None,
