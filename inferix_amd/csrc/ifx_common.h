@@ -89,15 +89,32 @@ struct RowDivisor {
   }
 };
 
+// Wave-wide reductions on the DPP path (no LDS traffic): hipcc lowers `__shfl_xor` to ds_bpermute_b32 + s_waitcnt lgkmcnt(0), an LDS
+// round trip of ~100 cycles per step — twelve of them in a row of LayerNorm, back to back on the critical path of a kernel that lives
+// for 8 us.  Steps: quad_perm xor 1, xor 2, row_half_mirror (= xor 4 once quads agree), row_mirror (= xor 8), row_bcast15 into rows
+// 1 / 3, row_bcast31 into rows 2 / 3; lane 63 then holds the total, read back as a scalar.  Same pairing as the xor butterfly
+// ((S0 + S1) + (S2 + S3) over the four 16-lane row sums, fp add is commutative): the results are bit-identical to it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_or<0xB1, 0xf>(0.f, v);      // quad_perm [1, 0, 3, 2]
+  v += dpp_or<0x4E, 0xf>(0.f, v);      // quad_perm [2, 3, 0, 1]
+  v += dpp_or<0x141, 0xf>(0.f, v);     // row_half_mirror
+  v += dpp_or<0x140, 0xf>(0.f, v);     // row_mirror
+  v += dpp_or<0x142, 0xa>(0.f, v);     // row_bcast15 -> rows 1, 3
+  v += dpp_or<0x143, 0xc>(0.f, v);     // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_or<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_or<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_or<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_or<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_or<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_or<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // logical token -> physical slot of a paged KV view (see ifx_kv_view)

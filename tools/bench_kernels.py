@@ -81,6 +81,22 @@ if what in ("norm", "all"):
     w1 = rnd(d)
     med, _ = timeit(lambda: ops.rmsnorm_rope_kv_append(qkv, w1, w1, 1e-6, rope, ops.KvCacheView(kc, vc), 0, d))
     print(f"rmsnorm+rope+append: {med*1e3:7.1f} us  {12.0*M*d/med/1e6:7.1f} GB/s")
+if what in ("norm", "all"):
+    # config 4's row passes: the per-token quantiser on the FFN activation and on a dim-wide row, LayerNorm + quantiser in one pass
+    for K in (f, d):
+        xk = rnd(M, K)
+        qb, sb = torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+        for fmt, nm in ((_hip.IFX_Q_FP8_E4M3, "fp8"), (_hip.IFX_Q_INT8, "int8")):
+            med, _ = timeit(lambda: ops.quant_per_token(xk, fmt, q=qb, scale=sb))
+            print(f"quant_per_token {nm} K={K}: {med*1e3:7.1f} us  {3.0*M*K/med/1e6:7.1f} GB/s")
+    x = rnd(M, d)
+    mod = rnd(3, 6, d)
+    qb, sb = torch.empty(M, d, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+    med, _ = timeit(lambda: ops.layernorm_quant(x, 1e-6, _hip.IFX_Q_FP8_E4M3, q=qb, scale=sb, mod=mod, rows_per_group=(M + 2) // 3))
+    print(f"adaln layernorm + fp8 quant: {med*1e3:7.1f} us  {3.0*M*d/med/1e6:7.1f} GB/s")
+    w1 = rnd(d)
+    med, _ = timeit(lambda: ops.rmsnorm(x, w1, 1e-6, out=x))
+    print(f"rmsnorm (cross q): {med*1e3:7.1f} us  {4.0*M*d/med/1e6:7.1f} GB/s")
 if what == "split":
     ops.set_option("attn_variant", int(os.environ.get("ATTN_VARIANT", "0")))
     q = rnd(M, H, D)
