@@ -157,22 +157,32 @@ __global__ __launch_bounds__(256) void magi_gate_norm_kernel(const unsigned shor
   const unsigned short* xr = x + (size_t)r * ldx;
   const unsigned short* rr = residual + (size_t)r * ldr;
   const unsigned short* gr = gate + (size_t)map[r] * ld_gate;
+  // every request of the row up front and branch-free (x, gate, residual and the fp32 norm weights, which do not depend on the
+  // statistics): with the loads inside `if (col < dim)` hipcc waited for each 512-channel chunk before requesting the next — six
+  // memory latencies per 3072-wide row (round 4; same rewrite as ifx_norm.hip::load_chunks)
   float v[NCH][8];
-  u16x8 res[NCH];
+  u16x8 xu[NCH], gu[NCH], res[NCH];
+  f32x4 w0[NCH], w1[NCH], b0[NCH], b1[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
-    if (col < dim) {
-      const u16x8 xu = *reinterpret_cast<const u16x8*>(xr + col);
-      const u16x8 gu = *reinterpret_cast<const u16x8*>(gr + col);
-      res[c] = *reinterpret_cast<const u16x8*>(rr + col);
+    const int cc = col < dim ? col : 0;
+    xu[c] = *reinterpret_cast<const u16x8*>(xr + cc);
+    gu[c] = *reinterpret_cast<const u16x8*>(gr + cc);
+    res[c] = *reinterpret_cast<const u16x8*>(rr + cc);
+  }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = bf2f(xu[i]) * bf2f(gu[i]);       // range_mod in fp32
-    } else {
-      res[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    const int cc = col < dim ? col : 0;
+    w0[c] = *reinterpret_cast<const f32x4*>(w + cc), w1[c] = *reinterpret_cast<const f32x4*>(w + cc + 4);
+    b0[c] = *reinterpret_cast<const f32x4*>(b + cc), b1[c] = *reinterpret_cast<const f32x4*>(b + cc + 4);
+  }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
-    }
+  for (int c = 0; c < NCH; ++c) {
+    const bool ok = c * 512 + lane * 8 < dim;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[c][i] = ok ? bf2f(xu[c][i]) * bf2f(gu[c][i]) : 0.f;       // range_mod in fp32
   }
   float s = 0.f;
 #pragma unroll
@@ -196,18 +206,15 @@ __global__ __launch_bounds__(256) void magi_gate_norm_kernel(const unsigned shor
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
-    if (col >= dim) continue;
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + col), w1 = *reinterpret_cast<const f32x4*>(w + col + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + col), b1 = *reinterpret_cast<const f32x4*>(b + col + 4);
     u16x8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float wi = (i < 4 ? w0[i] : w1[i - 4]) + one;
-      const float bi = i < 4 ? b0[i] : b1[i - 4];
+      const float wi = (i < 4 ? w0[c][i] : w1[c][i - 4]) + one;
+      const float bi = i < 4 ? b0[c][i] : b1[c][i - 4];
       const float n = (v[c][i] - mean) * rstd * wi + bi;                   // post_norm in fp32
       o[i] = f2bf(n + bf2f(res[c][i]));                                    // + residual.float(), one rounding
     }
-    *reinterpret_cast<u16x8*>(y + (size_t)r * ldy + col) = o;
+    if (col < dim) *reinterpret_cast<u16x8*>(y + (size_t)r * ldy + col) = o;
   }
 }
 
