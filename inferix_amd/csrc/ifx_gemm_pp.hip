@@ -351,6 +351,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
         while (__hip_atomic_load(ws_flag + first + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_s_barrier();
+    // s_barrier is IntrNoMem to hipcc: without this the partial-sum loads of the epilogue (raw_buffer_load, plain memory reads to the
+    // compiler) could be scheduled above the spin loop that makes them valid
+    asm volatile("" ::: "memory");
     if (wave == 0)
       for (int q = 0; q < n; ++q) __hip_atomic_store(ws_flag + first + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as found: zero
   };
@@ -763,18 +766,25 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     set_error("ifx_gemm_bf16: the ping-pong tile needs 8-byte aligned bias and 16-byte aligned residual / gate rows");
     return IFX_EINVAL;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
+  // CUs of the CURRENT device (one process may drive several): the persistent grid must not exceed them, a split-K consumer spins on
+  // a producer that has to be resident
+  static int cu_of_dev[16] = {0};
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+    if (cu_of_dev[dev] == 0) {
+      int v = 0;
+      cu_of_dev[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+    }
+    n_cu = cu_of_dev[dev];
   }
+  if (n_cu <= 0) n_cu = 256;
   const int BM = 64 * tj;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   // split K between two workgroups per tile when a workspace is given and the shape asks for it (gemm_pp_split: a function of N and K
   // only, so that a row's bits do not depend on how many rows the launch has)
-  const int ks = stream_k ? 0 : (!q8 && workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
+  // (only the 256-token tile is instantiated with the split: a caller that forces another tile on a split shape — gemm_variant 23 / 24
+  //  through ifx_gemm_bf16_ws — gets the unsplit launch, not an error)
+  const int ks = stream_k ? 0 : (!q8 && tj == 4 && workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
   const int total = tiles_m * tiles_n * (ks ? ks : 1), per_xcd = (total + 7) / 8;
   int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
   if (stream_k) {
@@ -817,27 +827,26 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     case IFX_EPI_GELU_TANH: IFX_LAUNCH_PP(IFX_EPI_GELU_TANH, T, S, Q); break; \
     case IFX_EPI_RESIDUAL: IFX_LAUNCH_PP(IFX_EPI_RESIDUAL, T, S, Q); break; \
     case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T, S, Q); break; \
-    default: return IFX_EINVAL;                                             \
+    default: set_error("ifx_gemm: the ping-pong tile has no epilogue %d", mode); return IFX_EINVAL; \
   }
   if (q8 && q8_int8) {
     if (tj == 4) { IFX_SWITCH_PP(4, 1, 2) }
     else if (tj == 3) { IFX_SWITCH_PP(3, 1, 2) }
     else if (tj == 2) { IFX_SWITCH_PP(2, 1, 2) }
-    else return IFX_EINVAL;
+    else { set_error("ifx_gemm_q8: no ping-pong tile of %d tokens", 64 * tj); return IFX_EINVAL; }
   } else if (q8) {
     if (tj == 4) { IFX_SWITCH_PP(4, 1, 1) }
     else if (tj == 3) { IFX_SWITCH_PP(3, 1, 1) }
     else if (tj == 2) { IFX_SWITCH_PP(2, 1, 1) }
-    else return IFX_EINVAL;
+    else { set_error("ifx_gemm_q8: no ping-pong tile of %d tokens", 64 * tj); return IFX_EINVAL; }
   } else if (ks == 0) {
     IFX_SWITCH_PP(2, 0, 0)
   } else if (ks == 2) {                              // split K: the 256-token tile only (what long-K, narrow-N shapes want)
-    if (tj != 4) return IFX_EINVAL;
     IFX_SWITCH_PP(4, 2, 0)
   } else if (tj == 4) { IFX_SWITCH_PP(4, 1, 0) }
   else if (tj == 3) { IFX_SWITCH_PP(3, 1, 0) }
   else if (tj == 2) { IFX_SWITCH_PP(2, 1, 0) }
-  else return IFX_EINVAL;
+  else { set_error("ifx_gemm_bf16: no ping-pong tile of %d tokens", 64 * tj); return IFX_EINVAL; }
 #undef IFX_SWITCH_PP
 #undef IFX_LAUNCH_PP
   return check_launch("ifx_gemm_bf16(pp)");
