@@ -64,6 +64,17 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + e);
 }
 
+// tanh-GELU of the FFN epilogues, x * sigmoid(2 u) with u = sqrt(2 / pi) (x + 0.044715 x^3), constants folded into the exponent:
+// exp(-2u) = exp2(x (c1 + c2 x^2)) — five VALU operations and two transcendentals per element where the unfolded form (u, then
+// __expf(-2u) = a multiply by log2(e) + v_exp_f32) takes nine; 128 elements per lane per 256 x 256 tile.  On every finite bf16 input the
+// bf16 result is the unfolded form's, bit for bit (checked on the CPU over all 65 280 inputs; both differ from torch's fp32 tanh
+// formula on the same 150, in the saturated tails).  v_rcp_f32 instead of the IEEE division sequence as before.
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  constexpr float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c2 = c1 * 0.044715f;
+  const float a = __builtin_fmaf(x * x, c2, c1) * x;
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
+}
+
 // x / s for the per-token quantisers, three VALU operations per element instead of the ~10 of the IEEE sequence (v_div_scale x2,
 // v_rcp, four FMAs, v_div_fmas, v_div_fixup):  q0 = x r;  e = fma(-q0, s, x) (exact residual);  q = fma(e, r, q0)  with r = rcp(s)
 // computed once per row.  CORRECTLY ROUNDED for the operands this is used on — x a bf16 value, s = RN(amax / QMAX) with amax a bf16

@@ -56,10 +56,6 @@ struct EpiArgs2 {
   int mod_slots, gate_slot, rows_per_group;
 };
 
-__device__ __forceinline__ float gelu_tanh_f2(float x) {
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));   // v_rcp_f32 (1 ulp fp32) instead of the IEEE division sequence
-}
 // exact (erf) GELU as torch.nn.functional.gelu evaluates it on a bf16 tensor: fp32 math, one rounding (MAGI CustomMLP,
 // inferix/models/magi/dit/dit_module.py:552).  Selected at run time inside the GELU epilogue instantiation: the epilogue's
 // otherwise unused `gate_slot` field carries 1 for IFX_EPI_GELU_ERF.
@@ -263,7 +259,7 @@ if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch arou
   for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
 } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_fast(bf2f(vv[e])));
 }
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
@@ -490,7 +486,7 @@ if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch arou
   for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
 } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_fast(bf2f(vv[e])));
 }
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
@@ -676,7 +672,7 @@ if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch arou
   for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
 } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_fast(bf2f(vv[e])));
 }
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
@@ -869,7 +865,7 @@ if (ea.gate_slot) {   // exact-erf GELU (IFX_EPI_GELU_ERF): a scalar branch arou
   for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
 } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_f2(bf2f(vv[e])));
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_fast(bf2f(vv[e])));
 }
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);

@@ -79,10 +79,6 @@ __device__ __forceinline__ v4i make_rsrc(const void* base, unsigned num_bytes) {
   r[3] = 0x00020000;
   return r;
 }
-__device__ __forceinline__ float gelu_tanh_p(float x) {
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
-}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -501,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
             for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_p(bf2f(vv[e])));
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_fast(bf2f(vv[e])));
           }
         } else {
           const u16x8 rv = __builtin_bit_cast(u16x8, e_res[j & 1][p]);

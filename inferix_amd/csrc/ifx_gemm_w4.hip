@@ -33,10 +33,6 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int A_OFF = 0, B_OFF = BM * BK * 2, STAGE = (BM + BN) * BK * 2;     // 64 KiB per stage, two stages
 constexpr int WM = 128, WN = 128, TJ = 4, TI = 4;
 
-__device__ __forceinline__ float gelu_tanh_w4(float x) {
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));   // v_rcp_f32 (1 ulp fp32) instead of the IEEE division sequence
-}
 }  // namespace w4
 
 #define W4_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
@@ -271,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf_f(bf2f(vv[e])));
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_w4(bf2f(vv[e])));
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_tanh_fast(bf2f(vv[e])));
         }
       } else {
         const u16x8 rv = *reinterpret_cast<const u16x8*>(ea.residual + (size_t)m * ea.ld_res + n);
