@@ -316,3 +316,42 @@ def test_pmc_traffic_stamp_matches_the_kernel_sources():
     t = bench.pmc_traffic(1)
     assert t["traffic"] and t["traffic"] > t["algorithmic_bytes_per_launch"], t
     assert bench._pmc_section("gemm_block")[0] is not None
+
+
+def test_bench_roofline_gemm_arithmetic_on_synthetic_records():
+    """`bench.roofline_gemm` (the `roofline_gemm` object of the bench line) on fabricated timer records: launches are bucketed by
+    (FLOPs, bytes) — O + gate and cross-o + residual share a bucket, cross-q and the two FFN launches have their own —, the per-layer
+    time is the sum of the six bucket means, achieved = 2 N (6 d^2 + 2 d ffn) / that, and the PMC fields come from the stamped file."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_gemm_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    rows, us = 4680, {"qkv": 70.0, "o+gate+res": 40.0, "cross_q": 36.0, "cross_o+res": 38.0, "ffn_up+gelu": 140.0, "ffn_down+gate+res": 120.0}
+    recs = []
+    for rep in range(3):
+        for nm, n_out, n_in, res in bench.BLOCK_GEMMS:
+            fl = 2.0 * rows * n_out * n_in
+            nb = 2.0 * (rows * n_in + n_out * n_in + rows * n_out * (1 + res))
+            recs.append(("gemm", Ev(0.0), Ev(us[nm] * 1e-3), fl, nb))
+    recs.append(("gemm", Ev(0.0), Ev(1.0), 2.0 * 3 * 1536 * 256, 123.0))          # a timestep-MLP launch: ignored
+    recs.append(("attn_self", Ev(0.0), Ev(1.0), 1.0, 1.0))
+    g = bench.roofline_gemm(recs, rows, forwards=35, layers=30, shards=1)
+    assert g is not None and g["bound"] == "mfma" and g["peak"] == 2500.0
+    assert abs(g["us_per_layer"] - sum(us.values())) < 0.11          # the shared bucket carries the mean of 40 and 38 twice
+    assert abs(g["per_launch"]["o+gate+res"]["us"] - 39.0) < 1e-6 and abs(g["per_launch"]["cross_q"]["us"] - 36.0) < 1e-6
+    flops = 2.0 * rows * (6 * 1536 ** 2 + 2 * 1536 * 8960)
+    assert g["algorithmic_flops_per_layer"] == flops
+    assert abs(g["achieved"] - flops / sum(us.values()) / 1e6) < 0.06 and abs(g["frac"] - g["achieved"] / 2500.0) < 1e-4
+    assert abs(g["ms_per_clip"] - sum(us.values()) * 35 * 30 / 1e3) < 0.06
+    assert g["traffic"] > g["algorithmic_bytes_per_layer"] and 0 < g["mfma_busy"] < 1 and g["traffic_over_algorithmic"] > 1
+    assert bench.roofline_gemm(recs[:3], rows, 35, 30, 1) is None      # a launch of the block missing (e.g. the K/V-first split): no object
+    sh = bench.roofline_gemm(recs, rows, 35, 30, 8)
+    assert sh["traffic"] is None and sh["mfma_busy"] is None            # counters were taken on the unsharded launches
