@@ -348,6 +348,16 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
       return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
                             ea.rows_per_group, (hipStream_t)stream, 2, workspace, nullptr, nullptr, nullptr, 0, 1);
   }
+  // Under gemm_small_split (a sequence-parallel rank: row-count dependent summation orders are allowed) narrow-N launches whose 128 x 128
+  // tiles make ONE round of at most 256 workgroups take tile 12 — 128 x 128 with K split between the two wave groups of the workgroup —
+  // ahead of the ping-pong tiles: at 2340 rows (P = 2) 19 x 12 = 228 workgroups against 60-120 work items of the 256-token ping-pong
+  // tile.  tools/bench_gemm_tiles.py 2340: 1536^2 28.1 / 25.8 -> 23.3 / 19.3 us (+ residual / bias only), 1536 x 8960 102.6 -> 82.1.
+  if (wide_ok && variant == 0 && gemm_small_split() && N <= 2048 && (K / 64) % 2 == 0 && K >= 1024) {
+    const int wgs128 = ((M + 127) / 128) * ((N + 127) / 128);
+    if (wgs128 > 128 && wgs128 <= 256)
+      return launch_gemm_lds_dma(12, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                                 ea.rows_per_group, (hipStream_t)stream);
+  }
   if (wide_ok && (variant == 0 || (variant >= 22 && variant <= 25))) {
     const bool ws_ok = workspace != nullptr && workspace_bytes >= (int64_t)gemm_pp_workspace_bytes(M, N, K) && variant != 25;
     int tj = variant == 0 ? pick_pp(M, N, K, mode, ws_ok) : (variant == 22 || variant == 25 ? 4 : variant == 23 ? 3 : 2);

@@ -602,6 +602,38 @@ def test_gemm_stream_k_variant_is_correct_and_deterministic(ops):
         assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-workgroup flags must be left zero"
 
 
+def test_gemm_small_split_auto_choice_at_2340_rows(ops):
+    """Round 4: under `gemm_small_split` (what a sequence-parallel model's forward scopes on) the narrow-N launches of a 2-way rank —
+    2340 rows x 1536 channels, K = 1536 and 8960: 228 tiles of 128 x 128 — take the in-workgroup split tile (variant 14) ahead of the
+    ping-pong tiles; without the option the auto choice is untouched.  Same bits as the forced variant, fp64-close, every epilogue."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(2340)
+    M, N, fs = 2340, 1536, 780
+    try:
+        for K in (1536, 8960):
+            x, w, b = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))
+            res, mod = gpu(rnd(g, M, N)), gpu(rnd(g, M // fs, 6, N, scale=0.5))
+            for kw in ({}, dict(epilogue=_hip.IFX_EPI_RESIDUAL, residual=res),
+                       dict(epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=2, rows_per_group=fs)):
+                ops.set_option("gemm_small_split", 0)
+                plain = ops.linear(x, w, b, **kw)
+                ops.set_option("gemm_variant", 14)
+                forced = ops.linear(x, w, b, **kw)
+                ops.set_option("gemm_variant", 0)
+                # (K = 8960: the default is the ping-pong tile's two-workgroup K split, first half + second half — the same two halves tile
+                #  12 adds, so the bits coincide; K = 1536: single pass against two halves)
+                assert torch.equal(plain, forced) == (K == 8960)
+                ops.set_option("gemm_small_split", 1)
+                auto = ops.linear(x, w, b, **kw)
+                assert torch.equal(auto, forced), f"K={K}: the auto choice under gemm_small_split is not tile 12"
+                assert_bf16_parity(auto, plain, max_ulp=2, max_mismatch_frac=0.03, floor=1.0, what=f"tile 12 vs default, K={K}")
+            y64 = x.cpu().double() @ w.cpu().double().t() + b.cpu().double()
+            assert rel_l2(ops.linear(x, w, b).cpu().double(), y64) < 3e-3
+    finally:
+        ops.set_option("gemm_variant", 0)
+        ops.set_option("gemm_small_split", 0)
+
+
 def test_gemm_split_k_tiles_refuse_indivisible_k(ops):
     """A forced split-K tile on a K it cannot split evenly is an error, not a silently different kernel; the auto choice
     (variant 0) only picks those tiles when K divides."""
