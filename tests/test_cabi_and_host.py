@@ -355,3 +355,55 @@ def test_bench_roofline_gemm_arithmetic_on_synthetic_records():
     assert bench.roofline_gemm(recs[:3], rows, 35, 30, 1) is None      # a launch of the block missing (e.g. the K/V-first split): no object
     sh = bench.roofline_gemm(recs, rows, 35, 30, 8)
     assert sh["traffic"] is None and sh["mfma_busy"] is None            # counters were taken on the unsharded launches
+
+
+def test_option_scope_restores_and_nests():
+    """`hip_ops.option_scope` (how a sequence-parallel model's forward turns `gemm_small_split` on for its own launches only, ADVICE
+    r3): sets on entry, restores the previous value on exit — also when nested and when the body raises — and leaves an equal value alone."""
+    import pytest
+    from inferix_amd import hip_ops as ops
+    ops.set_option("gemm_small_split", 0)
+    assert ops._OPTIONS["gemm_small_split"] == 0
+    with ops.option_scope("gemm_small_split", 1):
+        assert ops._OPTIONS["gemm_small_split"] == 1
+        with ops.option_scope("gemm_small_split", 1):          # already on: nothing to do, nothing to undo
+            assert ops._OPTIONS["gemm_small_split"] == 1
+        assert ops._OPTIONS["gemm_small_split"] == 1
+        with ops.option_scope("gemm_small_split", 0):
+            assert ops._OPTIONS["gemm_small_split"] == 0
+        assert ops._OPTIONS["gemm_small_split"] == 1
+    assert ops._OPTIONS["gemm_small_split"] == 0
+    with pytest.raises(RuntimeError):
+        with ops.option_scope("gemm_small_split", 1):
+            raise RuntimeError("body failed")
+    assert ops._OPTIONS["gemm_small_split"] == 0
+    # the workspace a GEMM shape asks for is cached per (shape, small_split): 585 x 1536 x 8960 splits across workgroups only without it
+    from inferix_amd import _hip
+    lib = _hip.load()
+    assert lib.ifx_gemm_workspace_bytes(585, 1536, 8960) > 0
+    with ops.option_scope("gemm_small_split", 1):
+        assert lib.ifx_gemm_workspace_bytes(585, 1536, 8960) == 0
+    assert lib.ifx_gemm_workspace_bytes(585, 1536, 8960) > 0
+
+
+def test_quantize_dynamic_resolves_names_like_the_quantised_model_oracle():
+    """Which linears `inferix_amd.quant.quantize_dynamic` quantises is decided by `_config_for`; which ones the quantised-model oracle
+    quantises by `oracle/quant_oracle.py::config_for`.  Both must resolve every nn.Linear name of the reference's transformer the same
+    way for any qconfig dict (longest matching module-name prefix, "" = default) — the example's dict and a few adversarial ones."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import quant_oracle as Q
+    from inferix_amd.quant import _BLOCK_LINEARS, _GLOBAL_LINEARS, _config_for
+    names = [n for n, _ in _GLOBAL_LINEARS]
+    for i in (0, 3, 29, 30):
+        for ref_name, key in _BLOCK_LINEARS:
+            names += [f"blocks.{i}.self_attn.{c}" for c in "qkv"] if key == "qkv" else [f"blocks.{i}.{ref_name}"]
+    dicts = [{"": 1, "text_embedding": None, "proj_out": None, "head": None}, {"": None, "blocks.3": 1}, {"": 1, "blocks.3.ffn": None, "blocks.3": 2},
+             {"": 1, "blocks.3.self_attn.q": None}, {"ffn": 1}, {"": 1, "head.head": None, "time_embedding.0": None}]
+    for d in dicts[:4] + dicts[5:]:
+        for n in names:
+            assert _config_for(n, d) == Q.config_for(n, d), (n, d)
+    ex = dicts[0]
+    assert [n for n in names if Q.config_for(n, ex) is None] == ["text_embedding.0", "text_embedding.2", "head.head"]
+    assert Q.config_for("blocks.30.ffn.0", {"": 1, "blocks.3": None}) == 1          # a prefix match stops at a module boundary
