@@ -41,7 +41,7 @@ typedef uint16_t ifx_bf16;
  * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static).  Callers built against another minor
  * must not call in: zero-initialise every struct (new fields default to 0 = off) and compare IFX_ABI_MINOR with
  * (ifx_version() >> 8) & 255 at load time, as inferix_amd/_hip.py does. */
-#define IFX_ABI_MINOR 4
+#define IFX_ABI_MINOR 5
 int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */
@@ -302,6 +302,15 @@ int ifx_quant_per_token(const ifx_bf16* x, int32_t ldx, void* q, int32_t ldq, fl
 int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
                 const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t format,
                 const ifx_epilogue* epi, void* stream);
+/* ifx_gemm_q8 with a caller-provided scratch buffer (the contract of ifx_gemm_bf16_ws: first 4096 bytes zero on entry and on exit,
+ * one stream per workspace): long-K, narrow-N launches — the block's FFN down-projection, 4680 x 1536 x 8960: 114 tiles of 256 x 256
+ * for 256 CUs — then run the 256-token ping-pong tile with K split between two workgroups.  Which shapes split is a function of N
+ * and K only (a row's bits do not depend on the launch's row count); e4m3: first half + second half in fp32, int8: the two exact
+ * int32 sums are added as integers — the same bits as the unsplit launch.  ifx_gemm_q8_workspace_bytes: what a shape wants (0 = none). */
+int64_t ifx_gemm_q8_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int ifx_gemm_q8_ws(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale, const ifx_bf16* bias,
+                   ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t format, const ifx_epilogue* epi,
+                   void* workspace, int64_t workspace_bytes, void* stream);
 /* ifx_layernorm_quant: ifx_layernorm followed by ifx_quant_per_token of its bf16 result, in one pass over the row — what the
  * quantised qkv / cross-attention q / ffn.0 linears of a block see (the reference's DAX wrapper quantises the input of every
  * nn.Linear, i.e. the norm's bf16 output: run_self_forcing_quantized.py:47-64, causal_model.py:419-428,470-476).  Same bytes and

@@ -123,6 +123,8 @@ SIGNATURES = {
     "ifx_quant_per_token": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "ifx_layernorm_quant": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ifx_gemm_q8": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
+    "ifx_gemm_q8_ws": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, C.c_int64, _vp]),
+    "ifx_gemm_q8_workspace_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "ifx_attn_fwd_paged_ld": (C.c_int, [_vp, _i32, _vp, _i32, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
                                         C.c_int64, _vp]),
     "ifx_gemm_q8_quant_out": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp, _i32, _vp]),
@@ -140,7 +142,7 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
-ABI_MINOR = 4      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
+ABI_MINOR = 5      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
 
 
 def load() -> C.CDLL:

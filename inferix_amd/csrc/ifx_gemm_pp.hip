@@ -368,23 +368,42 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     const bool has_bias = ea.bias != nullptr;
     const unsigned short* const bias_p = has_bias ? ea.bias : y;      // any valid address: the values are not used without a bias
     const unsigned bias_mask = has_bias ? 0xffffffffu : 0u;
+    // PRIV (8-bit operands, residual / gate epilogue, 256 tokens): the 48 registers of bias and weight scales do not fit next to 128
+    // accumulators, the residual double buffer and the gate rows — hipcc then spills 36-164 bytes per lane and picks loop-carried
+    // values for it (the K loop ran 4x slower: 326 us on the FFN down-projection).  There lane L keeps the bias and the scales of ONE
+    // register quad, (L & 7), for its own channel half — 6 registers — and every lane fetches quad (i, g)'s from lane
+    // (L & 32) | (i * 4 + g) with ds_bpermute when it gets there (48 crossbar reads per 32-token block; same values, same bits).
+    // (Parking the vectors in private memory was tried: volatile reads are waited for one by one, + 40 us per tile; plain ones
+    //  are hoisted back into registers by the scheduler and spill again.)
+    constexpr bool PRIV = Q8 != 0 && RES && TJ == 4;
     u32x2 e_bias[2][4];
+    int q_bias[2] = {0, 0}, q_sw[4] = {0, 0, 0, 0};   // PRIV: the quad (ln & 7) only, as separate scalars
+    if constexpr (PRIV) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + (ln & 7) * 8 + hi * 4);
+      q_bias[0] = (int)(b[0] & bias_mask), q_bias[1] = (int)(b[1] & bias_mask);
+      const u32x4 sq = *reinterpret_cast<const u32x4*>(ea.sw + e_n0 + (ln & 7) * 8 + hi * 4);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int e = 0; e < 4; ++e) q_sw[e] = (int)sq[e];
+    } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // no bias: the loaded bits are masked to +0.0 and added all the same (a branch per register quad costs more than 16 v_and)
-        const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + i * 32 + g * 8 + hi * 4);
-        e_bias[i][g] = u32x2{b[0] & bias_mask, b[1] & bias_mask};
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // no bias: the loaded bits are masked to +0.0 and added all the same (a branch per register quad costs more than 16 v_and)
+          const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + e_n0 + i * 32 + g * 8 + hi * 4);
+          e_bias[i][g] = u32x2{b[0] & bias_mask, b[1] & bias_mask};
+        }
+    }
     f32x4 e_sw[Q8 ? 2 : 1][Q8 ? 4 : 1];               // Q8: per-channel weight scales of the lane's channels, per-token scales of its TJ tokens
     float e_sa[Q8 ? TJ : 1];
     f32x4 e_qd[2];                                    // quantised output: the divisors of the 8 channels this lane stores per row
     if constexpr (Q8) {
+      if constexpr (!PRIV) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) e_sw[i][g] = *reinterpret_cast<const f32x4*>(ea.sw + e_n0 + i * 32 + g * 8 + hi * 4);
+          for (int g = 0; g < 4; ++g) e_sw[i][g] = *reinterpret_cast<const f32x4*>(ea.sw + e_n0 + i * 32 + g * 8 + hi * 4);
+      }
 #pragma unroll
       for (int j = 0; j < TJ; ++j) e_sa[j] = ea.sa[min(e_m0 + j * 32 + l31, M - 1)];
       if constexpr (EPI == IFX_EPI_GELU_TANH) {
@@ -422,15 +441,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     // use that it sinks into a branch (the masked store of a ragged tile) leaves the load "maybe pending" at the loop back-edge — it then
     // protects the registers with vmcnt(3 .. 0) in the middle of the NEXT K-step's fragment reads, which drains the whole DMA queue
     // (measured: the loader phase 1100 -> 1900 cycles in the residual / gate instantiations).
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_bias[i][g]));
-    if constexpr (Q8) {
+    if constexpr (PRIV) {
+      asm volatile("" : "+v"(q_bias[0]), "+v"(q_bias[1]), "+v"(q_sw[0]), "+v"(q_sw[1]), "+v"(q_sw[2]), "+v"(q_sw[3]));
+    } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_sw[i][g]));
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_bias[i][g]));
+    }
+    if constexpr (Q8) {
+      if constexpr (!PRIV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(e_sw[i][g]));
+      }
 #pragma unroll
       for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(e_sa[j]));
       if constexpr (EPI == IFX_EPI_GELU_TANH) asm volatile("" : "+v"(e_qd[0]), "+v"(e_qd[1]));
@@ -439,11 +464,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     for (int j = 0; j < TJ; ++j) {
       if (j + 1 < TJ) fetch_res(j + 1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if constexpr (Q8 == 2) {
+          if constexpr (Q8 == 2 && KS <= 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (float)__builtin_bit_cast(int, v[e]);                  // the exact int32 sum
           }
@@ -452,8 +477,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
             // the accumulator vectors first costs hipcc ~300 spilled registers): first half + second half, then the bias
             const f32x4 pq = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024, part_so, 16));
+            if constexpr (Q8 == 2) {                   // int8: both halves are exact int32 sums (bit patterns): the split does not change a bit
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += pq[e];
+              for (int e = 0; e < 4; ++e) {
+                const float pe = pq[e];                // (bit_cast of a vector ELEMENT expression reads element 0 whatever e is: hipcc 7.0)
+                v[e] = (float)(__builtin_bit_cast(int, v[e]) + __builtin_bit_cast(int, pe));
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += pq[e];
+            }
           }
           if constexpr (SK) {                          // the later K ranges of the tile, in ascending K order
             for (int q = 0; q < part_n; ++q) {
@@ -464,10 +497,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
             }
           }
           if constexpr (Q8) {
+            f32x4 swv;
+            if constexpr (PRIV) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(v[e], __fmul_rn(e_sa[j], e_sw[i][g][e]));   // not contracted with the bias add
+              for (int e = 0; e < 4; ++e)
+                swv[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((ln & 32) | (i * 4 + g)) << 2, q_sw[e]));
+            } else {
+              swv = e_sw[i][g];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(v[e], __fmul_rn(e_sa[j], swv[e]));   // not contracted with the bias add
           }
-          const u32x2 b = e_bias[i][g];
+          u32x2 b;
+          if constexpr (PRIV) {
+            b[0] = (unsigned)__builtin_amdgcn_ds_bpermute(((ln & 32) | (i * 4 + g)) << 2, q_bias[0]);
+            b[1] = (unsigned)__builtin_amdgcn_ds_bpermute(((ln & 32) | (i * 4 + g)) << 2, q_bias[1]);
+          } else {
+            b = e_bias[i][g];
+          }
           v[0] += __builtin_bit_cast(float, b[0] << 16);
           v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
           v[2] += __builtin_bit_cast(float, b[1] << 16);
@@ -478,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
           // channel nl = i * 32 + g * 8 + hi * 4 of token l31: 16-byte chunk (i * 4 + g) XOR (l31 & 7), half hi
           *reinterpret_cast<u16x4*>(wr + (((i * 4 + g) ^ (l31 & 7)) << 4)) = o;
         }
+      }
       wait_lds();                                            // wave-private region: no barrier
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -780,7 +828,8 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
   // only, so that a row's bits do not depend on how many rows the launch has)
   // (only the 256-token tile is instantiated with the split: a caller that forces another tile on a split shape — gemm_variant 23 / 24
   //  through ifx_gemm_bf16_ws — gets the unsplit launch, not an error)
-  const int ks = stream_k ? 0 : (!q8 && tj == 4 && workspace != nullptr && gemm_pp_split(N, K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
+  // (8-bit operands: a K-step is 128 elements, K counts elements; the same (N, K)-only rule on the step count)
+  const int ks = stream_k ? 0 : (tj == 4 && workspace != nullptr && gemm_pp_split(N, q8 ? K / 2 : K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
   const int total = tiles_m * tiles_n * (ks ? ks : 1), per_xcd = (total + 7) / 8;
   int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
   if (stream_k) {
@@ -825,7 +874,10 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     case IFX_EPI_GATE_RES: IFX_LAUNCH_PP(IFX_EPI_GATE_RES, T, S, Q); break; \
     default: set_error("ifx_gemm: the ping-pong tile has no epilogue %d", mode); return IFX_EINVAL; \
   }
-  if (q8 && q8_int8) {
+  if (q8 && ks == 2) {
+    if (q8_int8) { IFX_SWITCH_PP(4, 2, 2) }
+    else { IFX_SWITCH_PP(4, 2, 1) }
+  } else if (q8 && q8_int8) {
     if (tj == 4) { IFX_SWITCH_PP(4, 1, 2) }
     else if (tj == 3) { IFX_SWITCH_PP(3, 1, 2) }
     else if (tj == 2) { IFX_SWITCH_PP(2, 1, 2) }

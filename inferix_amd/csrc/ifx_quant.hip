@@ -605,6 +605,8 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
                    const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8);
+bool gemm_pp_split(int N, int K);
+size_t gemm_pp_workspace_bytes(int M, int N, int K);
 }
 
 // Ping-pong tile for an FP8 launch (tokens = 64 tj), 0 = none: the model of pick_pp (ifx_gemm.hip) — a K-step moves the same bytes and
@@ -625,9 +627,18 @@ static int pick_pp_q8(int M, int N, int K, int mode) {
   return best;
 }
 
+// Shapes that run the 256-token tile with K split between two workgroups when the caller gives a workspace (ifx_gemm_q8_ws): the rule
+// of the bf16 tiles on the K-STEP count (gemm_pp_split: N <= 2048, >= 64 steps, an even number of them) — a function of N and K only,
+// taken at ANY row count so that a row's summation order does not depend on it (unless the caller opted into row-count dependent
+// choices for shard-sized launches: gemm_small_split).
+static bool q8_split_shape(int M, int N, int K) {
+  return N % 64 == 0 && K % 128 == 0 && gemm_pp_split(N, K / 2) && gemm_pp_workspace_bytes(M, N, K / 2) > 0 && !(gemm_small_split() && M < 2048);
+}
+
 static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
                         const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
-                        int32_t format, const ifx_epilogue* epi, void* stream, const float* qdiv, int q_via_bf16) {
+                        int32_t format, const ifx_epilogue* epi, void* stream, const float* qdiv, int q_via_bf16,
+                        void* workspace = nullptr, int64_t workspace_bytes = 0) {
   IFX_REQUIRE(xq && wq && x_scale && w_scale && y && M >= 0 && N > 0 && K > 0, "ifx_gemm_q8: null/empty operand");
   IFX_REQUIRE(K % 128 == 0, "ifx_gemm_q8: K (%d) must be a multiple of 128", K);
   IFX_REQUIRE(N % 4 == 0 && ldx % 16 == 0 && ldy % 4 == 0, "ifx_gemm_q8: N %% 4, ldx %% 16, ldy %% 4 required");
@@ -668,14 +679,17 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
   // FP8 / INT8 launches of >= 1024 rows: the ping-pong tile (gemm_variant 22 / 23 / 24 force its 256 / 192 / 128-token form, 3 = never)
   if (wide_ok && gemm_variant() != 1 && gemm_variant() != 2 && gemm_variant() != 3) {
     const int v = gemm_variant();
-    int tj = v == 22 ? 4 : v == 23 ? 3 : v == 24 ? 2 : pick_pp_q8(M, N, K, mode);
+    const bool split_ok = qdiv == nullptr && v != 25 && workspace != nullptr && q8_split_shape(M, N, K) &&
+                          workspace_bytes >= (int64_t)gemm_pp_workspace_bytes(M, N, K / 2) &&
+                          (mode != IFX_EPI_GATE_RES || ea.rows_per_group >= 128);
+    int tj = (v == 22 || v == 25 || (v == 0 && split_ok)) ? 4 : v == 23 ? 3 : v == 24 ? 2 : pick_pp_q8(M, N, K, mode);
     if (mode == IFX_EPI_GATE_RES && ea.rows_per_group < 32 * tj) tj = ea.rows_per_group >= 64 ? 2 : 0;
     const bool aligned = ((uintptr_t)bias & 7) == 0 && ((uintptr_t)ea.residual & 15) == 0 && ((uintptr_t)ea.mod & 15) == 0 &&
                          ((uintptr_t)w_scale & 15) == 0 && ((uintptr_t)qdiv & 15) == 0 && ldx % 16 == 0 && N % 64 == 0 && K % 128 == 0;
     if (tj != 0 && aligned)
       return launch_gemm_pp((const unsigned short*)xp, ldx, (const unsigned short*)wp, y, ldy, M, N, K,
-                            mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj, nullptr, x_scale, w_scale, qdiv,
-                            q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0);
+                            mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj,
+                            split_ok && tj == 4 ? workspace : nullptr, x_scale, w_scale, qdiv, q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0);
   }
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
@@ -732,6 +746,17 @@ extern "C" int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, co
                            const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,
                            int32_t format, const ifx_epilogue* epi, void* stream) {
   return gemm_q8_impl(xq, ldx, x_scale, wq, w_scale, bias, y, ldy, M, N, K, format, epi, stream, nullptr, 0);
+}
+
+extern "C" int64_t ifx_gemm_q8_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (gemm_variant() != 0 && gemm_variant() != 22)) return 0;
+  return q8_split_shape(M, N, K) ? (int64_t)gemm_pp_workspace_bytes(M, N, K / 2) : 0;
+}
+
+extern "C" int ifx_gemm_q8_ws(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,
+                              const ifx_bf16* bias, ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t format,
+                              const ifx_epilogue* epi, void* workspace, int64_t workspace_bytes, void* stream) {
+  return gemm_q8_impl(xq, ldx, x_scale, wq, w_scale, bias, y, ldy, M, N, K, format, epi, stream, nullptr, 0, workspace, workspace_bytes);
 }
 
 extern "C" int ifx_gemm_q8_quant_out(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale,

@@ -554,11 +554,22 @@ def linear_q8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
         assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
+    wkey = ("q8", M, N, K, _OPTIONS.get("gemm_small_split", 0))
+    need = _GEMM_WS_NEED.get(wkey)
+    if need is None:
+        need = _GEMM_WS_NEED[wkey] = int(lib.ifx_gemm_q8_workspace_bytes(M, N, K))
     with _timed("gemm_q8", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * N):
-        _hip.check(lib.ifx_gemm_q8(_dev(xq, "xq", torch.uint8), xq.stride(0), _dev(x_scale, "x_scale", torch.float32),
-                                   _dev(wq, "wq", torch.uint8), _dev(w_scale, "w_scale", torch.float32),
-                                   _dev(bias, "bias") if bias is not None else None, _dev(out, "out"), ldy, M, N, K,
-                                   fmt, C.byref(epi), _stream()), "ifx_gemm_q8")
+        if need:       # long-K, narrow-N launches: the 256-token tile with K split between two workgroups (ifx_gemm_q8_ws)
+            ws = _gemm_workspace(xq.device, need)
+            _hip.check(lib.ifx_gemm_q8_ws(_dev(xq, "xq", torch.uint8), xq.stride(0), _dev(x_scale, "x_scale", torch.float32),
+                                          _dev(wq, "wq", torch.uint8), _dev(w_scale, "w_scale", torch.float32),
+                                          _dev(bias, "bias") if bias is not None else None, _dev(out, "out"), ldy, M, N, K,
+                                          fmt, C.byref(epi), ws.data_ptr(), ws.numel(), _stream()), "ifx_gemm_q8_ws")
+        else:
+            _hip.check(lib.ifx_gemm_q8(_dev(xq, "xq", torch.uint8), xq.stride(0), _dev(x_scale, "x_scale", torch.float32),
+                                       _dev(wq, "wq", torch.uint8), _dev(w_scale, "w_scale", torch.float32),
+                                       _dev(bias, "bias") if bias is not None else None, _dev(out, "out"), ldy, M, N, K,
+                                       fmt, C.byref(epi), _stream()), "ifx_gemm_q8")
     return out
 
 

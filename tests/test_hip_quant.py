@@ -151,6 +151,48 @@ def test_gemm_q8_ping_pong_tiles_vs_oracle(variant, fmt):
         ops.set_option("gemm_variant", 0)
 
 
+@pytest.mark.parametrize("fmt", [Q.FP8, Q.INT8])
+def test_gemm_q8_split_k_is_deterministic_row_invariant_and_exact_for_int8(fmt):
+    """Round 4: long-K, narrow-N 8-bit launches (the block's FFN down-projection, 1536 x 8960) run the 256-token ping-pong tile with K
+    split between two workgroups when `linear_q8` is given its workspace (ifx_gemm_q8_ws).  The split depends on (N, K) only: the
+    bits of a row do not depend on how many rows the launch has; run to run identical; the per-tile flags are left zero; int8 — two
+    exact int32 partial sums added as integers — is bit-identical to the unsplit launch, e4m3 differs from it by the one fp32
+    addition (bounded like any other tile choice, and against the oracle)."""
+    from inferix_amd import _hip, hip_ops as ops
+    from inferix_amd.quant import QConfig, quantize_weight
+    g = torch.Generator().manual_seed(8960 + fmt)
+    M, N, K, fs = 4680, 1536, 8960, 1560
+    assert _hip.load().ifx_gemm_q8_workspace_bytes(M, N, K) == 4096 + 19 * 6 * 256 * 256 * 4
+    assert _hip.load().ifx_gemm_q8_workspace_bytes(M, N, 1536) == 0 and _hip.load().ifx_gemm_q8_workspace_bytes(M, 8960, 1536) == 0
+    x, w, b = rnd(g, 2 * M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+    res, mod = rnd(g, 2 * M, N), rnd(g, 2 * M // fs, 6, N, scale=0.5)
+    wq, sw = quantize_weight(w.cuda(), QConfig(fmt, "t"))
+    xq, sx = ops.quant_per_token(x.cuda(), fmt)
+    kw = dict(epilogue=_hip.IFX_EPI_GATE_RES, mod=mod.cuda(), gate_slot=5, rows_per_group=fs)
+    run = lambda rows: ops.linear_q8(xq[:rows], sx[:rows], wq, sw, b.cuda(), fmt, residual=res.cuda()[:rows], **kw)
+    outs = [run(M) for _ in range(3)]
+    assert all(torch.equal(o, outs[0]) for o in outs), "split-K launches are deterministic"
+    for rows in (2 * M, 2340, 585, 300):
+        assert torch.equal(run(rows)[:min(rows, M)], outs[0][:min(rows, M)]), f"a row's bits must not depend on the row count ({rows})"
+    ops.set_option("gemm_variant", 25)                       # the 256-token tile without the split
+    try:
+        unsplit = run(M)
+    finally:
+        ops.set_option("gemm_variant", 0)
+    if fmt == Q.INT8:
+        assert torch.equal(unsplit, outs[0]), "int8: integer partial sums, the same bits as the unsplit launch"
+    else:
+        assert_bf16_parity(outs[0], unsplit, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what="e4m3 split-K vs single pass")
+    sel = slice(0, 512)
+    y = Q.linear_q8(x[sel], w, b, fmt)
+    gate = mod[:1, 5].unsqueeze(0).unsqueeze(2)
+    assert_bf16_parity(outs[0][sel], O.gated_residual(res[None, sel], y[None], gate, 1)[0], max_ulp=4, max_mismatch_frac=0.03, floor=1.0,
+                       what="q8 split-K gate epilogue vs oracle")
+    torch.cuda.synchronize()
+    for ws in ops._GEMM_WS.values():
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-tile flags must be left zero"
+
+
 @pytest.mark.parametrize("which", ["fp8", "int8"])
 def test_quantize_dynamic_model_rollout(which):
     """quantize_dynamic on the tiny model with the reference example's exclusion dict: the block linears become
