@@ -2,6 +2,9 @@ import sys, torch
 sys.path.insert(0, "/root/repo")
 from inferix_amd import hip_ops as ops, _hip
 dev = "cuda"
+import os
+if os.environ.get("IFX_SMALL_SPLIT") == "1":
+    ops.set_option("gemm_small_split", 1)      # what a sequence-parallel model's forward scopes on
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
 M, d, f = (int(sys.argv[1]) if len(sys.argv) > 1 else 4680), 1536, 8960
