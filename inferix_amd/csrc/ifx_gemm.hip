@@ -199,7 +199,20 @@ static int pick_pp(int M, int N, int K, int mode, bool have_ws) {
   if (N % 64 != 0 || K % 64 != 0) return 0;
   // the split shapes at ANY row count (a row's summation order must not depend on it) unless the caller opted into the row-count
   // dependent in-workgroup splits for small launches
-  if (have_ws && gemm_pp_split(N, K) && ((M + 255) / 256) * ((N + 255) / 256) <= 1024 && !(gemm_small_split() && M < 2048)) return 4;
+  if (have_ws && gemm_pp_split(N, K) && ((M + 255) / 256) * ((N + 255) / 256) <= 1024 && !(gemm_small_split() && M < 2048)) {
+    // 256 or 192 tokens per tile: twice the work items of half the K-steps; the height that needs less time by the rounds model (the
+    // bits do not depend on it).  4680 rows: 228 items = one round of the 256-token tile; 10800 rows (720p): 516 items = three rounds
+    // against three shorter ones of the 192-token tile's 684
+    const int tn = (N + 255) / 256, steps = K / 64 / 2;
+    const int i4 = ((M + 255) / 256) * tn * 2, i3 = ((M + 191) / 192) * tn * 2;
+    const float t4 = ((i4 + 255) / 256) * (steps * 1.6f + 9.f), t3 = ((i3 + 255) / 256) * (steps * 1.4f + 9.f);
+    static int allow3 = -1;
+    if (allow3 < 0) {
+      const char* e = getenv("IFX_PP_SPLIT_TJ3");     // lab: 0 = the split on the 256-token tile only (rounds 3-4 before this rule)
+      allow3 = e ? atoi(e) : 1;
+    }
+    return (allow3 && i3 <= 2048 && t3 < t4 && mode != IFX_EPI_GELU_TANH) ? 3 : 4;
+  }
   if (M < 1024) return 0;
   static const float step_us[5] = {0.f, 0.f, 1.2f, 1.4f, 1.6f};
   const float tile_us = (mode == IFX_EPI_GELU_TANH ? 8.f : 3.f);

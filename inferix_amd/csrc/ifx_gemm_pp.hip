@@ -779,10 +779,15 @@ bool gemm_pp_split(int N, int K) {
 }
 // stream-K (128-token tile): one 128 KiB slot per workgroup behind the 4 KiB of flags
 size_t gemm_pp_stream_k_workspace_bytes() { return 4096 + (size_t)256 * 128 * 256 * 4; }
+// (the split runs on the 256- or the 192-token tile — whichever needs fewer rounds, pick_pp; the tile height does not change a bit of
+//  the result — so the workspace covers the larger of the two tilings: 4096 bytes of flags + one fp32 tile image per tile)
 size_t gemm_pp_workspace_bytes(int M, int N, int K) {
   if (!gemm_pp_split(N, K)) return 0;
-  const size_t tiles = (size_t)((M + 255) / 256) * ((N + 255) / 256);
-  return tiles <= 1024 ? 4096 + tiles * 256 * 256 * 4 : 0;
+  const size_t tn = (size_t)(N + 255) / 256;
+  const size_t t4 = (size_t)((M + 255) / 256) * tn, t3 = (size_t)((M + 191) / 192) * tn;
+  if (t4 > 1024) return 0;
+  const size_t b4 = t4 * 256 * 256 * 4, b3 = t3 <= 1024 ? t3 * 192 * 256 * 4 : 0;
+  return 4096 + (b4 > b3 ? b4 : b3);
 }
 
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
@@ -826,10 +831,11 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   // split K between two workgroups per tile when a workspace is given and the shape asks for it (gemm_pp_split: a function of N and K
   // only, so that a row's bits do not depend on how many rows the launch has)
-  // (only the 256-token tile is instantiated with the split: a caller that forces another tile on a split shape — gemm_variant 23 / 24
-  //  through ifx_gemm_bf16_ws — gets the unsplit launch, not an error)
+  // (the 256- and 192-token tiles are instantiated with the split: a caller that forces the 128-token tile on a split shape — gemm_variant
+  //  24 through ifx_gemm_bf16_ws — gets the unsplit launch, not an error)
   // (8-bit operands: a K-step is 128 elements, K counts elements; the same (N, K)-only rule on the step count)
-  const int ks = stream_k ? 0 : (tj == 4 && workspace != nullptr && gemm_pp_split(N, q8 ? K / 2 : K) && tiles_m * tiles_n <= 1024) ? 2 : 1;
+  const int ks = stream_k ? 0 : ((tj == 4 || (tj == 3 && !q8)) && workspace != nullptr && gemm_pp_split(N, q8 ? K / 2 : K) &&
+                                 tiles_m * tiles_n <= 1024) ? 2 : 1;
   const int total = tiles_m * tiles_n * (ks ? ks : 1), per_xcd = (total + 7) / 8;
   int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
   if (stream_k) {
@@ -889,8 +895,9 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     else { set_error("ifx_gemm_q8: no ping-pong tile of %d tokens", 64 * tj); return IFX_EINVAL; }
   } else if (ks == 0) {
     IFX_SWITCH_PP(2, 0, 0)
-  } else if (ks == 2) {                              // split K: the 256-token tile only (what long-K, narrow-N shapes want)
-    IFX_SWITCH_PP(4, 2, 0)
+  } else if (ks == 2) {                              // split K: long-K, narrow-N shapes on the 256- or the 192-token tile
+    if (tj == 4) { IFX_SWITCH_PP(4, 2, 0) }
+    else { IFX_SWITCH_PP(3, 2, 0) }
   } else if (tj == 4) { IFX_SWITCH_PP(4, 1, 0) }
   else if (tj == 3) { IFX_SWITCH_PP(3, 1, 0) }
   else if (tj == 2) { IFX_SWITCH_PP(2, 1, 0) }

@@ -563,6 +563,11 @@ def test_gemm_ping_pong_split_k_is_deterministic_and_row_invariant(ops):
         assert all(torch.equal(o, outs[0]) for o in outs)
         both = ops.linear(x, w, b, **kw2)
         assert torch.equal(both[:M], outs[0]), f"N={N} K={K}: a row's bits changed with the number of rows in the launch"
+        if N == 1536:
+            # 7020 rows (nine 480p frames / a 720p partial block): the split runs on the 192-token tile there (fewer rounds), on the
+            # 256-token tile at 4680 and 9360 rows — the tile height must not change a bit
+            part = ops.linear(x[:7020], w, b, **dict(kw, residual=res[:7020]))
+            assert torch.equal(part[:M], outs[0]), "the 192-token split tile gives other bits than the 256-token one"
         ops.set_option("gemm_variant", 25)
         try:
             single = ops.linear(x[:M], w, b, **kw)
