@@ -28,6 +28,30 @@ def test_cabi_library_loads_and_exports_all_declared_symbols():
     assert lib.ifx_last_error() is not None
 
 
+def test_cabi_gemm_workspace_rules_are_functions_of_n_and_k():
+    """`ifx_gemm_workspace_bytes` / `ifx_gemm_q8_workspace_bytes` (pure arithmetic, no GPU): which launches get the two-workgroup K
+    split is decided by (N, K) alone — N <= 2048, at least 64 K-steps, an even number of them — at every row count, so that a row's
+    summation order does not depend on the batch; the size covers the larger of the 256- and 192-token tilings (4096 bytes of flags +
+    one fp32 image per tile); `gemm_small_split` (a sequence-parallel rank) opts launches below 2048 rows out of it."""
+    from inferix_amd import _hip
+    lib = _hip.load()
+    tile = lambda M, t: -(-M // t) * 6 * t * 256 * 4
+    for M in (300, 585, 4680, 7020, 9360, 10800):
+        want = 4096 + max(tile(M, 256), tile(M, 192))
+        assert lib.ifx_gemm_workspace_bytes(M, 1536, 8960) == want, M                   # the block's FFN down-projection
+        assert lib.ifx_gemm_q8_workspace_bytes(M, 1536, 8960) == want, M                # 70 K-steps of 128 one-byte elements
+        assert lib.ifx_gemm_workspace_bytes(M, 1536, 1536) == 0 and lib.ifx_gemm_workspace_bytes(M, 8960, 1536) == 0
+        assert lib.ifx_gemm_workspace_bytes(M, 4608, 8960) == 0                         # N > 2048
+        assert lib.ifx_gemm_q8_workspace_bytes(M, 1536, 4096) == 0                      # 32 K-steps
+        assert lib.ifx_gemm_q8_workspace_bytes(M, 1536, 8960 + 128) == 0                # an odd number of K-steps
+    assert lib.ifx_set_option(b"gemm_small_split", 1) == 0
+    try:
+        assert lib.ifx_gemm_workspace_bytes(585, 1536, 8960) == 0 and lib.ifx_gemm_q8_workspace_bytes(585, 1536, 8960) == 0
+        assert lib.ifx_gemm_workspace_bytes(4680, 1536, 8960) > 0 and lib.ifx_gemm_q8_workspace_bytes(4680, 1536, 8960) > 0
+    finally:
+        lib.ifx_set_option(b"gemm_small_split", 0)
+
+
 def test_cabi_argument_validation_without_gpu():
     """Bad arguments are rejected before any launch (no GPU needed): negative code + message, no crash."""
     import ctypes as C
