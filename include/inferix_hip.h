@@ -38,10 +38,10 @@ typedef uint16_t ifx_bf16;
 
 /* library identity ------------------------------------------------------- */
 /* The MINOR number is the ABI generation: it changes whenever an argument struct gains a field or an entry point changes its
- * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static).  Callers built against another minor
+ * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static; 0.6: ifx_get_option, ifx_device_error, bounded device waits).  Callers built against another minor
  * must not call in: zero-initialise every struct (new fields default to 0 = off) and compare IFX_ABI_MINOR with
  * (ifx_version() >> 8) & 255 at load time, as inferix_amd/_hip.py does. */
-#define IFX_ABI_MINOR 5
+#define IFX_ABI_MINOR 6
 int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */
@@ -72,6 +72,19 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   7 software-pipelined and unrolled four times over constant LDS slots (what 0 = auto picks for large launches)
  * Results are identical across variants up to fp32 summation order.  Returns IFX_EINVAL for unknown keys. */
 int ifx_set_option(const char* key, int32_t value);
+/* The value an option has NOW in the library (set through ifx_set_option by anyone in the process, or its environment default):
+ * what a scoped override has to put back (a Python-side mirror misses options set through another binding).
+ * Further keys of both calls:
+ *   "spin_timeout_ms": budget of every DEVICE-side wait (the split-K / stream-K hand-off of ifx_gemm_bf16_ws / ifx_gemm_q8_ws), 1 ..
+ *                      600000, default 2000 (env IFX_SPIN_TIMEOUT_MS).  A wait that runs out raises the device error word, the launch
+ *                      completes with invalid results instead of hanging the GPU.
+ *   "spin_fault":      tests only — 1 keeps the producers' flags down so that every such wait runs into its budget. */
+int ifx_get_option(const char* key, int32_t* value);
+/* Device error word: 0, or (kind << 24) | detail of the first wait a kernel gave up since the word was last cleared (kind 1 = split-K /
+ * stream-K consumer, detail = flag index).  Pinned host memory: reading it needs no device synchronisation, but a launch only shows up
+ * here once it has run — check after the stream has been synchronised.  `clear` != 0 resets the word.  ifx_last_error() reports (and
+ * clears) a raised word ahead of the thread's last host-side message. */
+int32_t ifx_device_error(int32_t clear);
 
 /* ------------------------------------------------------------------------
  * Paged KV cache view (one request, one layer).
@@ -306,7 +319,13 @@ int ifx_gemm_q8(const void* xq, int32_t ldx, const float* x_scale, const void* w
  * one stream per workspace): long-K, narrow-N launches — the block's FFN down-projection, 4680 x 1536 x 8960: 114 tiles of 256 x 256
  * for 256 CUs — then run the 256-token ping-pong tile with K split between two workgroups.  Which shapes split is a function of N
  * and K only (a row's bits do not depend on the launch's row count); e4m3: first half + second half in fp32, int8: the two exact
- * int32 sums are added as integers — the same bits as the unsplit launch.  ifx_gemm_q8_workspace_bytes: what a shape wants (0 = none). */
+ * int32 sums are added as integers — the same bits as the unsplit launch.  ifx_gemm_q8_workspace_bytes: what a shape wants (0 = none).
+ * e4m3 BIT STABILITY: "a row's bits do not depend on the launch" holds when every launch of a shape goes through THIS entry
+ * point with the workspace it asks for — what inferix_amd does.  A launch of a split shape runs UNSPLIT (first + second K half summed
+ * in one fp32 chain instead of two: e4m3 results may differ in a few elements per million, int8 results never) when: the caller uses
+ * plain ifx_gemm_q8 or passes no / too small a workspace; the gate epilogue has rows_per_group < 128; ifx_gemm_q8_quant_out (static
+ * output quantiser) is used; bias / residual / gate / scale pointers or ldx miss the tile's alignment (8 / 16 bytes, ldx % 16); the
+ * launch has more than 1024 tiles of 256 x 256 (M > ~43 000 at N = 1536); or gemm_variant forces another tile. */
 int64_t ifx_gemm_q8_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int ifx_gemm_q8_ws(const void* xq, int32_t ldx, const float* x_scale, const void* wq, const float* w_scale, const ifx_bf16* bias,
                    ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t format, const ifx_epilogue* epi,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "ifx_last_error": (C.c_char_p, []),
     "ifx_arch": (C.c_char_p, []),
     "ifx_set_option": (C.c_int, [C.c_char_p, _i32]),
+    "ifx_get_option": (C.c_int, [C.c_char_p, C.POINTER(_i32)]),
+    "ifx_device_error": (_i32, [_i32]),
     "ifx_attn_fwd_paged": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _vp]),
     "ifx_attn_split_plan": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int64)]),
     "ifx_attn_fwd_paged_split": (C.c_int, [_vp, _vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _i32, _vp,
@@ -142,7 +144,7 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
-ABI_MINOR = 5      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
+ABI_MINOR = 6      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
 
 
 def load() -> C.CDLL:

@@ -103,8 +103,11 @@ struct RowDivisor {
 // Wave-wide reductions on the DPP path (no LDS traffic): hipcc lowers `__shfl_xor` to ds_bpermute_b32 + s_waitcnt lgkmcnt(0), an LDS
 // round trip of ~100 cycles per step — twelve of them in a row of LayerNorm, back to back on the critical path of a kernel that lives
 // for 8 us.  Steps: quad_perm xor 1, xor 2, row_half_mirror (= xor 4 once quads agree), row_mirror (= xor 8), row_bcast15 into rows
-// 1 / 3, row_bcast31 into rows 2 / 3; lane 63 then holds the total, read back as a scalar.  Same pairing as the xor butterfly
-// ((S0 + S1) + (S2 + S3) over the four 16-lane row sums, fp add is commutative): the results are bit-identical to it.
+// 1 / 3, row_bcast31 into rows 2 / 3; lane 63 then holds the total, read back as a scalar.  The association tree is that of an
+// ASCENDING-offset xor butterfly (1, 2, 4, 8 inside a row, then (S0 + S1) + (S2 + S3) over the four 16-lane row sums; fp add is
+// commutative): bit-identical to that butterfly — NOT to the descending-offset loop (32 .. 1) the kernels used before round 4, so
+// LayerNorm / RMSNorm / softmax statistics moved in their last fp32 bits at that commit (every golden is compared
+// through the bf16 / ULP rules of tests/util.py, none pins fp32 statistics bit for bit).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_or(float old, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
@@ -145,6 +148,9 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 int gemm_variant();   // 0 auto, 1 register-staged 128x128, 2..8 LDS-DMA tiles (see include/inferix_hip.h)
 int gemm_small_split();   // 1: launches of at most one workgroup per CU may split K between the wave groups of a workgroup (row-count dependent bits)
+unsigned* device_error_word();    // pinned host word, mapped into every device, that a kernel raises when it gives up a wait (ifx_core.hip); may be nullptr
+long long spin_timeout_ticks();   // budget of a device-side wait in ticks of the 100 MHz wall clock (option "spin_timeout_ms", default 2000 ms)
+int spin_fault();                 // lab / tests: 1 = split-K producers do not raise their flag, so that the consumer's wait runs into its budget
 int attn_variant();   // 0 auto (= 7 for large launches), 1 four-wave kernel, 2 ping-pong, 3 three groups, 4 free-running, 5 software-pipelined, 6 its two-per-CU form, 7 its four-times-unrolled form
 
 }  // namespace ifx

@@ -311,6 +311,15 @@ static int pick_tile(int M, int N, int K) {
 
 using namespace ifx;
 
+// ONE definition of "this launch takes the in-workgroup split 128 x 128 tile ahead of the ping-pong tiles", used by the launcher and by
+// ifx_gemm_workspace_bytes (the two had drifted — the workspace query still reported up to 75 MB of split-K scratch for
+// launches that never touch it)
+static bool small_split_takes_tile12(int M, int N, int K) {
+  if (!gemm_small_split() || N > 2048 || (K / 64) % 2 != 0 || K < 1024) return false;
+  const int wgs128 = ((M + 127) / 128) * ((N + 127) / 128);
+  return wgs128 > 128 && wgs128 <= 256;
+}
+
 static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
                           int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* stream, void* workspace,
                           int64_t workspace_bytes) {
@@ -365,12 +374,9 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
   // tiles make ONE round of at most 256 workgroups take tile 12 — 128 x 128 with K split between the two wave groups of the workgroup —
   // ahead of the ping-pong tiles: at 2340 rows (P = 2) 19 x 12 = 228 workgroups against 60-120 work items of the 256-token ping-pong
   // tile.  tools/bench_gemm_tiles.py 2340: 1536^2 28.1 / 25.8 -> 23.3 / 19.3 us (+ residual / bias only), 1536 x 8960 102.6 -> 82.1.
-  if (wide_ok && variant == 0 && gemm_small_split() && N <= 2048 && (K / 64) % 2 == 0 && K >= 1024) {
-    const int wgs128 = ((M + 127) / 128) * ((N + 127) / 128);
-    if (wgs128 > 128 && wgs128 <= 256)
-      return launch_gemm_lds_dma(12, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
-                                 ea.rows_per_group, (hipStream_t)stream);
-  }
+  if (wide_ok && variant == 0 && small_split_takes_tile12(M, N, K))
+    return launch_gemm_lds_dma(12, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                               ea.rows_per_group, (hipStream_t)stream);
   if (wide_ok && (variant == 0 || (variant >= 22 && variant <= 25))) {
     const bool ws_ok = workspace != nullptr && workspace_bytes >= (int64_t)gemm_pp_workspace_bytes(M, N, K) && variant != 25;
     int tj = variant == 0 ? pick_pp(M, N, K, mode, ws_ok) : (variant == 22 || variant == 25 ? 4 : variant == 23 ? 3 : 2);
@@ -421,6 +427,7 @@ extern "C" int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   const int v = gemm_variant();
   if (v == 20) return want_w4_splitk(M, N, K) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
   if (v == 26 && N % 64 == 0 && K % 64 == 0) return (int64_t)gemm_pp_stream_k_workspace_bytes();
+  if (v == 0 && N % 8 == 0 && small_split_takes_tile12(M, N, K)) return 0;      // the launcher's shortcut (wide_ok needs N % 8 == 0)
   if ((v == 0 && N % 64 == 0 && K % 64 == 0 && !(gemm_small_split() && M < 2048)) || v == 22) return (int64_t)gemm_pp_workspace_bytes(M, N, K);
   return 0;
 }

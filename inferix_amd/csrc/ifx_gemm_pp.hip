@@ -105,7 +105,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
                                                          int ldy, int M, int N, int K, int tiles_m, int total, int per_xcd,
                                                          int wg_per_xcd, EpiArgsP ea, unsigned long long* __restrict__ trace, int dbg,
-                                                         float* __restrict__ ws_part, unsigned* __restrict__ ws_flag) {
+                                                         float* __restrict__ ws_part, unsigned* __restrict__ ws_flag,
+                                                         unsigned* __restrict__ err_word, long long spin_ticks) {
   using namespace gpp;
   constexpr int BM = 64 * TJ;               // tokens per tile: two groups x TJ blocks of 32
   constexpr int GM = 4;                     // row tiles per rasterisation group (see ifx_gemm_glds.hip)
@@ -343,8 +344,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   auto consumer_sync = [&](int i) __attribute__((always_inline)) {              // all eight waves: the partial sums the epilogue adds are complete and visible
     const int first = SK ? sk_p + 1 : item_tile(i), n = item_parts(i);
     if (wave == 0) {
-      for (int q = 0; q < n; ++q)
-        while (__hip_atomic_load(ws_flag + first + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+      // BOUNDED (round-4 verdict): a producer that is not resident (a grid larger than the chip admits, a preempted queue)
+      // would otherwise hang the GPU.  After `spin_ticks` of the 100 MHz wall clock the wait gives up, raises the device error word
+      // (ifx_last_error / ifx_device_error report it) and the launch runs to its end on whatever the workspace holds.
+      const long long t0 = wall_clock64();
+      bool gave_up = false;
+      for (int q = 0; q < n && !gave_up; ++q)
+        while (__hip_atomic_load(ws_flag + first + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t0 > spin_ticks) {
+            gave_up = true;
+            if (err_word != nullptr)
+              __hip_atomic_store(err_word, (1u << 24) | ((unsigned)(first + q) & 0xffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+        }
     }
     __builtin_amdgcn_s_barrier();
     // s_barrier is IntrNoMem to hipcc: without this the partial-sum loads of the epilogue (raw_buffer_load, plain memory reads to the
@@ -662,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
       // ---------------- phase 2g: MFMA ----------------
       PP_STAMP();
       if (KS != 1 && flag_pending) {                  // every wave waited for its dump before the barrier above
-        if (wave == 0) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0 && !(dbg & 32)) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag_pending = 0;
       }
       if (!(dbg & 2)) {
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     }
     if (KS != 1) {
       __builtin_amdgcn_s_barrier();                  // group 1's dump of the last item is complete as well
-      if (flag_pending && wave == 0) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (flag_pending && wave == 0 && !(dbg & 32)) __hip_atomic_store(ws_flag + flag_pending - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     // x-upper(0); x-lower(0), x-upper(1): the x-upper cursor runs one K-step ahead of the x-lower cursor
@@ -856,6 +870,11 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     const char* e = getenv("IFX_PP_DEBUG");       // lab only: 1 all workgroups stream tile 0, 2 no MFMAs, 4 K rotation by column tile, 16 staggered loaders
     dbg = e ? atoi(e) : 0;
   }
+  // 32 = fault injection (ifx_set_option "spin_fault"): the producers of a split-K / stream-K launch keep their flags down, so that every
+  // consumer's wait runs into its budget — the timeout path's test (tests/test_hip_kernels.py)
+  const int dbg_launch = dbg | (spin_fault() ? 32 : 0);
+  unsigned* const err_word = device_error_word();
+  const long long spin_ticks = spin_timeout_ticks();
 #if IFX_PP_TRACE
   if (!trace) {
     const char* e = getenv("IFX_PP_TRACE_PTR");
@@ -870,7 +889,7 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
       attr_set = true;                                                                                                               \
     }                                                                                                                                \
     hipLaunchKernelGGL((gemm_pp_kernel<E, T, S, Q>), grid, block, LDS_BYTES, s, x, ldx, w, y, ldy, M, N, K, tiles_m, total, per_xcd, \
-                       wg_per_xcd, ea, trace, dbg, ws_part, ws_flag);                                                                \
+                       wg_per_xcd, ea, trace, dbg_launch, ws_part, ws_flag, err_word, spin_ticks);                                   \
   } while (0)
 #define IFX_SWITCH_PP(T, S, Q)                                              \
   switch (mode) {                                                           \

@@ -258,12 +258,34 @@ def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[tor
     return q_out
 
 
-_OPTIONS: dict = {}          # key -> value last set through set_option in this process (unset = the library's default, 0)
+_OPTIONS: dict = {}          # key -> value last seen in the library (set_option / option_scope refresh it from ifx_get_option)
+
+
+def get_option(key: str) -> int:
+    """The value the LIBRARY holds for an option right now (`ifx_get_option`): whoever set it — this module, another binding of the
+    same process, or the environment default."""
+    v = C.c_int32(0)
+    _hip.check(_hip.load().ifx_get_option(key.encode(), C.byref(v)), "ifx_get_option")
+    _OPTIONS[key] = int(v.value)
+    return int(v.value)
+
+
+def device_error(clear: bool = True) -> int:
+    """0, or the code of the first device-side wait a kernel gave up (`ifx_device_error`; meaningful once the stream has been
+    synchronised).  `check_device()` raises on it."""
+    return int(_hip.load().ifx_device_error(1 if clear else 0))
+
+
+def check_device(what: str = "") -> None:
+    """Raise if a kernel gave up a device-side wait since the last check (call after a synchronisation)."""
+    if device_error(clear=False):
+        msg = _hip.load().ifx_last_error().decode("utf-8", "replace")       # reports and clears the word
+        raise _hip.HipKernelError(f"{what + ': ' if what else ''}{msg}")
 
 
 def set_option(key: str, value: int) -> None:
-    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..26, 'attn_variant' 0..7, 'gemm_small_split' 0/1
-    (include/inferix_hip.h); 0 = choose by shape."""
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..26, 'attn_variant' 0..7, 'gemm_small_split' 0/1,
+    'spin_timeout_ms', 'spin_fault' (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
     _OPTIONS[key] = int(value)
     if key == "attn_variant":
@@ -280,7 +302,7 @@ class option_scope:
         self.key, self.value, self.prev = key, int(value), 0
 
     def __enter__(self):
-        self.prev = _OPTIONS.get(self.key, 0)
+        self.prev = get_option(self.key)         # the library's value, not a mirror: options set through lib.ifx_set_option count
         if self.prev != self.value:
             set_option(self.key, self.value)
         return self

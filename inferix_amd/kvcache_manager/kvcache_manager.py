@@ -94,7 +94,7 @@ class KVCacheManager:
     def __init__(self, device: Union[str, torch.device, int]):
         self.device = torch.device(device)
         self.serial = next(KVCacheManager._serials)
-        self._free_listeners: List[Callable[[str], None]] = []   # called with the request id on `free` (peer-mapping owners)
+        self._free_listeners: List[tuple] = []   # (fn, takes_layer): called on `free` / `free_layer` (peer-mapping owners)
         self.offload_device = torch.device("cpu")
         self.request_to_kv_caches: Dict[str, KVCaches] = {}
         self._generation: Dict[tuple, int] = {}      # (request id, layer) -> how many times that layer has been allocated
@@ -123,15 +123,26 @@ class KVCacheManager:
         del self.request_to_kv_caches[req.request_id]
         self._notify_free(req.request_id)
 
-    def add_free_listener(self, fn: Callable[[str], None]) -> None:
-        """`fn(request_id)` runs whenever a request (or one of its layers) is freed: the sequence-parallel peer-store exchange drops
-        its IPC address book for that request there (inferix_amd.sequence_parallel.PeerStoreExchange.forget)."""
-        if fn not in self._free_listeners:
-            self._free_listeners.append(fn)
+    def add_free_listener(self, fn: Callable[..., None]) -> None:
+        """`fn(request_id)` runs when a request is freed, `fn(request_id, layer_name)` when ONE of its layers is (listeners that take a
+        single argument get `fn(request_id)` for both): the sequence-parallel peer-store exchange drops its IPC address book for exactly
+        that (request, layer) there (inferix_amd.sequence_parallel.PeerStoreExchange.forget)."""
+        if any(f == fn for f, _ in self._free_listeners):
+            return
+        import inspect
+        try:
+            params = list(inspect.signature(fn).parameters.values())
+            takes_layer = len(params) >= 2 or any(p.kind == p.VAR_POSITIONAL for p in params)
+        except (TypeError, ValueError):          # builtins without a signature: the one-argument form
+            takes_layer = False
+        self._free_listeners.append((fn, takes_layer))
 
-    def _notify_free(self, request_id: str) -> None:
-        for fn in list(self._free_listeners):
-            fn(request_id)
+    def _notify_free(self, request_id: str, layer_name: Optional[str] = None) -> None:
+        for fn, takes_layer in list(self._free_listeners):
+            if layer_name is not None and takes_layer:
+                fn(request_id, layer_name)
+            else:
+                fn(request_id)
 
     def free_layer(self, req: KVCacheRequest, layer_name: str) -> None:
         c = self.request_to_kv_caches[req.request_id]
@@ -139,7 +150,7 @@ class KVCacheManager:
         del c.specs[layer_name]
         c.page_tables.pop(layer_name, None)
         c.views.pop(layer_name, None)
-        self._notify_free(req.request_id)
+        self._notify_free(req.request_id, layer_name)
 
     def allocation_id(self, req: KVCacheRequest, layer_name: str) -> tuple:
         """(request id, layer, (manager serial, generation)): names ONE allocation of a layer's cache in this process.  A data pointer

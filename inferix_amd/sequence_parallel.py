@@ -137,6 +137,8 @@ class PeerStoreExchange:
         self.timeout_ms = timeout_ms
         self._opened: Dict[bytes, int] = {}                 # IPC handle -> base address mapped into this process
         self._views: Dict[Tuple, Tuple[List[int], List[int]]] = {}
+        self._view_handles: Dict[Tuple, set] = {}           # allocation id -> the peer IPC handles its addresses lie in
+        self._handle_refs: Dict[bytes, int] = {}            # IPC handle -> number of remembered views (+ the flag blocks) using it
         self._epoch = [0] * self.MAX_LAYERS
         self.status = torch.zeros(1, dtype=torch.int32, device="cuda")
         try:
@@ -148,13 +150,16 @@ class PeerStoreExchange:
                 raise RuntimeError("peer-store exchange: could not allocate the flag block")
             self.peer_flags = [self.flags.ptr]
         else:
-            self.peer_flags = self._exchange_addresses(self.flags.ptr if self.flags is not None else None)
+            pinned: set = set()
+            self.peer_flags = self._exchange_addresses(self.flags.ptr if self.flags is not None else None, pinned)
+            for h in pinned:                                # the flag blocks stay mapped for the life of the exchange
+                self._handle_refs[h] = self._handle_refs.get(h, 0) + 1
 
     # ---- addresses ----
-    def _exchange_addresses(self, ptr: Optional[int]) -> List[int]:
+    def _exchange_addresses(self, ptr: Optional[int], used: Optional[set] = None) -> List[int]:
         """This rank's device address `ptr` -> the same buffer of every rank, mapped into this process (rank order).  Every rank
         runs the same two collectives whatever fails locally, and all ranks raise together: a rank must never sit in a collective
-        its peers have left (the caller falls back to the all-gather exchange)."""
+        its peers have left (the caller falls back to the all-gather exchange).  `used` collects the peer handles touched."""
         from . import hip_ops as ops
         mine = None
         if ptr is not None:
@@ -177,6 +182,8 @@ class PeerStoreExchange:
                     if base is None:
                         base = ops.peer_open(handle)
                         self._opened[handle] = base
+                    if used is not None:
+                        used.add(handle)
                     out.append(base + offset)
             except Exception as exc:                        # noqa: BLE001
                 ok = False
@@ -215,17 +222,39 @@ class PeerStoreExchange:
                 dist.all_gather_object(geo, self.view_geometry(view), group=self.group)
                 if any(g != geo[0] for g in geo):
                     raise RuntimeError(f"peer-store exchange: ranks disagree on the cache geometry / page table of {ident}: {geo}")
-                got = (self._exchange_addresses(kp), self._exchange_addresses(vp))
+                used: set = set()
+                got = (self._exchange_addresses(kp, used), self._exchange_addresses(vp, used))
             if ident is not None:
                 for old in [k for k in self._views if k[:2] == ident[:2]]:      # earlier allocations of this (request, layer)
-                    del self._views[old]
+                    self._drop(old)
                 self._views[ident] = got
+                if not self.emulated:
+                    self._view_handles[ident] = used
+                    for h in used:
+                        self._handle_refs[h] = self._handle_refs.get(h, 0) + 1
         return got
 
-    def forget(self, request_id: str) -> None:
-        """Drop the mappings of a freed request (the manager's `free`); harmless if there are none."""
-        for k in [k for k in self._views if k[0] == request_id]:
-            del self._views[k]
+    def _drop(self, key: Tuple) -> None:
+        del self._views[key]
+        for h in self._view_handles.pop(key, ()):
+            self._handle_refs[h] = self._handle_refs.get(h, 1) - 1
+
+    def forget(self, request_id: str, layer_name: Optional[str] = None) -> None:
+        """Drop the address book of a freed (request, layer) — `KVCacheManager.free_layer` — or of a whole request (`free`,
+        `layer_name` None); harmless if there is none.  Only THAT layer's entry goes (dropping the request's whole book on a
+        single layer's release forced an all_gather_object + IPC re-exchange for every other layer in the middle of the next forward).
+        On a whole-request release the peer mappings no remembered view uses any more are closed (after a device synchronise: a
+        kernel in flight may still store through them); the caching allocator's segments they name can then be returned by the peers."""
+        for k in [k for k in self._views if k[0] == request_id and (layer_name is None or k[1] == layer_name)]:
+            self._drop(k)
+        if layer_name is None and not self.emulated:
+            dead = [h for h, n in self._handle_refs.items() if n <= 0 and h in self._opened]
+            if dead:
+                from . import hip_ops as ops
+                torch.cuda.synchronize()
+                for h in dead:
+                    ops.peer_close(self._opened.pop(h))
+                    del self._handle_refs[h]
 
     # ---- per layer ----
     def _index(self, layer: int, kind: int) -> int:
@@ -331,6 +360,8 @@ class PeerStoreExchange:
             ops.peer_close(base)
         self._opened.clear()
         self._views.clear()
+        self._view_handles.clear()
+        self._handle_refs.clear()
         if self.flags is not None:
             self.flags.free()
 
@@ -563,8 +594,11 @@ def attach_sequence_parallel(model, group=None, overlap: bool = True,
     sp = HipSequenceParallel(group, overlap, exchange, peer, kv_first)
     # a rank's launches have 4680 / P rows: the GEMM tile choice may split K inside a workgroup for them (row-count dependent bits,
     # which the default choice avoids; the row count of a rank is fixed by P).  The option is process-global in the library, so it is
-    # scoped to THIS model's forwards (HipCausalWanModel.forward: hip_ops.option_scope) and every other GEMM of the process — a
-    # second, unsharded model, the umT5 encoder, the VAE — keeps its row-count-invariant summation order.
+    # scoped to THIS model's forwards (HipCausalWanModel.forward: hip_ops.option_scope, which reads the library's own value back on
+    # entry: ifx_get_option) and every other GEMM enqueued by this thread OUTSIDE those forwards — a second, unsharded model, the umT5
+    # encoder, the VAE — keeps its row-count-invariant summation order.  What the scope cannot cover: GEMMs enqueued by
+    # ANOTHER host thread while this model is inside its forward see the option too (tile selection happens at enqueue time, per
+    # process); run such work from the thread that drives the model, as the pipelines do.
     sp.gemm_small_split = True
     pc = model.parallel_config
     if pc.world_size != sp.ex.world or pc.rank != sp.ex.rank:

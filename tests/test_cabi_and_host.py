@@ -381,6 +381,71 @@ def test_bench_roofline_gemm_arithmetic_on_synthetic_records():
     assert sh["traffic"] is None and sh["mfma_busy"] is None            # counters were taken on the unsharded launches
 
 
+def test_get_option_reads_the_library_and_option_scope_restores_what_it_found():
+    """`option_scope` took its 'previous' value from a Python mirror; an option set through the library directly (as several
+    tests do) was invisible to it.  `ifx_get_option` reads the library's own value; the scope restores THAT."""
+    import ctypes as C
+    import pytest
+    from inferix_amd import _hip
+    from inferix_amd import hip_ops as ops
+    lib = _hip.load()
+    assert lib.ifx_set_option(b"gemm_small_split", 1) == 0            # behind the mirror's back
+    try:
+        assert ops.get_option("gemm_small_split") == 1
+        with ops.option_scope("gemm_small_split", 0):
+            assert ops.get_option("gemm_small_split") == 0
+        assert ops.get_option("gemm_small_split") == 1, "the scope must restore the value it found in the library"
+    finally:
+        assert lib.ifx_set_option(b"gemm_small_split", 0) == 0
+    assert ops.get_option("gemm_small_split") == 0
+    for key, lo in (("gemm_variant", 0), ("attn_variant", 0), ("spin_fault", 0)):
+        assert ops.get_option(key) == lo
+    assert ops.get_option("spin_timeout_ms") >= 1
+    v = C.c_int32(7)
+    assert lib.ifx_get_option(b"no_such_option", C.byref(v)) != 0 and b"unknown key" in lib.ifx_last_error()
+    assert lib.ifx_set_option(b"spin_timeout_ms", 0) != 0             # out of range
+    assert lib.ifx_device_error(1) == 0                               # no kernel has run: the word is clear (and needs no GPU)
+    with pytest.raises(_hip.HipKernelError):
+        ops.get_option("no_such_option")
+    # the tile-12 shortcut of a sequence-parallel rank and the workspace query agree (ADVICE r4): 2340 x 1536 x 8960 takes the in-workgroup
+    # split tile under gemm_small_split and asks for no scratch
+    assert lib.ifx_gemm_workspace_bytes(2340, 1536, 8960) > 0
+    with ops.option_scope("gemm_small_split", 1):
+        assert lib.ifx_gemm_workspace_bytes(2340, 1536, 8960) == 0
+        assert lib.ifx_gemm_workspace_bytes(2340, 1536, 1536) == 0
+    assert lib.ifx_gemm_workspace_bytes(2340, 1536, 8960) > 0
+
+
+def test_free_layer_notifies_listeners_with_the_layer():
+    """`KVCacheManager.free_layer` told its listeners the request id only, and the peer-store exchange then dropped the
+    address book of EVERY layer of the request.  Two-argument listeners now get (request, layer); one-argument ones keep working."""
+    import torch
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.kvcache_manager.kvcache_manager import KVCacheRequestSpec, KVCacheSpec
+    mgr, req = KVCacheManager("cpu"), KVCacheRequest("r")
+    spec = KVCacheRequestSpec(num_tokens=8, block_size=1,
+                              specs={n: KVCacheSpec(num_kv_heads=1, head_size=4, dtype=torch.float32, kv_offload=False, use_mla=False)
+                                     for n in ("layer_0", "layer_1")})
+    mgr.allocate_slots(req, spec)
+    one, two = [], []
+    mgr.add_free_listener(one.append)
+    mgr.add_free_listener(lambda r, layer=None: two.append((r, layer)))
+    mgr.free_layer(req, "layer_1")
+    mgr.free(req)
+    assert one == ["r", "r"] and two == [("r", "layer_1"), ("r", None)]
+
+    class Book:                          # the bookkeeping half of PeerStoreExchange.forget, without a device
+        def __init__(self):
+            self._views = {("r", "layer_0", (1, 1)): 0, ("r", "layer_1", (1, 1)): 1, ("q", "layer_0", (1, 1)): 2}
+            self._view_handles, self._handle_refs, self._opened, self.emulated = {}, {}, {}, True
+    from inferix_amd.sequence_parallel import PeerStoreExchange
+    bk = Book()
+    PeerStoreExchange.forget(bk, "r", "layer_1")
+    assert sorted(bk._views) == [("q", "layer_0", (1, 1)), ("r", "layer_0", (1, 1))]
+    PeerStoreExchange.forget(bk, "r")
+    assert sorted(bk._views) == [("q", "layer_0", (1, 1))]
+
+
 def test_option_scope_restores_and_nests():
     """`hip_ops.option_scope` (how a sequence-parallel model's forward turns `gemm_small_split` on for its own launches only, ADVICE
     r3): sets on entry, restores the previous value on exit — also when nested and when the body raises — and leaves an equal value alone."""

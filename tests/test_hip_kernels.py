@@ -261,7 +261,11 @@ def test_attention_480p_block_shapes(ops):
         ref_bf = O.attention(q[sel][None], k[None], v[None])[0]
         e_gpu = (out[sel.cuda()].cpu().double() - ref64).abs().max().item()
         e_ref = (ref_bf.double() - ref64).abs().max().item()
-        assert e_gpu <= 2 * e_ref + 2e-3, (kv_len, e_gpu, e_ref)
+        r_gpu, r_ref = rel_l2(out[sel.cuda()].cpu().double(), ref64), rel_l2(ref_bf, ref64)
+        # same rule as the long-prefix tests below: 1.25 x the reference's own distance from exact attention (+ 5e-4 on the rel-L2,
+        # + one bf16 step of the largest output on the max)
+        assert r_gpu <= 1.25 * r_ref + 5e-4, (kv_len, r_gpu, r_ref)
+        assert e_gpu <= 1.25 * e_ref + float(ref64.abs().max()) * 2.0 ** -8, (kv_len, e_gpu, e_ref)
 
 
 @pytest.mark.parametrize("kv_len", [14040, 23400, 32760])
@@ -271,7 +275,8 @@ def test_attention_480p_long_prefixes_vs_fp64_oracle(ops, kv_len, paged, prescal
     """The prefix lengths of blocks 2 / 4 / 6 of the BASELINE clip (where 70 % of the attention time is): 4680 queries x 12 heads
     over 14040 / 23400 / 32760 cached keys, default schedule, contiguous and through a page table (pages of one frame, shuffled).
     192 query rows (the first, a middle and the last ragged tile) against the CPU fp64 oracle, with the reference's own bf16 SDPA
-    measured on the same rows as the yardstick: the kernel may be at most twice as far from exact attention as the reference is.
+    measured on the same rows as the yardstick: rel-L2 within 1.25 x the reference's own distance from exact attention + 5e-4 (the block /
+    rollout rule), max error within 1.25 x the reference's + one bf16 step of the largest output.
     `prescaled`: the form the model uses — q multiplied by scale * log2(e) before its rounding to bf16, the call with scale = ln 2 (the
     exponent fast path); the fp64 reference is evaluated on that q."""
     g = torch.Generator().manual_seed(kv_len + int(paged))
@@ -299,8 +304,11 @@ def test_attention_480p_long_prefixes_vs_fp64_oracle(ops, kv_len, paged, prescal
     e_gpu, e_ref = (got - ref64[0]).abs().max().item(), (ref_bf.double() - ref64[0]).abs().max().item()
     r_gpu, r_ref = rel_l2(got, ref64[0]), rel_l2(ref_bf, ref64[0])
     print(f"L={kv_len} paged={paged} prescaled={prescaled}: max|err| hip {e_gpu:.3e} / reference bf16 SDPA {e_ref:.3e}; rel-L2 hip {r_gpu:.3e} / reference {r_ref:.3e}")
-    assert e_gpu <= 2 * e_ref + 1e-3, (kv_len, e_gpu, e_ref)
-    assert r_gpu <= 2 * r_ref + 1e-3, (kv_len, r_gpu, r_ref)
+    # the block / rollout rule (1.25 x the reference's own distance from exact attention + 5e-4) on the rel-L2; the max over 295 k
+    # elements moves by one bf16 step of the largest outputs between two correct kernels (measured 3.0e-4 vs 2.3e-4 on one launch)
+    ulp_top = float(ref64[0].abs().max()) * 2.0 ** -8
+    assert r_gpu <= 1.25 * r_ref + 5e-4, (kv_len, r_gpu, r_ref)
+    assert e_gpu <= 1.25 * e_ref + ulp_top, (kv_len, e_gpu, e_ref, ulp_top)
     assert (lse[:, sel.cuda()].cpu().double() - lse64[0]).abs().max().item() < 2e-3
 
 
@@ -313,7 +321,7 @@ def test_attention_720p_block_at_size_vs_fp64_oracle(ops, kv_len, paged, prescal
     21-latent segment — the launches whose tile height the rounds-aware choice decides (256-row x 3 rounds against 128-row x 2,
     DESIGN §5).  Default (auto) schedule, contiguous and through a page table with pages of one frame (3600 tokens, shuffled).
     192 query rows (first, middle and last tile) against the CPU fp64 oracle with the reference's bf16 SDPA on the same rows as the
-    yardstick: at most twice as far from exact attention as the reference is; LSE to 2e-3.  `prescaled` = the model's exponent form."""
+    yardstick: the 1.25 x floor + 5e-4 rule of the 480p test above; LSE to 2e-3.  `prescaled` = the model's exponent form."""
     g = torch.Generator().manual_seed(kv_len + int(paged))
     rows, heads, hd, fsz = 10800, 12, 128, 3600
     q, k, v = rnd(g, rows, heads, hd), rnd(g, kv_len, heads, hd), rnd(g, kv_len, heads, hd)
@@ -340,8 +348,11 @@ def test_attention_720p_block_at_size_vs_fp64_oracle(ops, kv_len, paged, prescal
     e_gpu, e_ref = (got - ref64[0]).abs().max().item(), (ref_bf.double() - ref64[0]).abs().max().item()
     r_gpu, r_ref = rel_l2(got, ref64[0]), rel_l2(ref_bf, ref64[0])
     print(f"720p L={kv_len} paged={paged} prescaled={prescaled}: max|err| hip {e_gpu:.3e} / reference bf16 SDPA {e_ref:.3e}; rel-L2 hip {r_gpu:.3e} / reference {r_ref:.3e}")
-    assert e_gpu <= 2 * e_ref + 1e-3, (kv_len, e_gpu, e_ref)
-    assert r_gpu <= 2 * r_ref + 1e-3, (kv_len, r_gpu, r_ref)
+    # the block / rollout rule (1.25 x the reference's own distance from exact attention + 5e-4) on the rel-L2; the max over 295 k
+    # elements moves by one bf16 step of the largest outputs between two correct kernels (measured 3.0e-4 vs 2.3e-4 on one launch)
+    ulp_top = float(ref64[0].abs().max()) * 2.0 ** -8
+    assert r_gpu <= 1.25 * r_ref + 5e-4, (kv_len, r_gpu, r_ref)
+    assert e_gpu <= 1.25 * e_ref + ulp_top, (kv_len, e_gpu, e_ref, ulp_top)
     assert (lse[:, sel.cuda()].cpu().double() - lse64[0]).abs().max().item() < 2e-3
     if prescaled or paged:
         return
@@ -580,6 +591,80 @@ def test_gemm_ping_pong_split_k_is_deterministic_and_row_invariant(ops):
     ws = next(iter(ops._GEMM_WS.values()))
     torch.cuda.synchronize()
     assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-tile flags must be left zero"
+
+
+@pytest.mark.parametrize("M", [7020, 10800])
+def test_gemm_ffn_down_720p_rows_vs_fp64(ops, M):
+    """Round-4 verdict: the 192-token split tile (FFN down at 7020 / 10800 rows) was checked through a chain of bit-equalities only.
+    Direct check: y = bf16(res + bf16(bf16(x W^T + b) * gate)) with the accumulation in fp64 on the device (every row, every channel),
+    for the gate + residual epilogue the block uses and for the plain bias epilogue.  fp32 MFMA accumulation over K = 8960 against the
+    fp64 sum: the bf16 result may flip one rounding in a few elements per thousand — 2 ULP, <= 2 % of the elements."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(80 + M)
+    N, K, fs = 1536, 8960, M // 3
+    x, w, b = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))
+    res, mod = gpu(rnd(g, M, N)), gpu(rnd(g, 3, 6, N, scale=0.5))
+    acc = torch.empty(M, N, dtype=torch.float64, device="cuda")
+    wd = w.double().t().contiguous()
+    for r0 in range(0, M, 1080):                       # row slabs keep the fp64 operands small
+        acc[r0:r0 + 1080] = x[r0:r0 + 1080].double() @ wd
+    y = (acc + b.double()).to(BF)                      # one rounding of the exact sum (double -> bf16 rounds to nearest even directly)
+    assert lib_ws(ops, M, N, K) > 0, "auto must ask for the split-K workspace on this shape"
+    got = ops.linear(x, w, b)
+    assert_bf16_parity(got, y, max_ulp=1, max_mismatch_frac=0.02, floor=0.05, what=f"FFN down {M} rows, bias")
+    gate = torch.repeat_interleave(mod[:, 5], fs, dim=0)[:M]
+    want = (res.float() + (y.float() * gate.float()).to(BF).float()).to(BF)
+    got = ops.linear(x, w, b, epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=5, rows_per_group=fs)
+    assert_bf16_parity(got, want, max_ulp=2, max_mismatch_frac=0.02, floor=1.0, what=f"FFN down {M} rows, gate + residual")
+    again = ops.linear(x, w, b, epilogue=_hip.IFX_EPI_GATE_RES, residual=res, mod=mod, gate_slot=5, rows_per_group=fs)
+    assert torch.equal(got, again)
+
+
+def lib_ws(ops, M, N, K):
+    from inferix_amd import _hip
+    ops.set_option("gemm_small_split", 0)
+    return int(_hip.load().ifx_gemm_workspace_bytes(M, N, K))
+
+
+def test_split_k_consumer_wait_is_bounded_and_reported(ops):
+    """Round-4 verdict item 7 / ADVICE r3: the split-K consumer of the ping-pong GEMM waits for its partner's flag with a BUDGET.  With the
+    lab switch `spin_fault` the producers keep their flags down: the launch must still END (within the budget, not hang the GPU), raise
+    the device error word (kind 1), `ifx_last_error` / `check_device` must say so and clear it, the flag page must be left zero, and
+    the next ordinary launch of the same shape must be bit-identical to the one before the fault."""
+    import time
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(91)
+    ops.set_option("gemm_small_split", 0)
+    M, N, K = 4680, 1536, 8960
+    x, w, b = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1))
+    assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) > 0
+    good = ops.linear(x, w, b)
+    torch.cuda.synchronize()
+    assert ops.device_error() == 0
+    assert ops.get_option("spin_timeout_ms") == 2000 and ops.get_option("spin_fault") == 0
+    ops.set_option("spin_timeout_ms", 25)
+    ops.set_option("spin_fault", 1)
+    try:
+        t0 = time.perf_counter()
+        bad = ops.linear(x, w, b)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 5.0, f"the faulted launch took {dt:.2f} s: the wait is not bounded"
+        assert dt > 0.02, "the consumers did not wait for their budget"
+        code = ops.device_error(clear=False)
+        assert code >> 24 == 1, hex(code)
+        with pytest.raises(_hip.HipKernelError, match="gave up a wait"):
+            ops.check_device("faulted GEMM")
+        assert ops.device_error() == 0, "reporting must clear the word"
+        assert bad.shape == good.shape
+    finally:
+        ops.set_option("spin_fault", 0)
+        ops.set_option("spin_timeout_ms", 2000)
+    ws = ops._gemm_workspace(x.device, 4096)
+    assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-tile flags must be left zero by the faulted launch"
+    again = ops.linear(x, w, b)
+    torch.cuda.synchronize()
+    assert torch.equal(again, good) and ops.device_error() == 0
 
 
 def test_gemm_stream_k_variant_is_correct_and_deterministic(ops):
