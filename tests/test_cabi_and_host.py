@@ -438,6 +438,9 @@ def test_free_layer_notifies_listeners_with_the_layer():
         def __init__(self):
             self._views = {("r", "layer_0", (1, 1)): 0, ("r", "layer_1", (1, 1)): 1, ("q", "layer_0", (1, 1)): 2}
             self._view_handles, self._handle_refs, self._opened, self.emulated = {}, {}, {}, True
+
+        def _drop(self, key):
+            PeerStoreExchange._drop(self, key)
     from inferix_amd.sequence_parallel import PeerStoreExchange
     bk = Book()
     PeerStoreExchange.forget(bk, "r", "layer_1")
