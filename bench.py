@@ -79,17 +79,29 @@ def cpu_baseline(layers: int = 30):
     pe = torch.zeros(1, cfg.text_len, cfg.text_dim)
     pe[:, :40] = torch.randn(1, 40, cfg.text_dim, generator=torch.Generator().manual_seed(1))
     pe = pe.to(torch.bfloat16)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out, _ = O.inference(W, cfg, noise, list(pe), [1000], shift=5.0, num_frame_per_block=BLOCK)
-    dt = time.perf_counter() - t0
-    assert torch.isfinite(out.float()).all()
+    # (round-4 verdict: 0.041-0.053 frames/s between boxes and runs.)  One untimed single-layer pass pages in the math libraries and
+    # the thread pool; then up to two timed runs — the second only while the leg stays inside ~100 s — and the MINIMUM is reported,
+    # both wall times beside it.
+    if layers > 1:
+        cfg1 = O.WanConfig(num_layers=1)
+        with torch.no_grad():
+            O.inference(O.init_weights(cfg1, seed=0), cfg1, noise, list(pe), [1000], shift=5.0, num_frame_per_block=BLOCK)
+    runs = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out, _ = O.inference(W, cfg, noise, list(pe), [1000], shift=5.0, num_frame_per_block=BLOCK)
+        runs.append(time.perf_counter() - t0)
+        assert torch.isfinite(out.float()).all()
+        if runs[0] > 50.0:
+            break
+    dt = min(runs)
     extra = {} if layers == 30 else {"INVALID": f"debug run with {layers} of 30 layers"}
     return {**extra, "value": BLOCK / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "BASELINE config 1, measured: Self-Forcing 480p, block_size 3, 1 denoise step + clean-context re-run = 2 "
                       "generator forwards of the 30-layer Wan2.1-1.3B causal DiT over one 3-frame block (N = L_kv = 4680), "
                       f"NO_DECODE, bf16 CPU oracle (O.inference); {dt:.1f} s wall",
-            "seconds": round(dt, 2), "ms_per_generator_forward": round(dt / 2 * 1e3, 1), "host_cpus": os.cpu_count()}
+            "seconds": round(dt, 2), "runs_s": [round(r, 2) for r in runs], "ms_per_generator_forward": round(dt / 2 * 1e3, 1), "host_cpus": os.cpu_count()}
 
 
 class ClockSampler:
@@ -645,6 +657,13 @@ def main():
         if a.sp_exchange == "peer" and model.cp.peer is None and peer is not None:
             raise SystemExit(f"--sp-exchange peer: the preflight comparison failed: {sp_preflight}")
         exchange_used = "peer_store" if model.cp.peer is not None else "allgather"
+        if rank == 0:
+            # FIRST thing a multi-GPU run says (stderr: stdout carries the one JSON line): what the first contact with RCCL / xGMI
+            # measured per exchange and which exchange the timed clips will use — a slow or fallen-back 8-GPU run is diagnosable from
+            # this line alone (round-4 verdict item 9)
+            print("[bench] " + json.dumps({"n_gpus": world, "rccl_ranks": rccl_ranks, "sp_exchange": exchange_used,
+                                           "sp_qkv": "kv-first" if model.cp.kv_first else "fused", "sp_preflight": sp_preflight}),
+                  file=sys.stderr, flush=True)
     elif a.emulate_sp > 1:
         from inferix_amd.sequence_parallel import LoopbackExchange, PeerStoreExchange, attach_sequence_parallel
         peer = PeerStoreExchange(emulate_world=a.emulate_sp) if a.sp_exchange == "peer" else None

@@ -323,5 +323,13 @@ def test_quantized_block_real_dims_vs_quantised_model_oracle(which):
     # K / V rows are single quantised projections of the block input (+ norm, RoPE).  A one-ULP flip of the LayerNorm output in
     # front of the quantiser moves an 8-bit code by a whole step (row max / 127 for int8, i.e. several bf16 ULPs of a small element), so
     # the per-element bound is taken at the tensor's scale; the tensors as a whole agree to 1e-3 (measured 1.7e-4)
-    assert_bf16_parity(raw[0, :2 * n, 0], fx[f"block_cache_k_{which}"], max_ulp=4, max_mismatch_frac=0.02, floor=1.0, what="cache K")
-    assert_bf16_parity(raw[1, :2 * n, 0], fx[f"block_cache_v_{which}"], max_ulp=4, max_mismatch_frac=0.02, floor=1.0, what="cache V")
+    # (round-4 verdict: the measured mismatch fraction and rel-L2 are printed and part of the failure message, so that a drift INSIDE the
+    #  2 % / 4-ULP hole is visible from the log: fp8 / int8 sit at a few 1e-3 of the elements and ~1.7e-4 rel-L2)
+    for name, got_rows, key in (("K", raw[0, :2 * n, 0], f"block_cache_k_{which}"), ("V", raw[1, :2 * n, 0], f"block_cache_v_{which}")):
+        want = fx[key]
+        frac_now = float((got_rows.cpu().double() != want.double()).double().mean())
+        rel_now = rel_l2(got_rows.cpu(), want)
+        print(f"{which} cache {name} rows vs q8 oracle: {frac_now:.5f} of the elements differ, rel-L2 {rel_now:.3e}")
+        assert rel_now <= 5e-4, f"cache {name}: rel-L2 {rel_now:.3e} (measured 1.7e-4 when written), mismatch fraction {frac_now:.5f}"
+        assert_bf16_parity(got_rows, want, max_ulp=4, max_mismatch_frac=0.02, floor=1.0,
+                           what=f"cache {name} (mismatch fraction {frac_now:.5f}, rel-L2 {rel_now:.3e})")
