@@ -582,6 +582,9 @@ def main():
     ap.add_argument("--sp-qkv", choices=["auto", "fused", "kv-first"], default="auto",
                     help="N > 1: one fused q/k/v projection before the exchange starts, or the K/V projection first so that the exchange "
                          "runs under the q projection; auto = kv-first in front of the all-gather, fused in front of the peer stores")
+    ap.add_argument("--pair", choices=["auto", "on", "off"], default="auto",
+                    help="the clean-context re-run of a block enqueued layer-interleaved with the next block's first step "
+                         "(pipeline pair_forwards; bit-identical results): auto = on for sequence-parallel ranks, off on one GPU")
     ap.add_argument("--magi-leg", choices=["fp8", "bf16"], default=None,
                     help="debug: run ONLY the config 5 leg (MAGI-4.5B model through the chunk schedule, one emulated cp rank) and print it")
     ap.add_argument("--magi-steps", type=int, default=0, help="debug: with --magi-leg, only the first N steps of each schedule stage")
@@ -623,6 +626,7 @@ def main():
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     model, gen, pipe = build_pipeline(device, pc, a.layers or None)
+    pipe.args.pair_forwards = {"auto": None, "on": True, "off": False}[a.pair]
     exchange_used, rccl_ranks, sp_preflight = None, None, None
     if world > 1:
         from inferix_amd.sequence_parallel import PeerStoreExchange
@@ -734,6 +738,8 @@ def main():
         evs.append((kw["current_start"] // (BLOCK * 1560), s, e))
         return r
     gen.forward = timed_forward
+    pair_was = getattr(pipe.args, "pair_forwards", None)
+    pipe.args.pair_forwards = False      # the instrumented clips time ONE forward per interval: no layer-interleaved pairs in them
     breakdown = None
     if a.kernel_breakdown:
         allt = ops.KernelTimer(names=("attn_self", "attn_cross", "gemm", "gemm_q8", "quant_per_token", "layernorm",
@@ -763,6 +769,7 @@ def main():
             ops.set_kernel_timer(None)
         gemm_roof = roofline_gemm(gt.records, 4680 // (world if world > 1 else max(a.emulate_sp, 1)),
                                   (FRAMES // BLOCK) * (len(STEPS_LIST) + 1), model.num_layers, world if world > 1 else max(a.emulate_sp, 1))
+    pipe.args.pair_forwards = pair_was
     ks = timer.summary().get("attn_self", dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
     attn_tflops = ks["flops"] / (ks["ms"] * 1e-3) / 1e12 if ks["ms"] else 0.0
     nblk = FRAMES // BLOCK
@@ -791,7 +798,8 @@ def main():
                                    "is measured beside it (`per_block_decode`, `vae_decode`), the text encoder in `text_encoder`",
                        "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
                        "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
-                       "layers": model.num_layers},
+                       "layers": model.num_layers,
+                       "pair_forwards": bool(pipe._pairing())},
             "rccl_ranks": rccl_ranks, "sp_exchange": exchange_used, "sp_preflight": sp_preflight,
             "ms_per_denoise_step": round(sum(denoise_ms) / len(denoise_ms), 3),
             "ms_per_forward_by_block": per_block_ms,

@@ -57,11 +57,29 @@ class CausalInferencePipeline(torch.nn.Module):
             model.num_frame_per_block = self.num_frame_per_block
 
     # ------------------------------------------------------------------
+    def _gen_kw(self, x, cond, timestep, start_frame, kvm, reqs) -> dict:
+        return dict(noisy_image_or_video=x, conditional_dict=cond, timestep=timestep,
+                    kv_cache_meta=self.kv_cache_meta, crossattn_cache_meta=self.crossattn_cache_meta,
+                    current_start=start_frame * self.frame_seq_length, kv_cache_manager=kvm, kv_cache_requests=reqs)
+
     def _gen(self, x, cond, timestep, start_frame, kvm, reqs):
-        return self.generator(noisy_image_or_video=x, conditional_dict=cond, timestep=timestep,
-                              kv_cache_meta=self.kv_cache_meta, crossattn_cache_meta=self.crossattn_cache_meta,
-                              current_start=start_frame * self.frame_seq_length, kv_cache_manager=kvm,
-                              kv_cache_requests=reqs)
+        return self.generator(**self._gen_kw(x, cond, timestep, start_frame, kvm, reqs))
+
+    def _pairing(self) -> bool:
+        """Whether the clean-context re-run of block b is enqueued TOGETHER with the first denoising step of block b + 1, layer by
+        layer on two streams (`generator.forward_pair`): the two calls depend on each other only through layer l's cache rows, and a
+        sequence-parallel rank's launches leave most of the chip idle, so the second chain is nearly free there.  The
+        results are bit-identical to the sequential calls.  `args.pair_forwards` / env IFX_PAIR_FORWARDS: 1 on, 0 off, unset = on
+        for sequence-parallel models only."""
+        import os
+        if not hasattr(self.generator, "forward_pair"):
+            return False
+        want = getattr(self.args, "pair_forwards", None)
+        if want is None and os.environ.get("IFX_PAIR_FORWARDS", "") != "":
+            want = os.environ["IFX_PAIR_FORWARDS"] not in ("0", "false", "off")
+        if want is None:
+            want = getattr(getattr(self.generator, "model", None), "cp", None) is not None
+        return bool(want)
 
     def inference(self, noise: torch.Tensor, text_prompts: List[str], kv_cache_manager: KVCacheManager,
                   kv_cache_requests: List[KVCacheRequest], initial_latent: Optional[torch.Tensor] = None,
@@ -123,6 +141,8 @@ class CausalInferencePipeline(torch.nn.Module):
         want_steps = self._profiler is not None and hasattr(self._profiler, "record_diffusion_step")
         want_blocks = profile and self._profiler is not None and hasattr(self._profiler, "record_block_computation")
         self.block_times_ms: List[float] = []
+        pair = self._pairing() and not want_steps and not profile      # the per-step / per-block timers want one call per interval
+        pending = None                   # keyword arguments of the previous block's clean-context re-run, deferred into the next step
         for block_index, nf in enumerate(frames):
             if profile:
                 b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -135,7 +155,13 @@ class CausalInferencePipeline(torch.nn.Module):
                     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s0.record()
                 timestep = torch.ones([B, nf], device=dev, dtype=torch.int64) * tcur
-                _, x0 = self._gen(x, cond, timestep, cur, kv_cache_manager, kv_cache_requests)
+                if pending is not None:
+                    # the previous block's clean-context re-run and this first step, layer-interleaved (same results as back to back)
+                    _, (_, x0) = self.generator.forward_pair(pending, self._gen_kw(x, cond, timestep, cur, kv_cache_manager,
+                                                                                     kv_cache_requests))
+                    pending = None
+                else:
+                    _, x0 = self._gen(x, cond, timestep, cur, kv_cache_manager, kv_cache_requests)
                 if index < nsteps - 1:
                     flat = x0.flatten(0, 1)
                     eps = renoise.pop(0).to(flat.device, flat.dtype) if renoise is not None else torch.randn_like(flat)
@@ -153,7 +179,10 @@ class CausalInferencePipeline(torch.nn.Module):
             if x0 is not None:
                 output[:, cur:cur + nf] = x0
                 ctx_t = torch.ones_like(timestep) * getattr(self.args, "context_noise", 0)
-                self._gen(x0, cond, ctx_t, cur, kv_cache_manager, kv_cache_requests)
+                if pair and block_index + 1 < len(frames):
+                    pending = self._gen_kw(x0, cond, ctx_t, cur, kv_cache_manager, kv_cache_requests)
+                else:
+                    self._gen(x0, cond, ctx_t, cur, kv_cache_manager, kv_cache_requests)
             if profile:
                 b1.record()
                 torch.cuda.synchronize()

@@ -382,7 +382,8 @@ class HipSequenceParallel:
         # front of the peer stores (two flag round trips + 3.6 MB per link), which the prefix attention covers from the second block on.
         self.kv_first = (peer is None) if kv_first is None else kv_first
         self.overlap = overlap
-        self.comm_stream: Optional[torch.cuda.Stream] = None
+        self.comm_stream: Optional[torch.cuda.Stream] = None      # chain 0's side stream (kept under this name for the tests / tools)
+        self._comm_streams: Dict[int, torch.cuda.Stream] = {}     # chain -> side stream (HipCausalWanModel.forward_pair runs two chains)
         self._buf: Dict[Tuple, torch.Tensor] = {}
         if peer is not None and (peer.world != self.ex.world or peer.rank != self.ex.rank):
             raise ValueError("peer-store exchange and collective exchange disagree on (rank, world)")
@@ -422,12 +423,17 @@ class HipSequenceParallel:
                 warnings.warn(f"peer-store exchange disabled, using the all-gather: {exc}")
                 self.peer = None
         side = self.overlap and dev.type == "cuda"
-        st = dict(step=step, view=view, n_local=n_local, side=side, have_prefix=have_prefix, layer=l, epoch=0)
+        chain = int(getattr(model, "_chain", 0))
+        st = dict(step=step, view=view, n_local=n_local, side=side, have_prefix=have_prefix, layer=l, epoch=0, comm=None)
         main = torch.cuda.current_stream(dev) if side else None
         if side:
-            if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=dev)
-            self.comm_stream.wait_stream(main)
+            comm = self._comm_streams.get(chain)
+            if comm is None:
+                comm = self._comm_streams[chain] = torch.cuda.Stream(device=dev)
+                if chain == 0:
+                    self.comm_stream = comm
+            comm.wait_stream(main)
+            st["comm"] = comm
 
         def exchange():
             if self.peer is not None:
@@ -435,8 +441,8 @@ class HipSequenceParallel:
                 return
             # this rank's K / V -> staging (a dense 1-shard cache), one collective [2, n_local, H, D] -> [P, 2, n_local, H, D], one
             # kernel scatters K and V rows to their cache slots (through the page table when there is one)
-            stage = self._scratch("kv_stage", (2, n_local, H, hd), torch.bfloat16, dev)
-            gathered = self._scratch("kv_gather", (P, 2, n_local, H, hd), torch.bfloat16, dev)
+            stage = self._scratch(("kv_stage", chain), (2, n_local, H, hd), torch.bfloat16, dev)
+            gathered = self._scratch(("kv_gather", chain), (P, 2, n_local, H, hd), torch.bfloat16, dev)
             sview = ops.KvCacheView(stage[0], stage[1])
             ops.rmsnorm_rope_kv_push(kv_rows, w["nk"], model.eps, rope, [stage[0].data_ptr()], [stage[1].data_ptr()], sview, 0,
                                      rope.hw_local, rope.hw_local, 0, d)
@@ -444,7 +450,7 @@ class HipSequenceParallel:
             ops.kv_scatter_shards(gathered, P, frames, rope.hw_local, fs, step.local_start, view)
 
         if side:
-            with torch.cuda.stream(self.comm_stream):
+            with torch.cuda.stream(st["comm"]):
                 exchange()
         else:
             exchange()
@@ -463,7 +469,7 @@ class HipSequenceParallel:
 
         def arrived():
             if st["side"]:
-                torch.cuda.current_stream(dev).wait_stream(self.comm_stream)
+                torch.cuda.current_stream(dev).wait_stream(st["comm"])
             if self.peer is not None:
                 self.peer.wait_done(st["layer"], st["epoch"])
 

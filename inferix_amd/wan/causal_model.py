@@ -150,6 +150,8 @@ class HipCausalWanModel(torch.nn.Module):
         self.cross_dedup = True
         self._cross_dedup: Dict[str, Tuple[int, int]] = {}
         self._roll_scratch: Optional[torch.Tensor] = None
+        self._chain = 0                               # 0 except while forward_pair enqueues its second forward
+        self._pair_stream: Optional[torch.cuda.Stream] = None
         self.cp = None                                # set by inferix_amd.sequence_parallel when world_size > 1
         self.q_prescale = self.head_dim == 128        # exponent fast path of the self-attention kernel (hip_ops.attn_q_prescale)
 
@@ -215,7 +217,7 @@ class HipCausalWanModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name: str, *shape) -> torch.Tensor:
-        key = (name, shape)
+        key = (self._chain, name, shape)              # `_chain`: which of two layer-interleaved forwards is being enqueued (forward_pair)
         b = self._scratch.get(key)
         if b is None:
             b = torch.empty(*shape, dtype=BF16, device=self.device_)
@@ -268,17 +270,21 @@ class HipCausalWanModel(torch.nn.Module):
                              step.rolled // pt.page_size)
             return
         need = step.rolled * self.dim
+        if self._chain:                               # the second of two interleaved forwards shifts on its own stream: its own scratch
+            ops.kv_roll(view, step.sink_tokens, step.evicted, step.rolled, self._buf("roll", need))
+            return
         if self._roll_scratch is None or self._roll_scratch.numel() < need:
             self._roll_scratch = torch.empty(need, dtype=BF16, device=self.device_)
         ops.kv_roll(view, step.sink_tokens, step.evicted, step.rolled, self._roll_scratch)
 
     def _q8_scratch(self, rows: int, cols: int, device):
-        xq = self._scratch.get(("xq", rows, cols))
+        c = self._chain
+        xq = self._scratch.get((c, "xq", rows, cols))
         if xq is None:
             xq = torch.empty(rows, cols, dtype=torch.uint8, device=device)
-            self._scratch[("xq", rows, cols)] = xq
-            self._scratch[("xs", rows)] = torch.empty(rows, dtype=torch.float32, device=device)
-        return xq, self._scratch[("xs", rows)]
+            self._scratch[(c, "xq", rows, cols)] = xq
+            self._scratch[(c, "xs", rows)] = torch.empty(rows, dtype=torch.float32, device=device)
+        return xq, self._scratch[(c, "xs", rows)]
 
     def _lin(self, w: Dict[str, torch.Tensor], key: str, x: torch.Tensor, **kw) -> torch.Tensor:
         """Linear `key` of a block: bf16 MFMA GEMM, or (after inferix_amd.quant.quantize_dynamic) per-token
@@ -413,6 +419,72 @@ class HipCausalWanModel(torch.nn.Module):
                 current_end: Optional[int] = None) -> torch.Tensor:
         """x: [B, C, F, H, W] tensor (or list of [C, F, H, W]); t: [B, F]; context: [B, L, text_dim] tensor or
         list of [L_i, text_dim].  Returns the flow prediction [B, C_out, F, H, W] (bf16)."""
+        fw = self._prologue(x, t, context, kv_cache_meta, crossattn_cache_meta, current_start, kv_cache_manager, kv_cache_requests,
+                            kv_start, kv_end)
+        with self._small_split_scope():               # shard-sized launches of a sequence-parallel rank only (attach_sequence_parallel)
+            for l in range(self.num_layers):
+                self._run_block(l, fw["xact"], fw["E"][l], fw["st"], fw["kv_meta"][l], fw["cross_meta"][l], kv_cache_manager,
+                                kv_cache_requests)
+        return self._epilogue(fw)
+
+    def _small_split_scope(self):
+        import contextlib
+        return ops.option_scope("gemm_small_split", 1) if getattr(self.cp, "gemm_small_split", False) else contextlib.nullcontext()
+
+    @torch.no_grad()
+    def forward_pair(self, first: dict, second: dict):
+        """TWO forwards enqueued layer by layer on two streams — `first` on the current stream, `second` on a side stream whose layer l
+        starts when `first`'s layer l has been enqueued and finished (an event per layer) — for the one pair of generator calls of the
+        block loop that depend on each other ONLY through the cache: the clean-context re-run of block b (it writes block b's K / V
+        rows, layer by layer) and the first denoising step of block b + 1 (whose layer l attends to those rows of layer l and writes
+        the rows of block b + 1).  Same launches, same arguments, same order per cache as the two calls one after the other: the
+        results are bit-identical to them (tests/test_hip_model.py); what changes is that the second chain's launches fill the CUs and
+        the dependent-launch gaps the first one leaves — a sequence-parallel rank's launches (585 rows at P = 8) occupy a fraction of
+        the chip each.  `first` / `second`: the keyword arguments of `forward`.  Returns both flow predictions."""
+        dev = self.device_
+        main = torch.cuda.current_stream(dev)
+        if self._pair_stream is None:
+            self._pair_stream = torch.cuda.Stream(device=dev)
+        side = self._pair_stream
+        side.wait_stream(main)                        # the second forward's inputs were produced on the caller's stream
+        kvm, reqs = first["kv_cache_manager"], first["kv_cache_requests"]
+        assert second["kv_cache_manager"] is kvm, "forward_pair: both forwards must address the same cache"
+
+        def pro(kw):
+            return self._prologue(kw["x"], kw["t"], kw["context"], kw.get("kv_cache_meta"), kw.get("crossattn_cache_meta"),
+                                  kw.get("current_start", 0), kw["kv_cache_manager"], kw["kv_cache_requests"], kw.get("kv_start"),
+                                  kw.get("kv_end"))
+        try:
+            fa = pro(first)
+            self._chain = 1
+            with torch.cuda.stream(side):
+                fb = pro(second)
+            with self._small_split_scope():
+                for l in range(self.num_layers):
+                    self._chain = 0
+                    self._run_block(l, fa["xact"], fa["E"][l], fa["st"], fa["kv_meta"][l], fa["cross_meta"][l], kvm, reqs)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    self._chain = 1
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)           # layer l of the cache holds `first`'s rows before `second`'s layer l reads / evicts
+                        self._run_block(l, fb["xact"], fb["E"][l], fb["st"], fb["kv_meta"][l], fb["cross_meta"][l], kvm,
+                                        second["kv_cache_requests"])
+            self._chain = 0
+            ya = self._epilogue(fa)
+            self._chain = 1
+            with torch.cuda.stream(side):
+                yb = self._epilogue(fb)
+        finally:
+            self._chain = 0
+        main.wait_stream(side)
+        yb.record_stream(main)                        # allocated on the side stream, consumed (and later freed) on the caller's
+        return ya, yb
+
+    def _prologue(self, x, t, context, kv_cache_meta, crossattn_cache_meta, current_start, kv_cache_manager, kv_cache_requests,
+                  kv_start=None, kv_end=None) -> dict:
+        """Everything of a forward in front of the layers: embeddings, modulation tables, the text context (first call), the per-forward
+        state the layers share.  Enqueues on the current stream, takes its scratch from chain `self._chain`."""
         explicit = None
         if kv_start is not None and kv_end is not None:
             # CausVid addressing (models/causvid/causal_model.py:128-179,258-277): the caller names the cache
@@ -492,16 +564,13 @@ class HipCausalWanModel(torch.nn.Module):
 
         st = dict(B=B, N=N, F_=F_, fs=fs, rows_per_group=rows_per_group, rope=rope, sink_tokens=sink_tokens,
                   current_start=current_start, ctx=ctx, explicit_slots=explicit, attn_scale=attn_scale)
-        import contextlib
-        small = ops.option_scope("gemm_small_split", 1) if getattr(self.cp, "gemm_small_split", False) else contextlib.nullcontext()
-        with small:                                   # shard-sized launches of a sequence-parallel rank only (attach_sequence_parallel)
-            for l in range(L):
-                self._run_block(l, xact, E[l], st, kv_cache_meta[l], crossattn_cache_meta[l], kv_cache_manager,
-                                kv_cache_requests)
+        return dict(xact=xact, E=E, eh=eh, h=h, st=st, kv_meta=kv_cache_meta, cross_meta=crossattn_cache_meta, grid=grid, B=B, F_=F_,
+                    rows_per_group=rows_per_group)
 
-        # ---- head -------------------------------------------------------------------------
-        ops.layernorm(xact, self.eps, mod=eh, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group, out=h)
-        yv = self._lin(self.g, "head", h)                                         # [B*N, out*prod(patch)]
+    def _epilogue(self, fw: dict) -> torch.Tensor:
+        """The head behind the layers (modulated LayerNorm, projection, gather of the sequence-parallel shards, unpatchify)."""
+        ops.layernorm(fw["xact"], self.eps, mod=fw["eh"], shift_slot=0, scale_slot=1, rows_per_group=fw["rows_per_group"], out=fw["h"])
+        yv = self._lin(self.g, "head", fw["h"])                                   # [B*N, out*prod(patch)]
         if self.cp is not None:
-            yv = self.cp.gather_head(yv, B, F_)
-        return C.unpatchify(yv, B, grid, self.patch_size, self.out_dim)
+            yv = self.cp.gather_head(yv, fw["B"], fw["F_"])
+        return C.unpatchify(yv, fw["B"], fw["grid"], self.patch_size, self.out_dim)

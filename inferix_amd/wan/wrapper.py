@@ -89,6 +89,28 @@ class HipWanDiffusionWrapper(torch.nn.Module):
         return flow, x0
 
 
+    @torch.no_grad()
+    def forward_pair(self, first: dict, second: dict):
+        """Two `forward` calls (their keyword arguments) enqueued layer-interleaved on two streams (HipCausalWanModel.forward_pair) — for
+        the clean-context re-run of one block and the first denoising step of the next, which depend on each other only through the
+        cache, layer by layer.  Returns `((flow, x0), (flow, x0))`, bit-identical to the two calls made one after the other."""
+        def model_kw(kw):
+            if kw.get("kv_cache_meta") is None or kw.get("classify_mode") or kw.get("clean_x") is not None:
+                raise NotImplementedError("HipWanDiffusionWrapper implements the KV-cached inference call only")
+            return dict(x=kw["noisy_image_or_video"].permute(0, 2, 1, 3, 4), t=kw["timestep"],
+                        context=kw["conditional_dict"]["prompt_embeds"], kv_cache_meta=kw["kv_cache_meta"],
+                        crossattn_cache_meta=kw["crossattn_cache_meta"], current_start=kw["current_start"],
+                        kv_cache_manager=kw["kv_cache_manager"], kv_cache_requests=kw["kv_cache_requests"])
+        flows = self.model.forward_pair(model_kw(first), model_kw(second))
+        out = []
+        for kw, flow in zip((first, second), flows):
+            flow = flow.permute(0, 2, 1, 3, 4)
+            xt, ts = kw["noisy_image_or_video"], kw["timestep"]
+            x0 = self._convert_flow_pred_to_x0(flow.flatten(0, 1), xt.flatten(0, 1).to(flow.device), ts.flatten(0, 1)).unflatten(0, flow.shape[:2])
+            out.append((flow, x0))
+        return out[0], out[1]
+
+
 class HipCausVidDiffusionWrapper(HipWanDiffusionWrapper):
     """CausVid generator (inferix/models/causvid/wrapper.py:269-304): explicit `kv_start/kv_end` cache slots per
     call, returns `pred_x0` only.  Same kernels as Self-Forcing; the default timestep shift is 8.0."""

@@ -78,7 +78,7 @@ def _pipeline(cfg, W, steps, shift, **model_kw):
     return m, gen, args
 
 
-def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4):
+def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4, pair=None, want_cache=False):
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     from inferix_amd.pipeline import CausalInferencePipeline
@@ -86,6 +86,7 @@ def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4):
     W = O.init_weights(cfg, seed=0)
     m, gen, args = _pipeline(cfg, W, fx["steps"].tolist(), float(fx["shift"]))
     args.kv_cache_tokens = int(fx["cache_tokens"]) if cfg.local_attn_size == -1 else None
+    args.pair_forwards = pair            # None: the pipeline's default (off on one GPU); True: re-run + next first step layer-interleaved
     if cfg.local_attn_size == -1:
         args.kv_cache_tokens = min(int(fx["cache_tokens"]), 21 * cfg.frame_seqlen)
     pe = fx["prompt_embeds"].cuda()
@@ -104,6 +105,17 @@ def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4):
         trace.append((int(kw["current_start"]), int(meta["global_end_index"]), int(meta["local_end_index"])))
         return out
     gen.forward = rec
+    if pair:
+        # forward_pair does not go through gen.forward: record layer 0's index state as the MODEL leaves it, in host order (the first
+        # chain's layer 0 is enqueued before the second's: the order of the sequential calls)
+        run0 = m._run_block
+
+        def rec_block(l, xact, El, st, meta, cmeta, mgr, rq):
+            run0(l, xact, El, st, meta, cmeta, mgr, rq)
+            if l == 0:
+                trace.append((int(st["current_start"]), int(meta["global_end_index"]), int(meta["local_end_index"])))
+        m._run_block = rec_block
+        gen.forward = orig
     if paging:
         # allocate first so paging can be enabled before the rollout starts
         pipe._initialize_kv_cache(kvm, reqs, BF)
@@ -143,6 +155,10 @@ def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4):
         fl, r1, r2 = rel_l2(ref_c, ex_c), rel_l2(got, ref_c), rel_l2(got, ex_c)
         print(f"{name}: layer-0 cache {nm} after the rollout: floor {fl:.3e}; HIP vs exact {r2:.3e}; HIP vs reference {r1:.3e}")
         assert r1 <= slack * fl + eps and r2 <= slack * fl + eps, (nm, fl, r1, r2)
+    if want_cache:
+        caches = [kvm.get_raw(r, f"layer_{l}")[:, :le].clone() for r in reqs for l in range(cfg.num_layers)] if pt is None else \
+                 [k_log[:le].clone(), v_log[:le].clone()]
+        return out, fx, caches
     return out, fx
 
 
@@ -165,6 +181,23 @@ def test_rollout_local_attention_roll_and_page_table_agree():
     out_roll, fx = _run_rollout("rollout_tiny_local.npz", cfg)
     out_page, _ = _run_rollout("rollout_tiny_local.npz", cfg, paging=cfg.frame_seqlen)
     assert torch.equal(out_roll, out_page), "page-table rotation and physical roll diverge"
+
+
+@pytest.mark.parametrize("name,kw,paging", [("rollout_tiny.npz", {}, False), ("rollout_tiny_prefill.npz", {}, False),
+                                            ("rollout_tiny_b2.npz", {}, False),
+                                            ("rollout_tiny_local.npz", dict(local_attn_size=6, sink_size=1), False),
+                                            ("rollout_tiny_local.npz", dict(local_attn_size=6, sink_size=1), True)])
+def test_rollout_with_paired_forwards_is_bit_identical(name, kw, paging):
+    """`pair_forwards`: the clean-context re-run of block b and the first denoising step of block b + 1 enqueued layer by layer on two
+    streams (HipCausalWanModel.forward_pair).  Same launches on the same data in the same per-cache order: latents AND every layer's
+    cache rows must equal the sequential pipeline's BIT FOR BIT, the integer index trace must be the reference's, and the golden
+    bounds hold — plain, prefill, batch 2, and sink + rolling eviction through the shift kernel and through the page table."""
+    cfg = O.tiny_config(**kw)
+    pg = cfg.frame_seqlen if paging else None
+    seq, _, c_seq = _run_rollout(name, cfg, paging=pg, want_cache=True)
+    par, _, c_par = _run_rollout(name, cfg, paging=pg, pair=True, want_cache=True)
+    assert torch.equal(seq, par), f"{name}: paired forwards changed the latents ({rel_l2(par.cpu(), seq.cpu()):.3e})"
+    assert len(c_seq) == len(c_par) and all(torch.equal(a, b) for a, b in zip(c_seq, c_par)), f"{name}: paired forwards changed cache rows"
 
 
 def test_teacher_forced_forwards_vs_reference_golden():
