@@ -584,7 +584,10 @@ def main():
                          "runs under the q projection; auto = kv-first in front of the all-gather, fused in front of the peer stores")
     ap.add_argument("--pair", choices=["auto", "on", "off"], default="auto",
                     help="the clean-context re-run of a block enqueued layer-interleaved with the next block's first step "
-                         "(pipeline pair_forwards; bit-identical results): auto = on for sequence-parallel ranks, off on one GPU")
+                         "(pipeline pair_forwards; bit-identical results): auto = the pipeline's default (on)")
+    ap.add_argument("--pair-mode", choices=["auto", "streams", "lockstep"], default="auto",
+                    help="how a pair runs: two layer-interleaved launch chains on two streams, or one chain over both forwards' rows "
+                         "(auto: streams)")
     ap.add_argument("--magi-leg", choices=["fp8", "bf16"], default=None,
                     help="debug: run ONLY the config 5 leg (MAGI-4.5B model through the chunk schedule, one emulated cp rank) and print it")
     ap.add_argument("--magi-steps", type=int, default=0, help="debug: with --magi-leg, only the first N steps of each schedule stage")
@@ -627,6 +630,7 @@ def main():
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     model, gen, pipe = build_pipeline(device, pc, a.layers or None)
     pipe.args.pair_forwards = {"auto": None, "on": True, "off": False}[a.pair]
+    model.pair_mode = None if a.pair_mode == "auto" else a.pair_mode
     exchange_used, rccl_ranks, sp_preflight = None, None, None
     if world > 1:
         from inferix_amd.sequence_parallel import PeerStoreExchange
@@ -799,7 +803,7 @@ def main():
                        "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
                        "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
                        "layers": model.num_layers,
-                       "pair_forwards": bool(pipe._pairing())},
+                       "pair_forwards": bool(pipe._pairing()), "pair_mode": model._pair_mode() if pipe._pairing() else None},
             "rccl_ranks": rccl_ranks, "sp_exchange": exchange_used, "sp_preflight": sp_preflight,
             "ms_per_denoise_step": round(sum(denoise_ms) / len(denoise_ms), 3),
             "ms_per_forward_by_block": per_block_ms,

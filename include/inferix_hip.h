@@ -59,7 +59,11 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   auto picks for launches of at least 2048 rows); 22 splits K over two workgroups per tile where N <= 2048 and
  *                   K >= 4096 when the caller gives a workspace (ifx_gemm_bf16_ws), 25 = 22 without that split,
  *                   26 = stream-K on the 128-token ping-pong tile (needs the ifx_gemm_workspace_bytes workspace; an experiment that
- *                   lost to the tiles above at every size tried, kept for the lab: profiles/r3_gemm_pp.md).
+ *                   lost to the tiles above at every size tried, kept for the lab: profiles/r3_gemm_pp.md),
+ *                   27 / 28 / 29 = the 128-token ping-pong tile with K split over 2 / 4 / 8 workgroups per tile (each part >= 1 dumps
+ *                   its fp32 tile image and raises its own flag, part 0 adds them in part order; needs the ifx_gemm_workspace_bytes
+ *                   workspace and K / 64 divisible by the parts).  Under gemm_small_split 0 = auto takes the 4-way form for long-K
+ *                   launches whose 128 x 256 tiles x 4 make one round of 129 .. 256 work items (a 4-way rank's FFN down-projection).
  *                   ifx_gemm_q8 reads the same option: 1 / 2 = register-staged 128x128 / 64-byte-row LDS-DMA tiles, 3 = the LDS-DMA
  *                   tiles, never the ping-pong tile, 22 / 23 / 24 = the ping-pong tile with 256 / 192 / 128 tokens (FP8 and INT8)
  *   "gemm_small_split": 1 lets the auto choice split K between the wave groups of one workgroup for launches of at most one workgroup

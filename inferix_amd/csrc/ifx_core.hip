@@ -79,7 +79,7 @@ extern "C" const char* ifx_last_error(void) {
 }
 extern "C" const char* ifx_arch(void) { return "gfx950"; }
 extern "C" int ifx_set_option(const char* key, int32_t value) {
-  if (key && !strcmp(key, "gemm_variant") && value >= 0 && value <= 26) { ifx::g_gemm_variant = value; return IFX_OK; }
+  if (key && !strcmp(key, "gemm_variant") && value >= 0 && value <= 29) { ifx::g_gemm_variant = value; return IFX_OK; }
   if (key && !strcmp(key, "gemm_small_split") && (value == 0 || value == 1)) { ifx::g_gemm_small_split = value; return IFX_OK; }
   if (key && !strcmp(key, "attn_variant") && value >= 0 && value <= 7) { ifx::g_attn_variant = value; return IFX_OK; }
   if (key && !strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 600000) { ifx::g_spin_timeout_ms = value; return IFX_OK; }

@@ -186,7 +186,9 @@ size_t gemm_w4_workspace_bytes(int M, int N, int splits);
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa = nullptr,
-                   const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0, int stream_k = 0, int q8_int8 = 0);
+                   const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0, int stream_k = 0, int q8_int8 = 0,
+                   int force_ks = 0);
+size_t gemm_pp_small_workspace_bytes(int M, int N, int ks);
 size_t gemm_pp_stream_k_workspace_bytes();
 bool gemm_pp_split(int N, int K);
 size_t gemm_pp_workspace_bytes(int M, int N, int K);
@@ -320,6 +322,17 @@ static bool small_split_takes_tile12(int M, int N, int K) {
   return wgs128 > 128 && wgs128 <= 256;
 }
 
+// Shard-sized long-K launches (gemm_small_split): the 128-token ping-pong tile with K split over FOUR workgroups per tile where that
+// makes one round of 129 .. 256 work items — a 4-way rank's FFN down-projection, 1170 x 1536 x 8960: 60 tiles x 4 = 240 items of 35
+// K-steps, 52.0 us against 56.6 for the in-workgroup split 64 x 64 tiles (tools/bench_gemm_tiles.py 1170 0,27,28,29, round 5).  Measured
+// and NOT taken everywhere else: 585 rows 46.7 (4-way) against 35.5, 2340 rows 80.2 (2-way) against 81.0, every K = 1536 launch behind
+// the auto choice by 1.2 - 3x (the owner reads ks - 1 partial tiles: 128 KiB each through one CU).
+static bool small_split_takes_pp_ks4(int M, int N, int K) {
+  if (!gemm_small_split() || M >= 2048 || N > 2048 || N % 64 != 0 || K < 4096 || K % 64 != 0 || (K / 64) % 4 != 0) return false;
+  const int items = ((M + 127) / 128) * ((N + 255) / 256) * 4;
+  return items > 128 && items <= 256;
+}
+
 static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias, ifx_bf16* y,
                           int32_t ldy, int32_t M, int32_t N, int32_t K, const ifx_epilogue* epi, void* stream, void* workspace,
                           int64_t workspace_bytes) {
@@ -370,10 +383,32 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
       return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
                             ea.rows_per_group, (hipStream_t)stream, 2, workspace, nullptr, nullptr, nullptr, 0, 1);
   }
+  // lab (gemm_variant 27 / 28 / 29): the 128-token ping-pong tile with K split over 2 / 4 / 8 workgroups per tile, whatever the shape
+  if (wide_ok && variant >= 27 && variant <= 29) {
+    const int ks = 2 << (variant - 27);
+    const bool res = mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES;
+    const bool fits = N % 64 == 0 && K % 64 == 0 && (K / 64) % ks == 0 && workspace != nullptr &&
+                      workspace_bytes >= (int64_t)gemm_pp_small_workspace_bytes(M, N, ks) &&
+                      (long)((M + 127) / 128) * ((N + 255) / 256) * (ks - 1) <= 1024 && !((uintptr_t)bias & 7) &&
+                      (!res || (!((uintptr_t)ea.residual & 15) && ea.ld_res % 8 == 0)) &&
+                      (mode != IFX_EPI_GATE_RES || (!((uintptr_t)ea.mod & 15) && ea.rows_per_group >= 64));
+    if (fits)
+      return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                            ea.rows_per_group, (hipStream_t)stream, 2, workspace, nullptr, nullptr, nullptr, 0, 0, 0, ks);
+  }
   // Under gemm_small_split (a sequence-parallel rank: row-count dependent summation orders are allowed) narrow-N launches whose 128 x 128
   // tiles make ONE round of at most 256 workgroups take tile 12 — 128 x 128 with K split between the two wave groups of the workgroup —
   // ahead of the ping-pong tiles: at 2340 rows (P = 2) 19 x 12 = 228 workgroups against 60-120 work items of the 256-token ping-pong
   // tile.  tools/bench_gemm_tiles.py 2340: 1536^2 28.1 / 25.8 -> 23.3 / 19.3 us (+ residual / bias only), 1536 x 8960 102.6 -> 82.1.
+  if (wide_ok && variant == 0 && small_split_takes_pp_ks4(M, N, K) && workspace != nullptr &&
+      workspace_bytes >= (int64_t)gemm_pp_small_workspace_bytes(M, N, 4)) {
+    const bool res = mode == IFX_EPI_RESIDUAL || mode == IFX_EPI_GATE_RES;
+    const bool fits = !((uintptr_t)bias & 7) && (!res || (!((uintptr_t)ea.residual & 15) && ea.ld_res % 8 == 0)) &&
+                      (mode != IFX_EPI_GATE_RES || (!((uintptr_t)ea.mod & 15) && ea.rows_per_group >= 64));
+    if (fits)
+      return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
+                            ea.rows_per_group, (hipStream_t)stream, 2, workspace, nullptr, nullptr, nullptr, 0, 0, 0, 4);
+  }
   if (wide_ok && variant == 0 && small_split_takes_tile12(M, N, K))
     return launch_gemm_lds_dma(12, x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
                                ea.rows_per_group, (hipStream_t)stream);
@@ -427,6 +462,8 @@ extern "C" int64_t ifx_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   const int v = gemm_variant();
   if (v == 20) return want_w4_splitk(M, N, K) ? (int64_t)gemm_w4_workspace_bytes(M, N, 2) : 0;
   if (v == 26 && N % 64 == 0 && K % 64 == 0) return (int64_t)gemm_pp_stream_k_workspace_bytes();
+  if (v >= 27 && v <= 29) return (N % 64 == 0 && K % 64 == 0 && (K / 64) % (2 << (v - 27)) == 0) ? (int64_t)gemm_pp_small_workspace_bytes(M, N, 2 << (v - 27)) : 0;
+  if (v == 0 && small_split_takes_pp_ks4(M, N, K)) return (int64_t)gemm_pp_small_workspace_bytes(M, N, 4);
   if (v == 0 && N % 8 == 0 && small_split_takes_tile12(M, N, K)) return 0;      // the launcher's shortcut (wide_ok needs N % 8 == 0)
   if ((v == 0 && N % 64 == 0 && K % 64 == 0 && !(gemm_small_split() && M < 2048)) || v == 22) return (int64_t)gemm_pp_workspace_bytes(M, N, K);
   return 0;

@@ -118,6 +118,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   // KS = 2: every tile is TWO work items, the K halves, on two workgroups (neighbouring ids: same XCD, same position of their lists).
   // The second half's workgroup leaves its fp32 accumulators in the workspace (write-through stores) and raises the tile's flag; the
   // first half's workgroup adds them to its own — always first + second — and runs the epilogue.  `total` counts ITEMS.
+  // KS = 4, 8 (round 5; the shard-sized launches of a sequence-parallel rank): KS items per tile, parts 1 .. KS-1 each dump into their
+  // own slot (tile * (KS-1) + part - 1) and raise their own flag, part 0 waits for all of them and adds them IN PART ORDER
+  // (((p0 + p1) + p2) + ...: one fixed summation order, whoever finishes last).  Nobody waits for a workgroup that waits: owners wait
+  // for producers with LARGER item ids only, and every workgroup walks its ids upwards (wg_per_xcd >= KS or one item per workgroup).
   constexpr int ES = Q8 ? 1 : 2;            // bytes per operand element
   const unsigned char* const xb = reinterpret_cast<const unsigned char*>(x);
   const unsigned char* const wb = reinterpret_cast<const unsigned char*>(w);
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     return SK ? min(S, sk_u1 - (sk_t0 + i) * S) - (i == 0 ? sk_u0 - sk_t0 * S : 0) : KT;
   };
   // an item whose accumulators go to the workspace instead of through the epilogue / the number of later partial sums its epilogue adds
-  auto item_dumps = [&](int i) __attribute__((always_inline)) { return SK ? (i == 0 && sk_u0 > sk_t0 * S) : (KS > 1 && item_split(i) == 1); };
+  auto item_dumps = [&](int i) __attribute__((always_inline)) { return SK ? (i == 0 && sk_u0 > sk_t0 * S) : (KS > 1 && item_split(i) >= 1); };
   auto item_parts = [&](int i) __attribute__((always_inline)) {
-    if (!SK) return KS > 1 ? 1 : 0;
+    if (!SK) return KS > 1 ? KS - 1 : 0;
     const int t_end = (sk_t0 + i + 1) * S;            // first K-step of the next tile
     int n = 0;
     while (sk_p + 1 + n < sk_P && sk_start(sk_p + 1 + n) < t_end) ++n;
@@ -322,10 +326,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   //      (raised once every wave of the producer has waited for its stores: vmcnt(0) + the workgroup barrier).
   const __amdgpu_buffer_rsrc_t rs_ws =
       __builtin_amdgcn_make_buffer_rsrc((void*)ws_part, 0,
-                                        KS != 1 ? (int)min((long)(SK ? sk_P : total / KSD) * BM * BN * 4L, 0x7fffffffL) : 0, 0x00020000);
-  // slot of the workspace an item dumps to / the first slot its epilogue reads: the tile's (split-K), the workgroup's (stream-K)
-  auto part_soff = [&](int i) __attribute__((always_inline)) { return (SK ? sk_p : item_tile(i)) * (BM * BN * 4) + wave * (TJ * 8192); };
-  auto flag_of = [&](int i) __attribute__((always_inline)) { return SK ? sk_p : item_tile(i); };
+                                        KS != 1 ? (int)min((long)(SK ? sk_P : total / KSD * (KSD - 1)) * BM * BN * 4L, 0x7fffffffL) : 0, 0x00020000);
+  // slot of the workspace an item dumps to (split-K: part p >= 1 of tile t owns slot t (KS-1) + p - 1; stream-K: the workgroup's) / the
+  // first slot its epilogue reads (the owner, part 0: slot t (KS-1))
+  auto part_slot = [&](int i) __attribute__((always_inline)) {
+    return SK ? sk_p : item_tile(i) * (KSD - 1) + (item_split(i) > 0 ? item_split(i) - 1 : 0);
+  };
+  auto part_soff = [&](int i) __attribute__((always_inline)) { return part_slot(i) * (BM * BN * 4) + wave * (TJ * 8192); };
+  auto flag_of = [&](int i) __attribute__((always_inline)) { return part_slot(i); };
   auto dump_partial = [&](int i) __attribute__((always_inline)) {
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(ln));
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   };
   int flag_pending = 0;                              // 1 + tile whose partial this workgroup has dumped and not yet announced
   auto consumer_sync = [&](int i) __attribute__((always_inline)) {              // all eight waves: the partial sums the epilogue adds are complete and visible
-    const int first = SK ? sk_p + 1 : item_tile(i), n = item_parts(i);
+    const int first = SK ? sk_p + 1 : item_tile(i) * (KSD - 1), n = item_parts(i);
     if (wave == 0) {
       // BOUNDED (round-4 verdict): a producer that is not resident (a grid larger than the chip admits, a preempted queue)
       // would otherwise hang the GPU.  After `spin_ticks` of the 100 MHz wall clock the wait gives up, raises the device error word
@@ -487,19 +495,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
             for (int e = 0; e < 4; ++e) v[e] = (float)__builtin_bit_cast(int, v[e]);                  // the exact int32 sum
           }
           if constexpr (KS > 1) {
-            // + the partner's partial sums of the second K half, read where the accumulators are consumed (writing them back into
-            // the accumulator vectors first costs hipcc ~300 spilled registers): first half + second half, then the bias
-            const f32x4 pq = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024, part_so, 16));
-            if constexpr (Q8 == 2) {                   // int8: both halves are exact int32 sums (bit patterns): the split does not change a bit
+            // + the partners' partial sums of the later K ranges, read where the accumulators are consumed (writing them back into
+            // the accumulator vectors first costs hipcc ~300 spilled registers): ((first + second) + third) ..., then the bias.  The
+            // KS - 1 loads of a register quad are independent and requested together (compile-time trip count).
+            f32x4 pq[KSD - 1];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float pe = pq[e];                // (bit_cast of a vector ELEMENT expression reads element 0 whatever e is: hipcc 7.0)
-                v[e] = (float)(__builtin_bit_cast(int, v[e]) + __builtin_bit_cast(int, pe));
-              }
+            for (int q = 0; q < KSD - 1; ++q)
+              pq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, ln * 16 + ((i * TJ + j) * 4 + g) * 1024,
+                                                                                      part_so + q * (BM * BN * 4), 16));
+            if constexpr (Q8 == 2) {                   // int8: all parts are exact int32 sums (bit patterns): the split does not change a bit
+              int vi[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vi[e] = __builtin_bit_cast(int, v[e]);
+#pragma unroll
+              for (int q = 0; q < KSD - 1; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float pe = pq[q][e];           // (bit_cast of a vector ELEMENT expression reads element 0 whatever e is: hipcc 7.0)
+                  vi[e] += __builtin_bit_cast(int, pe);
+                }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (float)vi[e];
             } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += pq[e];
+              for (int q = 0; q < KSD - 1; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += pq[q][e];
             }
           }
           if constexpr (SK) {                          // the later K ranges of the tile, in ascending K order
@@ -804,10 +825,18 @@ size_t gemm_pp_workspace_bytes(int M, int N, int K) {
   return 4096 + (b4 > b3 ? b4 : b3);
 }
 
+// shard-sized launches (gemm_small_split): the 128-token tile with K split over `ks` workgroups per tile — 4096 bytes of flags + one
+// fp32 tile image per (tile, part >= 1)
+size_t gemm_pp_small_workspace_bytes(int M, int N, int ks) {
+  if (ks <= 1) return 0;
+  const size_t tiles = (size_t)((M + 127) / 128) * ((N + 255) / 256);
+  return 4096 + tiles * (size_t)(ks - 1) * 128 * 256 * 4;
+}
+
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8) {
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8, int force_ks) {
   using namespace gpp;
   const bool q8 = q8_sa != nullptr;                  // e4m3 operands: x / w point at bytes, ldx and K count elements = bytes
   EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, q8_sa, q8_sw, q8_qdiv, q8_via_bf16};
@@ -848,8 +877,19 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
   // (the 256- and 192-token tiles are instantiated with the split: a caller that forces the 128-token tile on a split shape — gemm_variant
   //  24 through ifx_gemm_bf16_ws — gets the unsplit launch, not an error)
   // (8-bit operands: a K-step is 128 elements, K counts elements; the same (N, K)-only rule on the step count)
-  const int ks = stream_k ? 0 : ((tj == 4 || (tj == 3 && !q8)) && workspace != nullptr && gemm_pp_split(N, q8 ? K / 2 : K) &&
-                                 tiles_m * tiles_n <= 1024) ? 2 : 1;
+  // force_ks = 2 / 4 / 8 (bf16, 128-token tile): the caller's choice for shard-sized launches (gemm_small_split; pick_pp_small) —
+  // the caller has checked the workspace against gemm_pp_small_workspace_bytes
+  int ks = stream_k ? 0 : ((tj == 4 || (tj == 3 && !q8)) && workspace != nullptr && gemm_pp_split(N, q8 ? K / 2 : K) &&
+                           tiles_m * tiles_n <= 1024) ? 2 : 1;
+  if (force_ks > 1) {
+    if (q8 || stream_k || tj != 2 || workspace == nullptr || (K / 64) % force_ks != 0 || tiles_m * tiles_n * (force_ks - 1) > 1024 ||
+        (force_ks != 2 && force_ks != 4 && force_ks != 8)) {
+      set_error("ifx_gemm_bf16: the %d-way K split needs the bf16 128-token tile, a workspace, K / 64 divisible by it and at most 1024 partial slots",
+                force_ks);
+      return IFX_EINVAL;
+    }
+    ks = force_ks;
+  }
   const int total = tiles_m * tiles_n * (ks ? ks : 1), per_xcd = (total + 7) / 8;
   int wg_per_xcd = min(per_xcd, max(1, n_cu / 8));
   if (stream_k) {
@@ -914,6 +954,9 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
     else { set_error("ifx_gemm_q8: no ping-pong tile of %d tokens", 64 * tj); return IFX_EINVAL; }
   } else if (ks == 0) {
     IFX_SWITCH_PP(2, 0, 0)
+  } else if (tj == 2 && ks == 2) { IFX_SWITCH_PP(2, 2, 0)
+  } else if (tj == 2 && ks == 4) { IFX_SWITCH_PP(2, 4, 0)
+  } else if (tj == 2 && ks == 8) { IFX_SWITCH_PP(2, 8, 0)
   } else if (ks == 2) {                              // split K: long-K, narrow-N shapes on the 256- or the 192-token tile
     if (tj == 4) { IFX_SWITCH_PP(4, 2, 0) }
     else { IFX_SWITCH_PP(3, 2, 0) }

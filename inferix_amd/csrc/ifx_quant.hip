@@ -604,7 +604,7 @@ namespace ifx {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8);
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8, int force_ks);
 bool gemm_pp_split(int N, int K);
 size_t gemm_pp_workspace_bytes(int M, int N, int K);
 }
@@ -689,7 +689,7 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
     if (tj != 0 && aligned)
       return launch_gemm_pp((const unsigned short*)xp, ldx, (const unsigned short*)wp, y, ldy, M, N, K,
                             mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj,
-                            split_ok && tj == 4 ? workspace : nullptr, x_scale, w_scale, qdiv, q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0);
+                            split_ok && tj == 4 ? workspace : nullptr, x_scale, w_scale, qdiv, q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0, 0);
   }
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };

@@ -284,7 +284,7 @@ def check_device(what: str = "") -> None:
 
 
 def set_option(key: str, value: int) -> None:
-    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..26, 'attn_variant' 0..7, 'gemm_small_split' 0/1,
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..29, 'attn_variant' 0..7, 'gemm_small_split' 0/1,
     'spin_timeout_ms', 'spin_fault' (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
     _OPTIONS[key] = int(value)

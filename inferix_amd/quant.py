@@ -178,6 +178,7 @@ def quantize_dynamic(module, qconfig_dict: Dict[str, Optional[QConfig]]):
         ng += 1
     model.quantized_linears = n
     model.quantized_global_linears = ng
+    getattr(model, "_temb_cache", {}).clear()        # memoised modulation tables were computed with the bf16 timestep MLPs
     return module
 
 
@@ -191,4 +192,5 @@ def dequantize(module):
         for k in [k for k in d if k.endswith(("_q", "_s", "_fmt", "_act"))]:
             del d[k]
     model.quantized_linears = model.quantized_global_linears = 0
+    getattr(model, "_temb_cache", {}).clear()
     return module

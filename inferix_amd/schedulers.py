@@ -6,6 +6,26 @@ from __future__ import annotations
 import torch
 
 
+class TensorMemo:
+    """value = f(tensor) memoised on the tensor's IDENTITY: storage address + version counter (any in-place write bumps it) + shape,
+    with the tensor kept alive in the entry — no other tensor can be allocated at that address while the entry exists, so a hit is the
+    same values.  For the handful of timestep tensors a clip reuses (sigma lookups: an argmin over the 1000-entry table per call)."""
+
+    def __init__(self, capacity: int = 16):
+        self.capacity, self.entries = capacity, {}
+
+    def get(self, t: torch.Tensor, extra, make):
+        key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, extra)
+        hit = self.entries.get(key)
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        v = make()
+        if len(self.entries) >= self.capacity:
+            self.entries.pop(next(iter(self.entries)))
+        self.entries[key] = (t, v)
+        return v
+
+
 class FlowMatchScheduler:
     def __init__(self, num_inference_steps=100, num_train_timesteps=1000, shift=3.0, sigma_max=1.0,
                  sigma_min=0.003 / 1.002, inverse_timesteps=False, extra_one_step=False, reverse_sigmas=False):
@@ -42,7 +62,9 @@ class FlowMatchScheduler:
 
     def add_noise(self, original_samples, noise, timestep):
         """(1 - sigma) * x0 + sigma * noise, sigma fp32, cast to noise dtype. [B*T, C, H, W], [B*T]."""
-        sigma = self.sigmas.to(noise.device)[self._lookup(timestep, noise.device)].reshape(-1, 1, 1, 1)
+        memo = self.__dict__.setdefault("_sigma_memo", TensorMemo())
+        sigma = memo.get(timestep, (str(noise.device), self.sigmas.data_ptr()),
+                         lambda: self.sigmas.to(noise.device)[self._lookup(timestep, noise.device)].reshape(-1, 1, 1, 1))
         return ((1 - sigma) * original_samples + sigma * noise).type_as(noise)
 
     def step(self, model_output, timestep, sample, to_final=False):

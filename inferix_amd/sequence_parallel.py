@@ -366,6 +366,15 @@ class PeerStoreExchange:
             self.flags.free()
 
 
+def _split_div():
+    import os
+    v = os.environ.get("IFX_SP_SPLIT_DIV", "")
+    if not v:
+        return (1, 1)
+    a, _, b = v.partition(",")
+    return (max(1, int(a)), max(1, int(b or a)))
+
+
 class HipSequenceParallel:
     """GPU side: what HipCausalWanModel calls per layer when world_size > 1.
 
@@ -476,6 +485,9 @@ class HipSequenceParallel:
         if st["side"] and st["have_prefix"]:
             s1 = ops.attention_split_plan(n_local, H, step.local_start)
             s2 = ops.attention_split_plan(n_local, H, step.local_end - step.local_start)
+            div = _split_div()
+            if div != (1, 1):                          # lab (IFX_SP_SPLIT_DIV="a,b"): fewer key chunks = fewer fp32 partials for the merge
+                s1, s2 = max(1, -(-s1 // div[0])), max(1, -(-s2 // div[1]))
             cap = s1 + s2
             ws = ops.attention_workspace(qv, cap)
             u1 = ops.attention_partial(qv, view, step.local_start, 0, s1, ws, 0, cap, scale=scale, tag="attn_self")

@@ -150,6 +150,8 @@ class HipCausalWanModel(torch.nn.Module):
         self.cross_dedup = True
         self._cross_dedup: Dict[str, Tuple[int, int]] = {}
         self._roll_scratch: Optional[torch.Tensor] = None
+        self._temb_cache: Dict[Tuple, Tuple] = {}      # timestep tensor identity -> (tensor, E, eh): see _prologue
+        self.index_trace: Optional[list] = None       # tests set a list: layer 0's KV index state after every forward
         self._chain = 0                               # 0 except while forward_pair enqueues its second forward
         self._pair_stream: Optional[torch.cuda.Stream] = None
         self.cp = None                                # set by inferix_amd.sequence_parallel when world_size > 1
@@ -213,6 +215,7 @@ class HipCausalWanModel(torch.nn.Module):
             w["f2_w"], w["f2_b"] = t(p + "ffn.2.weight"), t(p + "ffn.2.bias")
             mods.append(t(p + "modulation"))
         self.mod_all = torch.stack(mods, dim=0).contiguous()                      # [L, 1, 6, dim]
+        self._temb_cache.clear()
         return self
 
     # ------------------------------------------------------------------ helpers
@@ -329,11 +332,30 @@ class HipCausalWanModel(torch.nn.Module):
         ab = self._buf("a", B * N, d)
         ub = self._buf("u", B * N, self.ffn_dim)
         # ---------------- self attention ----------------
-        explicit = st.get("explicit_slots")          # CausVid: (kv_start, kv_end) given by the caller
-        if explicit is None:
+        # `samples`: what row block b = xact[b * N:(b + 1) * N] is — its request, RoPE grid, first token and (CausVid) named slots.  One per
+        # request normally; under `lockstep` (forward_pair's batched form) the blocks are TWO forwards of the same request(s), and the
+        # index state moves after each of them, as it would between the two calls.
+        explicit0 = st.get("explicit_slots")         # CausVid: (kv_start, kv_end) given by the caller
+        samples = st.get("samples")
+        if samples is None:
+            samples = [dict(req=req, rope=rope, current_start=current_start, explicit=explicit0, ctx_index=b)
+                       for b, req in enumerate(kv_cache_requests)]
+        lockstep = bool(st.get("lockstep"))
+        explicit_any = any(smp["explicit"] is not None for smp in samples)
+        if not explicit_any:
             g_end, l_end = self._meta_int(meta["global_end_index"]), self._meta_int(meta["local_end_index"])
         else:
             g_end = l_end = 0
+        steps_done: List[KVIndexStep] = []
+
+        def index_state(smp=None):                   # (global_end, local_end) a sample's slot arithmetic starts from
+            # the samples of ONE forward (its batch rows: separate caches, one shared index state) all start from the state that forward
+            # found; the second forward of a lockstep pair starts from what the first one left
+            if lockstep and smp is not None and smp.get("fwd", 0) > 0:
+                prev = [stp for stp, s0 in zip(steps_done, samples) if s0.get("fwd", 0) == smp["fwd"] - 1]
+                if prev:
+                    return prev[-1].global_end, prev[-1].local_end
+            return g_end, l_end
         step = None
         # 8-bit linears stay on the fused (norm + quantise -> one qkv GEMM) path: quantize_dynamic keeps the bf16 "qkv_w" next to
         # "qkv_q" / "qkv_s", so the test is for the QUANTISED entry — a split projection on the bf16 weights would silently bypass it
@@ -345,28 +367,36 @@ class HipCausalWanModel(torch.nn.Module):
             kvp = self._buf("kvp", B * N, 2 * d)
             ops.linear(h, w["qkv_w"][d:], w["qkv_b"][d:], out=kvp)
             name = blk.kv_cache_manager.self_name
-            pending = [self.cp.begin(self, l, self._kv_view(kv_cache_manager, req, name), kvp[b * N:(b + 1) * N], w, rope,
-                                     current_start, g_end, l_end, sink_tokens, kv_cache_manager, req, name)
-                       for b, req in enumerate(kv_cache_requests)]
+            pending = []
+            for b, smp in enumerate(samples):
+                ge, le = index_state(smp)
+                pst = self.cp.begin(self, l, self._kv_view(kv_cache_manager, smp["req"], name), kvp[b * N:(b + 1) * N], w, smp["rope"],
+                                    smp["current_start"], ge, le, sink_tokens, kv_cache_manager, smp["req"], name)
+                pending.append(pst)
+                steps_done.append(pst["step"])
             qraw = self._buf("qraw", B * N, d)
             ops.linear(h, w["qkv_w"][:d], w["qkv_b"][:d], out=qraw)
             for b, pst in enumerate(pending):
-                ops.rmsnorm_rope_kv_append(qraw[b * N:(b + 1) * N], w["nq"], None, self.eps, rope, None, 0, d, q_out=qb[b * N:(b + 1) * N])
+                ops.rmsnorm_rope_kv_append(qraw[b * N:(b + 1) * N], w["nq"], None, self.eps, samples[b]["rope"], None, 0, d,
+                                           q_out=qb[b * N:(b + 1) * N])
                 step = self.cp.finish(self, pst, qb[b * N:(b + 1) * N], ab[b * N:(b + 1) * N])
         else:
             self._norm_lin(w, "qkv", xact, h, dict(mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group), out=qkv)
-        for b, req in enumerate(() if kv_first else kv_cache_requests):
+        for b, smp in enumerate(() if kv_first else samples):
+            req, rope_b, explicit = smp["req"], smp["rope"], smp["explicit"]
             name = blk.kv_cache_manager.self_name
             view = self._kv_view(kv_cache_manager, req, name)
+            ge, le = index_state(smp)
             if self.cp is not None:
                 step = self.cp.self_attention(self, l, b, view, qkv[b * N:(b + 1) * N], qb[b * N:(b + 1) * N],
-                                              ab[b * N:(b + 1) * N], w, rope, current_start, g_end, l_end,
+                                              ab[b * N:(b + 1) * N], w, rope_b, smp["current_start"], ge, le,
                                               sink_tokens, kv_cache_manager, req, name)
+                steps_done.append(step)
                 continue
             if explicit is not None:
                 step = KVIndexStep(explicit[0], explicit[1], explicit[1], 0, 0, 0)
             else:
-                step = kv_index_update(g_end, l_end, current_start, N, view.k.shape[0], self.local_attn_size,
+                step = kv_index_update(ge, le, smp["current_start"], N, view.k.shape[0], self.local_attn_size,
                                        sink_tokens)
             if step.local_start < 0 or step.local_end > view.k.shape[0]:
                 raise _hip.HipKernelError(f"KV cache overflow: slots [{step.local_start}, {step.local_end}) of "
@@ -374,32 +404,43 @@ class HipCausalWanModel(torch.nn.Module):
             if step.evicted:
                 self._evict(kv_cache_manager, req, name, view, step)
                 view = self._kv_view(kv_cache_manager, req, name)
-            ops.rmsnorm_rope_kv_append(qkv[b * N:(b + 1) * N], w["nq"], w["nk"], self.eps, rope, view,
+            steps_done.append(step)
+            ops.rmsnorm_rope_kv_append(qkv[b * N:(b + 1) * N], w["nq"], w["nk"], self.eps, rope_b, view,
                                        step.local_start, d, q_out=qb[b * N:(b + 1) * N])
             ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end, scale=st.get("attn_scale", 0.0),
                           out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_self")
-        if explicit is None:
+        if not explicit_any:
             self._meta_set(meta, "global_end_index", step.global_end)
             self._meta_set(meta, "local_end_index", step.local_end)
+        if self.index_trace is not None and l == 0:   # tests: (current_start, global_end, local_end) of every FORWARD, in cache order
+            for smp, stp in zip(samples, steps_done if steps_done else [step] * len(samples)):
+                if smp["ctx_index"] == 0:
+                    self.index_trace.append((int(smp["current_start"]), int(stp.global_end), int(stp.local_end)))
         self._lin(w, "o", ab, epilogue=_hip.IFX_EPI_GATE_RES, residual=xact, mod=El, gate_slot=2,
                   rows_per_group=rows_per_group, out=xact)
         # ---------------- cross attention ----------------
         self._norm_lin(w, "cq", xact, h, dict(gamma=w["n3_w"], beta=w["n3_b"]), out=qb)
         ops.rmsnorm(qb, w["cnq"], self.eps, out=qb)
-        for b, req in enumerate(kv_cache_requests):
+        b = 0
+        while b < len(samples):
+            req = samples[b]["req"]
+            nb = 1                                   # consecutive row blocks of the SAME request (lockstep pair): one launch over all of them
+            while b + nb < len(samples) and samples[b + nb]["req"] is req:
+                nb += 1
             cview = self._kv_view(kv_cache_manager, req, blk.kv_cache_manager.cross_name)
             if not cmeta["is_init"]:
-                cb = ctx[b * self.text_len:(b + 1) * self.text_len]
+                ci = samples[b]["ctx_index"]
+                cb = ctx[ci * self.text_len:(ci + 1) * self.text_len]
                 kx = self._lin(w, "ck", cb)
                 ops.rmsnorm(kx, w["cnk"], self.eps, out=cview.k.view(self.text_len, d))
                 self._lin(w, "cv", cb, out=cview.v.view(self.text_len, d))
             nkeys, mult = self._cross_dedup.get(req.request_id, (self.text_len, 1)) if self.cross_dedup else (self.text_len, 1)
+            qv, av = qb[b * N:(b + nb) * N].view(nb * N, H, hd), ab[b * N:(b + nb) * N].view(nb * N, H, hd)
             if mult > 1:      # the zero-padded context rows are ONE key with a multiplicity (ifx_attn_fwd_dedup)
-                ops.attention_dedup(qb[b * N:(b + 1) * N].view(N, H, hd), cview, nkeys, mult,
-                                    out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
+                ops.attention_dedup(qv, cview, nkeys, mult, out=av, tag="attn_cross")
             else:
-                ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), cview, self.text_len,
-                              out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_cross")
+                ops.attention(qv, cview, self.text_len, out=av, tag="attn_cross")
+            b += nb
         cmeta["is_init"] = True
         self._lin(w, "co", ab, epilogue=_hip.IFX_EPI_RESIDUAL, residual=xact, out=xact)
         # ---------------- feed forward ----------------
@@ -441,6 +482,8 @@ class HipCausalWanModel(torch.nn.Module):
         results are bit-identical to them (tests/test_hip_model.py); what changes is that the second chain's launches fill the CUs and
         the dependent-launch gaps the first one leaves — a sequence-parallel rank's launches (585 rows at P = 8) occupy a fraction of
         the chip each.  `first` / `second`: the keyword arguments of `forward`.  Returns both flow predictions."""
+        if self._pair_mode() == "lockstep":
+            return self._forward_pair_lockstep(first, second)
         dev = self.device_
         main = torch.cuda.current_stream(dev)
         if self._pair_stream is None:
@@ -481,8 +524,69 @@ class HipCausalWanModel(torch.nn.Module):
         yb.record_stream(main)                        # allocated on the side stream, consumed (and later freed) on the caller's
         return ya, yb
 
+    def _pair_mode(self) -> str:
+        """How forward_pair runs its two forwards.  "streams" (default): two launch chains on two streams, layer-interleaved —
+        bit-identical to the sequential calls; the second chain fills the tails and the dependent-launch gaps of the first: - 2.2 % /
+        - 3 % of a clip on one GPU (two boxes), - 4 % on an emulated rank of 8.  "lockstep": ONE chain over both forwards' rows — every
+        row-local kernel (LayerNorms, the six GEMMs, RMSNorms, the cross-attention) runs once on 2 N rows, the self-attention part once
+        per forward in call order.  Built for the sequence-parallel rank (585 rows at P = 8: in the lab a layer's GEMMs take 110 us
+        for one forward and 168 us for two) and MEASURED behind the two-stream form there (283 vs 279 ms per clip at P = 8, 408 vs 407
+        at P = 4, 626 vs 620 at P = 2: inside the clip the 1170-row launches cost what two 585-row launches overlapped on two streams
+        cost), so it is not the default anywhere; kept, tested bit for bit against the sequential calls, selectable through the
+        `pair_mode` attribute / env IFX_PAIR_MODE."""
+        import os
+        m = getattr(self, "pair_mode", None) or os.environ.get("IFX_PAIR_MODE", "")
+        return m if m in ("streams", "lockstep") else "streams"
+
+    def _forward_pair_lockstep(self, first: dict, second: dict):
+        """forward_pair as one launch chain over the rows of both forwards (see _pair_mode).  Row block b < B is `first`'s sample b, row
+        block B + b `second`'s; the cache index state moves after each block's self-attention, exactly as between the two calls.  The
+        arithmetic of a row is the sequential call's; the GEMM tile (hence, where a tile splits K, the fp32 summation order) follows the
+        launch's row count as it does everywhere else: bit-identical to the sequential calls where the tile choice is row-invariant
+        (one GPU), within summation-order noise on a sequence-parallel rank (gemm_small_split)."""
+        kvm, reqs = first["kv_cache_manager"], list(first["kv_cache_requests"])
+        assert second["kv_cache_manager"] is kvm and list(second["kv_cache_requests"]) == reqs, \
+            "forward_pair: both forwards must address the same requests"
+        d = self.dim
+
+        def pro(kw, out):
+            return self._prologue(kw["x"], kw["t"], kw["context"], kw.get("kv_cache_meta"), kw.get("crossattn_cache_meta"),
+                                  kw.get("current_start", 0), kvm, reqs, kw.get("kv_start"), kw.get("kv_end"), xact_out=out)
+        lat = first["x"] if isinstance(first["x"], torch.Tensor) else torch.stack(list(first["x"]))
+        B = lat.shape[0]
+        pt_, ph, pw = self.patch_size
+        rows = B * (lat.shape[2] // pt_) * (lat.shape[3] // ph) * (lat.shape[4] // pw) // self.parallel_config.world_size
+        x2 = self._buf("x2", 2 * rows, d)
+        fa = pro(first, x2[:rows])
+        self._chain = 1                               # the second prologue's scratch (its `h`) must not alias the first's
+        try:
+            fb = pro(second, x2[rows:])
+        finally:
+            self._chain = 0
+        if fa["N"] != fb["N"] or fa["rows_per_group"] != fb["rows_per_group"] or fa["grid"] != fb["grid"]:
+            raise ValueError("forward_pair (lockstep): the two forwards must have the same latent geometry and timestep layout")
+        N = fa["N"]
+        E2 = torch.cat([fa["E"], fb["E"]], dim=1).contiguous()              # [L, 2 B Ft, 6, d]
+        eh2 = torch.cat([fa["eh"], fb["eh"]], dim=0).contiguous()
+        sa, sb = fa["st"], fb["st"]
+        samples = [dict(req=r, rope=s_["rope"], current_start=s_["current_start"], explicit=s_.get("explicit_slots"), ctx_index=b, fwd=f)
+                   for f, s_ in enumerate((sa, sb)) for b, r in enumerate(reqs)]
+        st = dict(sa, B=2 * B, samples=samples, lockstep=True, ctx=sa["ctx"] if sa["ctx"] is not None else sb["ctx"])
+        if sa["ctx"] is None and sb["ctx"] is not None or any(not m["is_init"] for m in fa["cross_meta"]):
+            raise RuntimeError("forward_pair: the cross-attention cache must be initialised before two forwards are paired")
+        with self._small_split_scope():
+            for l in range(self.num_layers):
+                self._run_block(l, x2, E2[l], st, fa["kv_meta"][l], fa["cross_meta"][l], kvm, reqs)
+        h2 = self._buf("h", 2 * B * N, d)
+        ops.layernorm(x2, self.eps, mod=eh2, shift_slot=0, scale_slot=1, rows_per_group=fa["rows_per_group"], out=h2)
+        yv = self._lin(self.g, "head", h2)
+        if self.cp is not None:
+            yv = self.cp.gather_head(yv, 2 * B, fa["F_"])
+        y = C.unpatchify(yv, 2 * B, fa["grid"], self.patch_size, self.out_dim)
+        return y[:B], y[B:]
+
     def _prologue(self, x, t, context, kv_cache_meta, crossattn_cache_meta, current_start, kv_cache_manager, kv_cache_requests,
-                  kv_start=None, kv_end=None) -> dict:
+                  kv_start=None, kv_end=None, xact_out: Optional[torch.Tensor] = None) -> dict:
         """Everything of a forward in front of the layers: embeddings, modulation tables, the text context (first call), the per-forward
         state the layers share.  Enqueues on the current stream, takes its scratch from chain `self._chain`."""
         explicit = None
@@ -517,16 +621,30 @@ class HipCausalWanModel(torch.nn.Module):
         patches = C.patchify(lat, self.patch_size)                               # [B*F*fs, 64]
         if cp_ws > 1:                                                            # keep hw-slice `rank` of every frame
             patches = patches.view(B * F_, fs, -1)[:, cp_rank * hw_local:(cp_rank + 1) * hw_local].reshape(B * N, -1)
-        xact = ops.linear(patches.contiguous(), self.g["patch_w"], self.g["patch_b"], out=self._buf("x", B * N, d))
+        xact = ops.linear(patches.contiguous(), self.g["patch_w"], self.g["patch_b"],
+                          out=self._buf("x", B * N, d) if xact_out is None else xact_out)
         t = t.to(dev)
-        emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]
-        # time_embedding / time_projection (a handful of rows): the same MFMA GEMM as the block linears, SiLU is elementwise glue
-        e = self._lin(self.g, "time2", F.silu(self._lin(self.g, "time0", emb.contiguous())))
-        e0 = self._lin(self.g, "tproj", F.silu(e)).unflatten(1, (6, d))                         # [B*Ft, 6, d]
         Ft = t.shape[1]                                                          # frames carrying a timestep (F or 1)
         rows_per_group = (F_ // Ft) * fs_l
-        E = (self.mod_all + e0.unsqueeze(0)).contiguous()                        # [L, B*Ft, 6, d] bf16
-        eh = (self.g["head_mod"] + e.unsqueeze(1)).contiguous()                  # [B*Ft, 2, d]
+        # The modulation tables are a function of the timestep tensor alone (and of the weights): a clip has five distinct ones (four
+        # denoising steps + the clean-context re-run) over 35 forwards.  Memoised on the tensor's identity — storage address, version
+        # counter (bumped by any in-place write) and shape — with the tensor itself kept alive in the entry, so that no other tensor can
+        # come to live at that address while the entry exists.  ~16 glue launches (sinusoid, three small GEMMs, SiLUs, the two table
+        # adds) per forward less; the same bits (the pipelines reuse one timestep tensor per step value, inferix_amd/pipeline).
+        tkey = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, self.g["time0_w"].data_ptr(), self.g.get("time0_fmt"))
+        hit = self._temb_cache.get(tkey)
+        if hit is not None and hit[0] is t:
+            E, eh = hit[1], hit[2]
+        else:
+            emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]
+            # time_embedding / time_projection (a handful of rows): the same MFMA GEMM as the block linears, SiLU is elementwise glue
+            e = self._lin(self.g, "time2", F.silu(self._lin(self.g, "time0", emb.contiguous())))
+            e0 = self._lin(self.g, "tproj", F.silu(e)).unflatten(1, (6, d))                         # [B*Ft, 6, d]
+            E = (self.mod_all + e0.unsqueeze(0)).contiguous()                        # [L, B*Ft, 6, d] bf16
+            eh = (self.g["head_mod"] + e.unsqueeze(1)).contiguous()                  # [B*Ft, 2, d]
+            if len(self._temb_cache) >= 16:
+                self._temb_cache.pop(next(iter(self._temb_cache)))
+            self._temb_cache[tkey] = (t, E, eh)
 
         need_ctx = any(not m["is_init"] for m in crossattn_cache_meta)
         ctx = None
@@ -565,7 +683,7 @@ class HipCausalWanModel(torch.nn.Module):
         st = dict(B=B, N=N, F_=F_, fs=fs, rows_per_group=rows_per_group, rope=rope, sink_tokens=sink_tokens,
                   current_start=current_start, ctx=ctx, explicit_slots=explicit, attn_scale=attn_scale)
         return dict(xact=xact, E=E, eh=eh, h=h, st=st, kv_meta=kv_cache_meta, cross_meta=crossattn_cache_meta, grid=grid, B=B, F_=F_,
-                    rows_per_group=rows_per_group)
+                    rows_per_group=rows_per_group, N=N, requests=list(kv_cache_requests))
 
     def _epilogue(self, fw: dict) -> torch.Tensor:
         """The head behind the layers (modulated LayerNorm, projection, gather of the sequence-parallel shards, unpatchify)."""

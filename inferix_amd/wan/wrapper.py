@@ -37,6 +37,8 @@ class HipWanDiffusionWrapper(torch.nn.Module):
         self.scheduler.set_timesteps(1000, training=True)
         self.seq_len = 32760
         self._sig64 = None
+        from ..schedulers import TensorMemo
+        self._sigma_memo = TensorMemo()
 
     @staticmethod
     def load_pretrained(model_path: str, **kw) -> HipCausalWanModel:
@@ -65,8 +67,10 @@ class HipWanDiffusionWrapper(torch.nn.Module):
         if self._sig64 is None or self._sig64[0].device != dev:
             self._sig64 = (self.scheduler.sigmas.double().to(dev), self.scheduler.timesteps.double().to(dev))
         sig, ts = self._sig64
-        idx = torch.argmin((ts.unsqueeze(0) - timestep.to(dev).double().unsqueeze(1)).abs(), dim=1)
-        return (xt.double() - sig[idx].reshape(-1, 1, 1, 1) * flow_pred.double()).to(flow_pred.dtype)
+        # the sigma of a timestep tensor is looked up once per tensor (memoised on its identity: a clip reuses five of them)
+        sigma = self._sigma_memo.get(timestep, (str(dev), sig.data_ptr()), lambda: sig[torch.argmin(
+            (ts.unsqueeze(0) - timestep.to(dev).double().unsqueeze(1)).abs(), dim=1)].reshape(-1, 1, 1, 1))
+        return (xt.double() - sigma * flow_pred.double()).to(flow_pred.dtype)
 
     @torch.no_grad()
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,

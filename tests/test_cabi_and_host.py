@@ -73,7 +73,7 @@ def test_cabi_argument_validation_without_gpu():
     assert lib.ifx_gemm_q8_quant_out(C.c_void_p(16), 128, C.c_void_p(8), C.c_void_p(16), C.c_void_p(8), None, C.c_void_p(16), 64, 4, 64, 128,
                                      0, C.byref(epi), C.c_void_p(8), 1, None) == -1
     assert b"GELU" in lib.ifx_last_error()
-    assert lib.ifx_set_option(b"gemm_variant", 26) == 0 and lib.ifx_set_option(b"gemm_variant", 27) != 0
+    assert lib.ifx_set_option(b"gemm_variant", 29) == 0 and lib.ifx_set_option(b"gemm_variant", 30) != 0
     assert lib.ifx_set_option(b"gemm_variant", 0) == 0
     assert lib.ifx_set_option(b"gemm_small_split", 1) == 0 and lib.ifx_set_option(b"gemm_small_split", 2) != 0
     assert lib.ifx_set_option(b"gemm_small_split", 0) == 0

@@ -78,7 +78,7 @@ def _pipeline(cfg, W, steps, shift, **model_kw):
     return m, gen, args
 
 
-def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4, pair=None, want_cache=False):
+def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4, pair=None, want_cache=False, pair_mode=None):
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
     from inferix_amd.pipeline import CausalInferencePipeline
@@ -86,7 +86,8 @@ def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4, pair=None, want_c
     W = O.init_weights(cfg, seed=0)
     m, gen, args = _pipeline(cfg, W, fx["steps"].tolist(), float(fx["shift"]))
     args.kv_cache_tokens = int(fx["cache_tokens"]) if cfg.local_attn_size == -1 else None
-    args.pair_forwards = pair            # None: the pipeline's default (off on one GPU); True: re-run + next first step layer-interleaved
+    args.pair_forwards = pair            # None: the pipeline's default; True: re-run + next block's first step enqueued as a pair
+    m.pair_mode = pair_mode              # None: streams on one GPU; "lockstep": one chain over both forwards' rows
     if cfg.local_attn_size == -1:
         args.kv_cache_tokens = min(int(fx["cache_tokens"]), 21 * cfg.frame_seqlen)
     pe = fx["prompt_embeds"].cuda()
@@ -95,27 +96,10 @@ def _run_rollout(name, cfg, paging=None, slack=1.25, eps=5e-4, pair=None, want_c
     B = fx["noise"].shape[0]
     kvm = KVCacheManager("cuda")
     reqs = [KVCacheRequest(f"req{i}") for i in range(B)]
-    # integer trace: wrap the generator to record the host-side index state after every forward
+    # integer trace: layer 0's host-side index state after every forward, recorded by the MODEL in host order (a paired re-run /
+    # first step does not pass through gen.forward; the first chain's layer 0 is enqueued before the second's: the sequential order)
     trace = []
-    orig = gen.forward
-
-    def rec(**kw):
-        out = orig(**kw)
-        meta = kw["kv_cache_meta"][0]
-        trace.append((int(kw["current_start"]), int(meta["global_end_index"]), int(meta["local_end_index"])))
-        return out
-    gen.forward = rec
-    if pair:
-        # forward_pair does not go through gen.forward: record layer 0's index state as the MODEL leaves it, in host order (the first
-        # chain's layer 0 is enqueued before the second's: the order of the sequential calls)
-        run0 = m._run_block
-
-        def rec_block(l, xact, El, st, meta, cmeta, mgr, rq):
-            run0(l, xact, El, st, meta, cmeta, mgr, rq)
-            if l == 0:
-                trace.append((int(st["current_start"]), int(meta["global_end_index"]), int(meta["local_end_index"])))
-        m._run_block = rec_block
-        gen.forward = orig
+    m.index_trace = trace
     if paging:
         # allocate first so paging can be enabled before the rollout starts
         pipe._initialize_kv_cache(kvm, reqs, BF)
@@ -187,17 +171,22 @@ def test_rollout_local_attention_roll_and_page_table_agree():
                                             ("rollout_tiny_b2.npz", {}, False),
                                             ("rollout_tiny_local.npz", dict(local_attn_size=6, sink_size=1), False),
                                             ("rollout_tiny_local.npz", dict(local_attn_size=6, sink_size=1), True)])
-def test_rollout_with_paired_forwards_is_bit_identical(name, kw, paging):
-    """`pair_forwards`: the clean-context re-run of block b and the first denoising step of block b + 1 enqueued layer by layer on two
-    streams (HipCausalWanModel.forward_pair).  Same launches on the same data in the same per-cache order: latents AND every layer's
-    cache rows must equal the sequential pipeline's BIT FOR BIT, the integer index trace must be the reference's, and the golden
-    bounds hold — plain, prefill, batch 2, and sink + rolling eviction through the shift kernel and through the page table."""
+@pytest.mark.parametrize("mode", ["streams", "lockstep"])
+def test_rollout_with_paired_forwards_is_bit_identical(name, kw, paging, mode):
+    """`pair_forwards`: the clean-context re-run of block b and the first denoising step of block b + 1 enqueued TOGETHER
+    (HipCausalWanModel.forward_pair) — "streams": layer by layer on two streams; "lockstep": one launch chain over both forwards' rows
+    (what a sequence-parallel rank runs).  Same arithmetic per row in the same per-cache order (and, without gemm_small_split, tiles
+    whose summation order does not depend on the row count): latents AND every layer's cache rows must equal the sequential pipeline's
+    BIT FOR BIT, the integer index trace must be the reference's, and the golden bounds hold — plain, prefill, batch 2, and sink +
+    rolling eviction through the shift kernel and through the page table."""
+    from inferix_amd import hip_ops as ops
+    ops.set_option("gemm_small_split", 0)
     cfg = O.tiny_config(**kw)
     pg = cfg.frame_seqlen if paging else None
-    seq, _, c_seq = _run_rollout(name, cfg, paging=pg, want_cache=True)
-    par, _, c_par = _run_rollout(name, cfg, paging=pg, pair=True, want_cache=True)
-    assert torch.equal(seq, par), f"{name}: paired forwards changed the latents ({rel_l2(par.cpu(), seq.cpu()):.3e})"
-    assert len(c_seq) == len(c_par) and all(torch.equal(a, b) for a, b in zip(c_seq, c_par)), f"{name}: paired forwards changed cache rows"
+    seq, _, c_seq = _run_rollout(name, cfg, paging=pg, pair=False, want_cache=True)
+    par, _, c_par = _run_rollout(name, cfg, paging=pg, pair=True, want_cache=True, pair_mode=mode)
+    assert torch.equal(seq, par), f"{name}: paired forwards ({mode}) changed the latents ({rel_l2(par.cpu(), seq.cpu()):.3e})"
+    assert len(c_seq) == len(c_par) and all(torch.equal(a, b) for a, b in zip(c_seq, c_par)), f"{name}: paired forwards ({mode}) changed cache rows"
 
 
 def test_teacher_forced_forwards_vs_reference_golden():

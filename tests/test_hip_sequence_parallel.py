@@ -98,19 +98,23 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend
                                        text_encoder=lambda text_prompts: {"prompt_embeds": pe}, vae=None,
                                        parallel_config=pc)
         trace = []
-        orig = gen.forward
-
         shapes, idents = set(), set()
+        # recorded where the MODEL leaves layer 0 (not around gen.forward): a sequence-parallel pipeline enqueues the clean-context re-run
+        # of a block together with the next block's first step (forward_pair, which does not pass through gen.forward); the first chain's
+        # layer 0 precedes the second's on the host, so the records come in the order of the sequential calls
+        run0 = m._run_block
+        index_trace = m.index_trace = []
 
-        def rec(**kw):
-            out = orig(**kw)
-            meta = kw["kv_cache_meta"][0]
-            shapes.add(tuple(kw["kv_cache_manager"].get_raw(kw["kv_cache_requests"][0], "layer_0").shape))
+        def rec(l, xact, El, st, meta, cmeta, mgr, rq):
+            run0(l, xact, El, st, meta, cmeta, mgr, rq)
+            if l == 0:
+                shapes.add(tuple(mgr.get_raw(rq[0], "layer_0").shape))
+                del trace[:]
+                trace.extend(list(r) for r in index_trace)
             if peer is not None:
                 idents.update(k[2] for k in peer._views)
-            trace.append([int(kw["current_start"]), int(meta["global_end_index"]), int(meta["local_end_index"])])
-            return out
-        gen.forward = rec
+        m._run_block = rec
+        assert pipe._pairing(), "a sequence-parallel model pairs its forwards by default"
         renoise = [fx[f"renoise_{i}"] for i in range(int(fx["num_renoise"]))]
         mgr1 = KVCacheManager("cuda")
         out = pipe.inference(noise=fx["noise"].cuda(), text_prompts=["x"], kv_cache_manager=mgr1,
@@ -131,6 +135,7 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend
             # second call the first call's (freed, still IPC-mapped) caches.  Same request id, fresh manager, caches of the first call
             # dropped in between: the rollout has to come out again, bit for bit.
             del trace[:]
+            del index_trace[:]
             idents.clear()
             mgr1.free(KVCacheRequest("r"))                       # (inference() has already dropped the layers: free_cache_before_vae)
             del mgr1
