@@ -359,7 +359,7 @@ def config1_gpu(model, gen, device):
             "ms": round(ms, 2), "latent_frames_per_s": round(BLOCK / ms * 1e3, 2)}
 
 
-def quant_leg(fmt, gen, clip, rounds: int = 2):
+def quant_leg(fmt, gen, clip, rounds: int = 2, pipe_args=None):
     """BASELINE config 4: the same clip with every nn.Linear the reference's exclusion dict leaves quantised as a dynamic per-token x
     per-channel 8-bit linear (fp8 e4m3 on the fp8 MFMA / int8).  Measured AFTER the headline region on the same model object, as
     FULL un-instrumented clips interleaved with bf16 clips in the same process (bf16, 8-bit, bf16, 8-bit: the clocks of a hot part
@@ -392,9 +392,14 @@ def quant_leg(fmt, gen, clip, rounds: int = 2):
             ms_q.append(timed_clip())
         t = ops.KernelTimer(names=("gemm_q8", "attn_self", "quant_per_token", "layernorm"))
         ops.set_kernel_timer(t)
+        pair_was = getattr(pipe_args, "pair_forwards", None)
+        if pipe_args is not None:
+            pipe_args.pair_forwards = False          # per-launch events: one forward at a time (see the headline's instrumented clips)
         clip()
         torch.cuda.synchronize()
         ops.set_kernel_timer(None)
+        if pipe_args is not None:
+            pipe_args.pair_forwards = pair_was
         ks = t.summary()
         gq, qa = ks["gemm_q8"], ks.get("quant_per_token", dict(ms=0.0, launches=0, bytes=0.0))
         tf = gq["flops"] / (gq["ms"] * 1e-3) / 1e12
@@ -446,25 +451,34 @@ def causvid_720p_leg(model, device):
     pipe.rollover(["prompt 0"], [noises[0][:, :BLOCK]], kvm, overlap_frames=BLOCK)          # warm: one block
     pipe.is_kv_cache_initialized = False
     kvm = KVCacheManager(device)
-    t = ops.KernelTimer(names=("attn_self",))
-    ops.set_kernel_timer(t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = pipe.rollover(list(table), noises, kvm, overlap_frames=BLOCK)
+    outs = pipe.rollover(list(table), noises, kvm, overlap_frames=BLOCK)          # un-instrumented, the pipeline's default pairing
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
-    ops.set_kernel_timer(None)
     assert all(torch.isfinite(o.float()).all() for o in outs)
+    # the roofline figure: ONE more segment with HIP events around every self-attention launch, forwards one at a time (a launch timed
+    # while a second chain runs beside it would be charged that chain's share of the chip)
+    pipe.is_kv_cache_initialized = False
+    args.pair_forwards = False
+    kvm = KVCacheManager(device)
+    t = ops.KernelTimer(names=("attn_self",))
+    ops.set_kernel_timer(t)
+    pipe.rollover(["prompt 0"], [noises[0]], kvm, overlap_frames=BLOCK)
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    args.pair_forwards = None
     ks = t.summary()["attn_self"]
     tf = ks["flops"] / (ks["ms"] * 1e-3) / 1e12
     new_frames = FRAMES + 2 * (FRAMES - BLOCK)                # segments 1, 2 regenerate nothing of their 3 prefilled frames
     fwd = 7 * 4 + 2 * (1 + 6 * 4)
+    paired = bool(pipe._pairing())
     del pipe, kvm
     torch.cuda.empty_cache()
     return {"workload": "config 3: CausVid 720p (latent 90x160, block 10800 tokens, steps [1000, 757, 522], shift 8.0), 3 segments x 21 "
                         "latent frames with per-segment request rollover (3 overlap latents prefilled), 30 layers, NO decode",
             "ms_total": round(ms, 1), "ms_per_segment": round(ms / 3, 1), "generator_forwards": fwd,
-            "new_latent_frames": new_frames, "latent_frames_per_s": round(new_frames / ms * 1e3, 3),
+            "new_latent_frames": new_frames, "latent_frames_per_s": round(new_frames / ms * 1e3, 3), "pair_forwards": paired,
             "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (self-attention launches, N = 10800, L = 10800 .. 75600)", "bound": "mfma",
                          "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                          "traffic": None, "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / ks["launches"], 4)}}
@@ -839,8 +853,8 @@ def main():
         if world == 1 and not a.no_decode_leg and a.emulate_sp <= 1:
             res["text_encoder"] = text_encoder_leg()
         if world == 1 and not a.no_config_legs and a.emulate_sp <= 1 and a.quant == "none" and not a.layers:
-            res["quant_fp8"] = quant_leg("fp8", gen, clip)
-            res["quant_int8"] = quant_leg("int8", gen, clip)
+            res["quant_fp8"] = quant_leg("fp8", gen, clip, pipe_args=pipe.args)
+            res["quant_int8"] = quant_leg("int8", gen, clip, pipe_args=pipe.args)
             kvm.free(reqs[0])
             torch.cuda.empty_cache()
             res["causvid_720p"] = causvid_720p_leg(model, device)

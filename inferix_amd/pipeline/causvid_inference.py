@@ -71,12 +71,37 @@ class CausVidInferencePipeline(torch.nn.Module):
         self.is_kv_cache_initialized = False
 
     # ---- one segment ------------------------------------------------------------------------------
-    def _gen(self, x, cond, timestep, block_index, kvm, reqs):
+    def _gen_kw(self, x, cond, timestep, block_index, kvm, reqs) -> dict:
         n = self.num_frame_per_block * self.frame_seq_length
-        return self.generator(noisy_image_or_video=x, conditional_dict=cond, timestep=timestep,
-                              current_start=block_index * n, current_end=(block_index + 1) * n,
-                              kv_start=block_index * n, kv_end=(block_index + 1) * n, kv_cache_manager=kvm,
-                              kv_cache_requests=reqs)
+        return dict(noisy_image_or_video=x, conditional_dict=cond, timestep=timestep,
+                    current_start=block_index * n, current_end=(block_index + 1) * n,
+                    kv_start=block_index * n, kv_end=(block_index + 1) * n, kv_cache_manager=kvm, kv_cache_requests=reqs)
+
+    def _gen(self, x, cond, timestep, block_index, kvm, reqs):
+        return self.generator(**self._gen_kw(x, cond, timestep, block_index, kvm, reqs))
+
+    def _pairing(self) -> bool:
+        """As CausalInferencePipeline._pairing: the clean-context re-run of a block is enqueued layer-interleaved with the next block's
+        first denoising step (`generator.forward_pair`; bit-identical results).  `args.pair_forwards` / env IFX_PAIR_FORWARDS; on by default."""
+        import os
+        if not hasattr(self.generator, "forward_pair"):
+            return False
+        want = getattr(self.args, "pair_forwards", None) if getattr(self, "args", None) is not None else None
+        if want is None and os.environ.get("IFX_PAIR_FORWARDS", "") != "":
+            want = os.environ["IFX_PAIR_FORWARDS"] not in ("0", "false", "off")
+        return True if want is None else bool(want)
+
+    def _timestep(self, value, shape, device, dtype=torch.int64) -> torch.Tensor:
+        """`torch.ones(shape) * value`, one tensor per (value, shape) reused across blocks (the model memoises its modulation tables
+        and the sigma lookups on the timestep tensor's identity; see CausalInferencePipeline._timestep).  Never written in place."""
+        cache = self.__dict__.setdefault("_ts_cache", {})
+        key = (float(value), tuple(shape), str(device), dtype)
+        t = cache.get(key)
+        if t is None:
+            if len(cache) >= 32:
+                cache.clear()
+            t = cache[key] = torch.ones(list(shape), device=device, dtype=dtype) * value
+        return t
 
     def inference(self, noise: torch.Tensor, text_prompts: List[str], start_latents: Optional[torch.Tensor],
                   return_latents: bool = True, kv_cache_manager: Optional[KVCacheManager] = None,
@@ -98,6 +123,8 @@ class CausVidInferencePipeline(torch.nn.Module):
         # uninitialised cross cache.  Here a new segment always recomputes them.
         self._reset_crossattn_cache()
         n_in = start_latents.shape[1] // nfb if start_latents is not None else 0
+        pair = self._pairing()
+        pending = None                   # the previous block's clean-context re-run, deferred into this block's first step
         for blk in range(T // nfb):
             sl = slice(blk * nfb, (blk + 1) * nfb)
             if blk < n_in:
@@ -110,17 +137,25 @@ class CausVidInferencePipeline(torch.nn.Module):
             x0 = timestep = None
             nsteps = len(self.denoising_step_list)
             for index, tcur in enumerate(self.denoising_step_list):
-                timestep = torch.ones([B, nfb], device=dev, dtype=torch.int64) * tcur
-                x0 = self._gen(x, cond, timestep, blk, kv_cache_manager, kv_cache_requests)
+                timestep = self._timestep(tcur, (B, nfb), dev)
+                if pending is not None:
+                    _, x0 = self.generator.forward_pair(pending, self._gen_kw(x, cond, timestep, blk, kv_cache_manager, kv_cache_requests))
+                    pending = None
+                else:
+                    x0 = self._gen(x, cond, timestep, blk, kv_cache_manager, kv_cache_requests)
                 if index < nsteps - 1:
                     flat = x0.flatten(0, 1)
                     eps = renoise.pop(0).to(flat.device, flat.dtype) if renoise is not None else torch.randn_like(flat)
-                    tn = self.denoising_step_list[index + 1] * torch.ones([B], device=dev, dtype=torch.long)
+                    tn = self._timestep(self.denoising_step_list[index + 1], (B,), dev, torch.long)
                     x = self.scheduler.add_noise(flat, eps, tn).view(x0.shape)
             if x0 is None:
                 raise RuntimeError(f"no denoising step ran for block {blk}")
             output[:, sl] = x0
-            self._gen(x0, cond, timestep * 0, blk, kv_cache_manager, kv_cache_requests)
+            t0 = self._timestep(0, tuple(timestep.shape), dev, timestep.dtype)          # `timestep * 0`
+            if pair and blk + 1 < T // nfb:
+                pending = self._gen_kw(x0, cond, t0, blk, kv_cache_manager, kv_cache_requests)
+            else:
+                self._gen(x0, cond, t0, blk, kv_cache_manager, kv_cache_requests)
         if not decode or self.vae is None:
             return (output, output) if return_latents else output
         chunk = vae_chunk_size if vae_chunk_size is not None else 2

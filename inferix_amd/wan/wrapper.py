@@ -99,11 +99,13 @@ class HipWanDiffusionWrapper(torch.nn.Module):
         the clean-context re-run of one block and the first denoising step of the next, which depend on each other only through the
         cache, layer by layer.  Returns `((flow, x0), (flow, x0))`, bit-identical to the two calls made one after the other."""
         def model_kw(kw):
-            if kw.get("kv_cache_meta") is None or kw.get("classify_mode") or kw.get("clean_x") is not None:
+            explicit = kw.get("kv_start") is not None and kw.get("kv_end") is not None        # the CausVid call names its slots
+            if (kw.get("kv_cache_meta") is None and not explicit) or kw.get("classify_mode") or kw.get("clean_x") is not None:
                 raise NotImplementedError("HipWanDiffusionWrapper implements the KV-cached inference call only")
             return dict(x=kw["noisy_image_or_video"].permute(0, 2, 1, 3, 4), t=kw["timestep"],
-                        context=kw["conditional_dict"]["prompt_embeds"], kv_cache_meta=kw["kv_cache_meta"],
-                        crossattn_cache_meta=kw["crossattn_cache_meta"], current_start=kw["current_start"],
+                        context=kw["conditional_dict"]["prompt_embeds"], kv_cache_meta=kw.get("kv_cache_meta"),
+                        crossattn_cache_meta=kw.get("crossattn_cache_meta"), current_start=kw["current_start"],
+                        kv_start=kw.get("kv_start"), kv_end=kw.get("kv_end"),
                         kv_cache_manager=kw["kv_cache_manager"], kv_cache_requests=kw["kv_cache_requests"])
         flows = self.model.forward_pair(model_kw(first), model_kw(second))
         out = []
@@ -133,3 +135,10 @@ class HipCausVidDiffusionWrapper(HipWanDiffusionWrapper):
                           ).permute(0, 2, 1, 3, 4)
         return self._convert_flow_pred_to_x0(flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1).to(flow.device),
                                              timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])
+
+    @torch.no_grad()
+    def forward_pair(self, first: dict, second: dict):
+        """The CausVid form of HipWanDiffusionWrapper.forward_pair: two calls' keyword arguments (each names its own cache slots),
+        `(pred_x0, pred_x0)` back — bit-identical to the two calls one after the other."""
+        (_, xa), (_, xb) = super().forward_pair(first, second)
+        return xa, xb

@@ -626,6 +626,53 @@ def lib_ws(ops, M, N, K):
     return int(_hip.load().ifx_gemm_workspace_bytes(M, N, K))
 
 
+def test_gemm_ping_pong_multi_part_split(ops):
+    """Round 5: K split over 2 / 4 / 8 workgroups per tile on the 128-token ping-pong tile (gemm_variant 27 / 28 / 29): parts 1 .. ks-1 dump
+    fp32 tile images and raise their own flags, part 0 adds them in part order.  Against F.linear in fp32 for every epilogue, the same bits
+    run to run (whoever finishes last), flags left zero; and the auto choice of a 4-way sequence-parallel rank (gemm_small_split) takes
+    the 4-way form for its FFN down-projection — the same bits as variant 28."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(95)
+    fs = 390
+    for (M, N, K, variants) in ((1170, 1536, 8960, (27, 28)), (585, 1536, 1536, (27, 28, 29)), (300, 512, 1024, (27, 28, 29))):
+        x, w, b = rnd(g, M, K), rnd(g, N, K, scale=K ** -0.5), rnd(g, N, scale=0.1)
+        res, mod = rnd(g, M, N), rnd(g, 3, 6, N, scale=0.5)
+        y = torch.nn.functional.linear(x.float(), w.float(), b.float()).to(BF)
+        gate = torch.repeat_interleave(mod[:, 2], fs, dim=0)[:M]
+        for v in variants:
+            ops.set_option("gemm_variant", v)
+            try:
+                assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) > 0
+                got = ops.linear(gpu(x), gpu(w), gpu(b))
+                assert_bf16_parity(got, y, max_mismatch_frac=0.03, what=f"variant {v} {M}x{N}x{K} bias")
+                again = [ops.linear(gpu(x), gpu(w), gpu(b)) for _ in range(3)]
+                assert all(torch.equal(a, got) for a in again), f"variant {v}: the result depends on which part finishes last"
+                got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_GELU_TANH)
+                assert_bf16_parity(got, torch.nn.functional.gelu(y, approximate="tanh"), max_ulp=2, floor=1.0, max_mismatch_frac=0.03,
+                                   what=f"variant {v} gelu")
+                got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_RESIDUAL, residual=gpu(res))
+                assert_bf16_parity(got, res + y, max_ulp=2, floor=1.0, max_mismatch_frac=0.03, what=f"variant {v} residual")
+                got = ops.linear(gpu(x), gpu(w), gpu(b), epilogue=_hip.IFX_EPI_GATE_RES, residual=gpu(res), mod=gpu(mod), gate_slot=2,
+                                 rows_per_group=fs)
+                assert_bf16_parity(got, res + (y * gate).to(BF), max_ulp=2, floor=1.0, max_mismatch_frac=0.03, what=f"variant {v} gate+residual")
+            finally:
+                ops.set_option("gemm_variant", 0)
+    torch.cuda.synchronize()
+    for ws in ops._GEMM_WS.values():
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, "per-part flags must be left zero"
+    M, N, K = 1170, 1536, 8960
+    x, w, b, res = gpu(rnd(g, M, K)), gpu(rnd(g, N, K, scale=K ** -0.5)), gpu(rnd(g, N, scale=0.1)), gpu(rnd(g, M, N))
+    ops.set_option("gemm_variant", 28)
+    try:
+        forced = ops.linear(x, w, b, epilogue=_hip.IFX_EPI_RESIDUAL, residual=res)
+    finally:
+        ops.set_option("gemm_variant", 0)
+    with ops.option_scope("gemm_small_split", 1):
+        assert _hip.load().ifx_gemm_workspace_bytes(M, N, K) > 0 and _hip.load().ifx_gemm_workspace_bytes(585, N, K) == 0
+        auto = ops.linear(x, w, b, epilogue=_hip.IFX_EPI_RESIDUAL, residual=res)
+    assert torch.equal(auto, forced), "a 4-way rank's FFN down-projection must run the 4-way split of the 128-token tile"
+
+
 def test_split_k_consumer_wait_is_bounded_and_reported(ops):
     """Round-4 verdict item 7 / ADVICE r3: the split-K consumer of the ping-pong GEMM waits for its partner's flag with a BUDGET.  With the
     lab switch `spin_fault` the producers keep their flags down: the launch must still END (within the budget, not hang the GPU), raise

@@ -264,7 +264,11 @@ def test_attention_varlen_arguments():
         attention(q.cuda(), k.cuda(), v.cuda(), k_lens=torch.tensor([1, 2]))
 
 
-def test_causvid_rollover_vs_reference_golden():
+_CAUSVID_SEQ: dict = {}        # segment -> latents of the sequential run (pair=False runs first): the paired run must reproduce them
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_causvid_rollover_vs_reference_golden(pair):
     """CausVid (BASELINE config 3 mechanics): explicit slot addressing, dropped last step, start_latents prefill and
     the per-segment request swap, against latents/caches generated by the reference's own CausVid pipeline."""
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
@@ -274,8 +278,10 @@ def test_causvid_rollover_vs_reference_golden():
     cfg = O.tiny_config(text_len=512)
     m = build(cfg, O.init_weights(cfg, seed=0))
     gen = HipCausVidDiffusionWrapper(model=m, timestep_shift=8.0)
+    # `pair`: the clean-context re-run of a block enqueued layer-interleaved with the next block's first step (forward_pair, which does
+    # not pass through gen.forward): the slot schedule is then read from the model's own record of layer 0
     args = SimpleNamespace(denoising_step_list=fx["steps"].tolist(), warp_denoising_step=True, num_frame_per_block=3,
-                           frame_seq_length=cfg.frame_seqlen, kv_cache_tokens=600)
+                           frame_seq_length=cfg.frame_seqlen, kv_cache_tokens=600, pair_forwards=pair)
     pe = fx["prompt_embeds"].cuda()
     pipe = CausVidInferencePipeline(args, device="cuda", generator=gen,
                                     text_encoder=lambda text_prompts: {"prompt_embeds": pe}, vae=None)
@@ -293,10 +299,20 @@ def test_causvid_rollover_vs_reference_golden():
     for seg in range(2):
         req = [KVCacheRequest(f"seg{seg}")]
         slots.clear()
+        m.index_trace = []
         lat = pipe.inference(fx[f"seg{seg}_noise"].cuda(), ["x"], start, return_latents=False, kv_cache_manager=kvm,
                              kv_cache_requests=req, decode=False, renoise=renoise[seg])
         torch.cuda.synchronize()
-        assert slots == fx[f"seg{seg}_slots"].tolist(), "cache slot schedule differs from the reference"
+        if pair:
+            assert pipe._pairing() and len(slots) < len(fx[f"seg{seg}_slots"]), "the paired calls must not pass through gen.forward"
+            got_slots = [[le - (ge - cs), le] for cs, ge, le in m.index_trace]      # explicit slots: (start, end, end) per forward
+            assert [s_[1] for s_ in got_slots] == [s_[1] for s_ in fx[f"seg{seg}_slots"].tolist()], "slot schedule differs"
+        else:
+            assert slots == fx[f"seg{seg}_slots"].tolist(), "cache slot schedule differs from the reference"
+        if pair:
+            assert torch.equal(lat, _CAUSVID_SEQ[seg]), "paired forwards changed the CausVid latents"
+        else:
+            _CAUSVID_SEQ[seg] = lat.clone()
         n = fx[f"seg{seg}_cache_k"].shape[0]
         raw = kvm.get_raw(req[0], "layer_0")
         # floor rule (round-3 verdict: no fixed 1e-2): the reference's own distance from the exact-attention evaluation of the
