@@ -233,6 +233,8 @@ typedef struct {
                             points called with scale = ln 2 the attention is the same function of the unrounded q — q·k·scale —
                             and the self-attention kernel takes its exponent fast path (scores are exp2 arguments; no scale-FMA
                             per score).  K / V and the cache are untouched. */
+  int32_t flags;         /* ABI 0.6, ifx_rmsnorm_rope_kv_append only: bit 0 = the V rows of this block are ALREADY in their cache slots
+                            (written by the projection, ifx_epilogue.y2): normalise / rotate / store q and K only */
 } ifx_rope_grid;
 
 int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t qkv_row_stride, ifx_bf16* q_out,
@@ -283,6 +285,14 @@ typedef struct {
   int32_t mod_slots;
   int32_t gate_slot;
   int32_t rows_per_group;
+  /* ABI 0.6 — second destination (zero-initialised = off): output columns [split_col, N) go to y2 [M, N - split_col] (row stride
+   * ldy2, 16-byte aligned, ldy2 % 8 == 0) instead of y.  The block's fused q|k|v projection writes its V columns straight into the
+   * rows of the KV cache that way (a contiguous cache: y2 = v + local_start * dim) and ifx_rmsnorm_rope_kv_append is told not to copy
+   * them (ifx_rope_grid.flags).  split_col must be a multiple of 256; served by the persistent ping-pong tiles only (launches of
+   * >= 2048 rows, bf16, IFX_EPI_BIAS): any other launch with y2 set returns IFX_EINVAL rather than dropping the columns. */
+  ifx_bf16* y2;
+  int32_t ldy2;
+  int32_t split_col;
 } ifx_epilogue;
 int ifx_gemm_bf16(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, const ifx_bf16* bias,
                   ifx_bf16* y, int32_t ldy, int32_t M, int32_t N, int32_t K,

@@ -41,7 +41,7 @@ class RopeGrid(C.Structure):
     """ifx_rope_grid"""
     _fields_ = [("freqs", C.c_void_p), ("max_pos", C.c_int32), ("start_frame", C.c_int32),
                 ("height", C.c_int32), ("width", C.c_int32), ("hw_offset", C.c_int32),
-                ("hw_local", C.c_int32), ("q_scale", C.c_float)]
+                ("hw_local", C.c_int32), ("q_scale", C.c_float), ("flags", C.c_int32)]
 
 
 class Conv3dDesc(C.Structure):
@@ -57,7 +57,7 @@ class Epilogue(C.Structure):
     """ifx_epilogue"""
     _fields_ = [("epilogue", C.c_int32), ("residual", C.c_void_p), ("ld_res", C.c_int32),
                 ("mod", C.c_void_p), ("mod_slots", C.c_int32), ("gate_slot", C.c_int32),
-                ("rows_per_group", C.c_int32)]
+                ("rows_per_group", C.c_int32), ("y2", C.c_void_p), ("ldy2", C.c_int32), ("split_col", C.c_int32)]
 
 
 class MagiHeadPrepDesc(C.Structure):

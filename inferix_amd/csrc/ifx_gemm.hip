@@ -187,7 +187,7 @@ int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, un
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa = nullptr,
                    const float* q8_sw = nullptr, const float* q8_qdiv = nullptr, int q8_via_bf16 = 0, int stream_k = 0, int q8_int8 = 0,
-                   int force_ks = 0);
+                   int force_ks = 0, unsigned short* y2 = nullptr, int ldy2 = 0, int split_col = 0);
 size_t gemm_pp_small_workspace_bytes(int M, int N, int ks);
 size_t gemm_pp_stream_k_workspace_bytes();
 bool gemm_pp_split(int N, int K);
@@ -382,6 +382,16 @@ static int gemm_bf16_impl(const ifx_bf16* x, int32_t ldx, const ifx_bf16* w, con
     if (fits)
       return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot,
                             ea.rows_per_group, (hipStream_t)stream, 2, workspace, nullptr, nullptr, nullptr, 0, 1);
+  }
+  // second destination (ifx_epilogue.y2: the q|k|v projection storing its V columns straight into the KV cache): the ping-pong tiles
+  // carry it; every other tile would drop the columns, so a launch that cannot take that path is an error, never a silent fallback
+  if (epi != nullptr && epi->y2 != nullptr) {
+    IFX_REQUIRE(mode == IFX_EPI_BIAS && wide_ok && N % 64 == 0 && !((uintptr_t)bias & 7) && (variant == 0 || (variant >= 22 && variant <= 25)),
+                "ifx_gemm_bf16: the second destination (y2) needs the bias epilogue, N %% 64 == 0, 8-byte aligned bias and the ping-pong tiles");
+    int tj = variant == 0 ? pick_pp(M, N, K, mode, false) : (variant == 22 || variant == 25 ? 4 : variant == 23 ? 3 : 2);
+    if (tj == 0) tj = 2;
+    return launch_gemm_pp(x, ldx, w, y, ldy, M, N, K, mode, ea.bias, nullptr, 0, nullptr, 1, 0, 1, (hipStream_t)stream, tj, nullptr, nullptr,
+                          nullptr, nullptr, 0, 0, 0, 0, epi->y2, epi->ldy2, epi->split_col);
   }
   // lab (gemm_variant 27 / 28 / 29): the 128-token ping-pong tile with K split over 2 / 4 / 8 workgroups per tile, whatever the shape
   if (wide_ok && variant >= 27 && variant <= 29) {

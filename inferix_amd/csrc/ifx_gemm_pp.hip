@@ -52,6 +52,9 @@ struct EpiArgsP {
   const float* sw = nullptr;
   const float* qdiv = nullptr;
   int q_via_bf16 = 0;
+  // second destination (ifx_epilogue.y2): column tiles from split_col on are stored to y2 (row stride ldy2) at column n - split_col
+  unsigned short* y2 = nullptr;
+  int ldy2 = 0, split_col = 0;
 };
 
 namespace gpp {
@@ -458,7 +461,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     }
     unsigned char* const wr = tw + l31 * 128 + hi * 8;
     const unsigned char* const rd = tw + rr * 128;
-    unsigned short* const yrow = y + (size_t)(e_m0 + rr) * ldy + e_n0 + cc * 8;
+    // (wave-uniform: a wave's 64 channels lie on one side of split_col, a multiple of 256)
+    const bool to_y2 = ea.y2 != nullptr && e_n0 >= ea.split_col;
+    const int ldo = to_y2 ? ea.ldy2 : ldy;
+    unsigned short* const yrow = (to_y2 ? ea.y2 - ea.split_col : y) + (size_t)(e_m0 + rr) * ldo + e_n0 + cc * 8;
     // Every loaded register is TOUCHED (an empty asm that reads it) on every path: hipcc waits for a load where its value is used, and a
     // use that it sinks into a branch (the masked store of a ragged tile) leaves the load "maybe pending" at the loop back-edge — it then
     // protects the registers with vmcnt(3 .. 0) in the middle of the NEXT K-step's fragment reads, which drains the whole DMA queue
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
             continue;
           }
         }
-        if (m < M && n_ok) *reinterpret_cast<u16x8*>(yrow + (size_t)(j * 32 + p * 8) * ldy) = o;
+        if (m < M && n_ok) *reinterpret_cast<u16x8*>(yrow + (size_t)(j * 32 + p * 8) * ldo) = o;
       }
       // (no wait here: the LDS operations of one wave execute in order, the next block's writes cannot overtake these reads)
     }
@@ -836,10 +842,15 @@ size_t gemm_pp_small_workspace_bytes(int M, int N, int ks) {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8, int force_ks) {
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8, int force_ks,
+                   unsigned short* y2, int ldy2, int split_col) {
   using namespace gpp;
   const bool q8 = q8_sa != nullptr;                  // e4m3 operands: x / w point at bytes, ldx and K count elements = bytes
-  EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, q8_sa, q8_sw, q8_qdiv, q8_via_bf16};
+  EpiArgsP ea{bias, residual, ld_res, mod, mod_slots, gate_slot, rows_per_group, q8_sa, q8_sw, q8_qdiv, q8_via_bf16, y2, ldy2, split_col};
+  if (y2 != nullptr && (q8 || split_col <= 0 || split_col % BN != 0 || split_col >= N || ldy2 % 8 != 0 || ((uintptr_t)y2 & 15))) {
+    set_error("ifx_gemm_bf16: the second destination needs bf16 operands, 0 < split_col < N a multiple of %d, ldy2 %% 8 == 0 and a 16-byte aligned y2", BN);
+    return IFX_EINVAL;
+  }
   if (q8 && (K % 128 != 0 || ldx % 16 != 0 || ((uintptr_t)q8_sw & 15) || ((uintptr_t)q8_qdiv & 15))) {
     set_error("ifx_gemm_q8: the ping-pong tile needs K %% 128 == 0, ldx %% 16 == 0 and 16-byte aligned scale vectors (K = %d, ldx = %d)", K, ldx);
     return IFX_EINVAL;

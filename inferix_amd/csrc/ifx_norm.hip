@@ -324,16 +324,17 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_append_kernel(
   // pairs above: 15 + 4 loads in flight per lane.  The kernel is a chain load -> wave reduction -> store per row; with the loads
   // inside per-chunk `if (col < dim)` blocks hipcc waited for each one before issuing the next (round 4, 23.4 us per 4680-row launch).
   const bool has_kv = kc != nullptr;               // wave-uniform
+  const bool copy_v = vc != nullptr;               // wave-uniform: nullptr = the projection wrote the V rows into the cache itself
   u16x8 qraw[NCH], kraw[NCH], vraw[NCH], wqv[NCH], wkv[NCH];
   load_chunks<NCH>(qraw, base, dim, lane);
   load_chunks<NCH>(wqv, wq, dim, lane);
   if (has_kv) {
     load_chunks<NCH>(kraw, base + dim, dim, lane);
-    load_chunks<NCH>(vraw, base + 2 * dim, dim, lane);
+    if (copy_v) load_chunks<NCH>(vraw, base + 2 * dim, dim, lane);
     load_chunks<NCH>(wkv, wk, dim, lane);
   }
   // ---- v (raw copy into the cache slot): out first, nothing depends on it ----
-  if (has_kv) {
+  if (has_kv && copy_v) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
@@ -548,6 +549,10 @@ extern "C" int ifx_rmsnorm_rope_kv_append(const ifx_bf16* qkv, int32_t ld, ifx_b
                   rope->width, rope->hw_offset, rope->hw_local};
     IFX_REQUIRE(rope->q_scale >= 0.f && rope->q_scale == rope->q_scale, "ifx_rmsnorm_rope_kv_append: q_scale must be >= 0 (0 = 1)");
     ra.q_scale = rope->q_scale > 0.f ? rope->q_scale : 1.0f;
+    if (rope->flags & 1) {            // the V rows are in their slots already (ifx_epilogue.y2): q and K only
+      IFX_REQUIRE(kv != nullptr, "ifx_rmsnorm_rope_kv_append: flags bit 0 (V in place) needs a cache view");
+      vc = nullptr;
+    }
   }
   if (rows == 0) return IFX_OK;
   return dispatch_nch(dim, [&](auto nch) {

@@ -604,7 +604,8 @@ namespace ifx {
 int launch_gemm_pp(const unsigned short* x, int ldx, const unsigned short* w, unsigned short* y, int ldy, int M, int N, int K,
                    int mode, const unsigned short* bias, const unsigned short* residual, int ld_res, const unsigned short* mod,
                    int mod_slots, int gate_slot, int rows_per_group, hipStream_t s, int tj, void* workspace, const float* q8_sa,
-                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8, int force_ks);
+                   const float* q8_sw, const float* q8_qdiv, int q8_via_bf16, int stream_k, int q8_int8, int force_ks,
+                   unsigned short* y2, int ldy2, int split_col);
 bool gemm_pp_split(int N, int K);
 size_t gemm_pp_workspace_bytes(int M, int N, int K);
 }
@@ -669,6 +670,7 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
     ea.gate_slot = epi->gate_slot;
     ea.rows_per_group = epi->rows_per_group;
   }
+  IFX_REQUIRE(epi == nullptr || epi->y2 == nullptr, "ifx_gemm_q8: the second destination (ifx_epilogue.y2) is built for the bf16 launches only");
   if (M == 0) return IFX_OK;
   hipStream_t s = (hipStream_t)stream;
   const unsigned char* xp = (const unsigned char*)xq;
@@ -689,7 +691,7 @@ static int gemm_q8_impl(const void* xq, int32_t ldx, const float* x_scale, const
     if (tj != 0 && aligned)
       return launch_gemm_pp((const unsigned short*)xp, ldx, (const unsigned short*)wp, y, ldy, M, N, K,
                             mode, ea.bias, ea.residual, ea.ld_res, ea.mod, ea.mod_slots, ea.gate_slot, ea.rows_per_group, s, tj,
-                            split_ok && tj == 4 ? workspace : nullptr, x_scale, w_scale, qdiv, q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0, 0);
+                            split_ok && tj == 4 ? workspace : nullptr, x_scale, w_scale, qdiv, q_via_bf16, 0, format == IFX_Q_INT8 ? 1 : 0, 0, nullptr, 0, 0);
   }
   if (wide_ok && gemm_variant() != 1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };

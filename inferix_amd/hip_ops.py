@@ -242,14 +242,18 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Te
 
 def rmsnorm_rope_kv_append(qkv: torch.Tensor, wq: torch.Tensor, wk: Optional[torch.Tensor], eps: float,
                            rope: Optional[RopeGridSpec], kv: Optional[KvCacheView], local_start: int,
-                           dim: int, q_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q_out = RoPE(RMSNorm(q)*wq); cache[local_start + r] <- (RoPE(RMSNorm(k)*wk), v)."""
+                           dim: int, q_out: Optional[torch.Tensor] = None, v_in_place: bool = False) -> torch.Tensor:
+    """q_out = RoPE(RMSNorm(q)*wq); cache[local_start + r] <- (RoPE(RMSNorm(k)*wk), v).  `v_in_place`: the projection has already
+    written the V rows into their cache slots (`linear(..., out2=)`): q and K only (the V columns of `qkv` are not read)."""
     lib = _hip.load()
     rows, _, ld = _rows2d(qkv, "qkv")
     q_out = torch.empty(rows, dim, dtype=BF16, device=qkv.device) if q_out is None else q_out
     rs = rope.struct() if rope is not None else None
+    if v_in_place:
+        assert rs is not None and kv is not None, "v_in_place needs a rope grid (it carries the flag) and a cache view"
+        rs.flags = 1
     ks = kv.struct() if kv is not None else None
-    nb = 2.0 * rows * dim * (6 if kv is not None else 2)      # read q,k,v + write q,K,V  |  read q + write q
+    nb = 2.0 * rows * dim * ((4 if v_in_place else 6) if kv is not None else 2)      # read q,k,v + write q,K,V  |  read q + write q
     with _timed("rmsnorm_rope_append", 0.0, nb):
         _hip.check(lib.ifx_rmsnorm_rope_kv_append(
             _dev(qkv, "qkv"), ld, _dev(q_out, "q_out"), _dev(wq, "wq"), _dev(wk, "wk") if wk is not None else None,
@@ -497,8 +501,10 @@ def lse_merge(out_a: torch.Tensor, lse_a: torch.Tensor, out_b: torch.Tensor, lse
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = _hip.IFX_EPI_BIAS,
            residual: Optional[torch.Tensor] = None, mod: Optional[torch.Tensor] = None, gate_slot: int = 0,
-           rows_per_group: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = epilogue(x @ w.T + bias) on MFMA (ifx_gemm_bf16). x `[..., K]`, w `[N, K]`."""
+           rows_per_group: int = 1, out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+           split_col: int = 0) -> torch.Tensor:
+    """y = epilogue(x @ w.T + bias) on MFMA (ifx_gemm_bf16). x `[..., K]`, w `[N, K]`.  `out2` `[M, N - split_col]` (ifx_epilogue.y2):
+    the output columns from `split_col` on go THERE instead of `out` — the q|k|v projection storing V straight into the cache rows."""
     lib = _hip.load()
     M, K, ldx = _rows2d(x, "x")
     N = w.shape[0]
@@ -514,8 +520,12 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
         assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
+    if out2 is not None:
+        r2, c2, ld2 = _rows2d(out2, "out2")
+        assert r2 == M and c2 == N - split_col and 0 < split_col < N, (out2.shape, M, N, split_col)
+        epi.y2, epi.ldy2, epi.split_col = _dev(out2, "out2"), ld2, int(split_col)
     wkey = (M, N, K, _OPTIONS.get("gemm_small_split", 0))
-    need = _GEMM_WS_NEED.get(wkey)
+    need = _GEMM_WS_NEED.get(wkey) if out2 is None else 0          # the two-destination launch takes no workspace (bias epilogue, unsplit)
     if need is None:
         need = _GEMM_WS_NEED[wkey] = int(lib.ifx_gemm_workspace_bytes(M, N, K))
     with _timed("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))):   # x + W + y (+ the residual rows)

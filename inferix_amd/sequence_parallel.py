@@ -366,6 +366,11 @@ class PeerStoreExchange:
             self.flags.free()
 
 
+def _lab_single_attention() -> bool:
+    import os
+    return os.environ.get("IFX_SP_SINGLE_ATTN", "") == "1"
+
+
 def _split_div():
     import os
     v = os.environ.get("IFX_SP_SPLIT_DIV", "")
@@ -482,7 +487,15 @@ class HipSequenceParallel:
             if self.peer is not None:
                 self.peer.wait_done(st["layer"], st["epoch"])
 
-        if st["side"] and st["have_prefix"]:
+        if st["side"] and st["have_prefix"] and _lab_single_attention():
+            # LAB ONLY (IFX_SP_SINGLE_ATTN=1; wrong ordering on real peers): ONE split launch over the prefix and the new block without
+            # waiting for the exchange — what a launch that waits for the peers' rows in-kernel could save at best
+            s = ops.attention_split_plan(n_local, H, step.local_end)
+            ws = ops.attention_workspace(qv, s)
+            u = ops.attention_partial(qv, view, step.local_end, 0, s, ws, 0, s, scale=scale, tag="attn_self")
+            ops.attention_merge(ws, s, u, av)
+            arrived()
+        elif st["side"] and st["have_prefix"]:
             s1 = ops.attention_split_plan(n_local, H, step.local_start)
             s2 = ops.attention_split_plan(n_local, H, step.local_end - step.local_start)
             div = _split_div()

@@ -23,6 +23,7 @@ unpatchify index permutes.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -150,6 +151,7 @@ class HipCausalWanModel(torch.nn.Module):
         self.cross_dedup = True
         self._cross_dedup: Dict[str, Tuple[int, int]] = {}
         self._roll_scratch: Optional[torch.Tensor] = None
+        self.v_direct = os.environ.get("IFX_V_DIRECT", "1") != "0"   # the q|k|v projection stores V straight into the cache rows (_run_block)
         self._temb_cache: Dict[Tuple, Tuple] = {}      # timestep tensor identity -> (tensor, E, eh): see _prologue
         self.index_trace: Optional[list] = None       # tests set a list: layer 0's KV index state after every forward
         self._chain = 0                               # 0 except while forward_pair enqueues its second forward
@@ -380,33 +382,55 @@ class HipCausalWanModel(torch.nn.Module):
                 ops.rmsnorm_rope_kv_append(qraw[b * N:(b + 1) * N], w["nq"], None, self.eps, samples[b]["rope"], None, 0, d,
                                            q_out=qb[b * N:(b + 1) * N])
                 step = self.cp.finish(self, pst, qb[b * N:(b + 1) * N], ab[b * N:(b + 1) * N])
-        else:
-            self._norm_lin(w, "qkv", xact, h, dict(mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group), out=qkv)
-        for b, smp in enumerate(() if kv_first else samples):
-            req, rope_b, explicit = smp["req"], smp["rope"], smp["explicit"]
+        planned: List[Tuple[KVIndexStep, ops.KvCacheView]] = []
+        v_direct = None
+
+        def plan(smp):
+            """The slot arithmetic of one sample, its eviction shift enqueued: (step, view)."""
             name = blk.kv_cache_manager.self_name
-            view = self._kv_view(kv_cache_manager, req, name)
+            view = self._kv_view(kv_cache_manager, smp["req"], name)
             ge, le = index_state(smp)
+            if smp["explicit"] is not None:
+                step = KVIndexStep(smp["explicit"][0], smp["explicit"][1], smp["explicit"][1], 0, 0, 0)
+            else:
+                step = kv_index_update(ge, le, smp["current_start"], N, view.k.shape[0], self.local_attn_size, sink_tokens)
+            if step.local_start < 0 or step.local_end > view.k.shape[0]:
+                raise _hip.HipKernelError(f"KV cache overflow: slots [{step.local_start}, {step.local_end}) of "
+                                          f"{view.k.shape[0]} (layer {l})")
+            if step.evicted:
+                self._evict(kv_cache_manager, smp["req"], name, view, step)
+                view = self._kv_view(kv_cache_manager, smp["req"], name)
+            steps_done.append(step)
+            return step, view
+        if not kv_first and self.cp is None and not lockstep:
+            # the slot arithmetic (and the eviction shift, which must be on the stream ahead of anything that writes the cache) first:
+            # the projection below may store its V columns straight into the new block's cache rows.  (Separate requests = separate
+            # caches: the order between them does not matter.  The two forwards of a lockstep pair share ONE cache — the second one's
+            # eviction must stay behind the first one's attention — so they are planned one at a time, below.)
+            planned = [plan(smp) for smp in samples]
+            # V straight into the cache (ifx_epilogue.y2): one sample, a contiguous cache (no page table / segment map), a launch the
+            # ping-pong tiles serve, bf16 weights.  The rope / append kernel then moves q and K only: a third of its 86 MB less.
+            step0, view0 = planned[0]
+            if (self.v_direct and len(samples) == 1 and B * N >= 2048 and "qkv_q" not in w and view0.page_table is None
+                    and not view0.seg_split and d % 256 == 0):
+                v_direct = view0.v.view(view0.v.shape[0], d)[step0.local_start:step0.local_start + N]
+        if not kv_first:
+            extra = dict(out2=v_direct, split_col=2 * d) if v_direct is not None else {}
+            self._norm_lin(w, "qkv", xact, h, dict(mod=El, shift_slot=0, scale_slot=1, rows_per_group=rows_per_group), out=qkv, **extra)
+        for b, smp in enumerate(() if kv_first else samples):
+            req, rope_b = smp["req"], smp["rope"]
+            name = blk.kv_cache_manager.self_name
             if self.cp is not None:
+                view = self._kv_view(kv_cache_manager, req, name)
+                ge, le = index_state(smp)
                 step = self.cp.self_attention(self, l, b, view, qkv[b * N:(b + 1) * N], qb[b * N:(b + 1) * N],
                                               ab[b * N:(b + 1) * N], w, rope_b, smp["current_start"], ge, le,
                                               sink_tokens, kv_cache_manager, req, name)
                 steps_done.append(step)
                 continue
-            if explicit is not None:
-                step = KVIndexStep(explicit[0], explicit[1], explicit[1], 0, 0, 0)
-            else:
-                step = kv_index_update(ge, le, smp["current_start"], N, view.k.shape[0], self.local_attn_size,
-                                       sink_tokens)
-            if step.local_start < 0 or step.local_end > view.k.shape[0]:
-                raise _hip.HipKernelError(f"KV cache overflow: slots [{step.local_start}, {step.local_end}) of "
-                                          f"{view.k.shape[0]} (layer {l})")
-            if step.evicted:
-                self._evict(kv_cache_manager, req, name, view, step)
-                view = self._kv_view(kv_cache_manager, req, name)
-            steps_done.append(step)
+            step, view = planned[b] if planned else plan(smp)
             ops.rmsnorm_rope_kv_append(qkv[b * N:(b + 1) * N], w["nq"], w["nk"], self.eps, rope_b, view,
-                                       step.local_start, d, q_out=qb[b * N:(b + 1) * N])
+                                       step.local_start, d, q_out=qb[b * N:(b + 1) * N], v_in_place=v_direct is not None)
             ops.attention(qb[b * N:(b + 1) * N].view(N, H, hd), view, step.local_end, scale=st.get("attn_scale", 0.0),
                           out=ab[b * N:(b + 1) * N].view(N, H, hd), tag="attn_self")
         if not explicit_any:

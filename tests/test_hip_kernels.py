@@ -626,6 +626,45 @@ def lib_ws(ops, M, N, K):
     return int(_hip.load().ifx_gemm_workspace_bytes(M, N, K))
 
 
+def test_gemm_second_destination_and_append_without_v(ops):
+    """Round 5: the q|k|v projection stores its V columns straight into the KV cache rows (ifx_epilogue.y2 / `linear(out2=)`) and
+    ifx_rmsnorm_rope_kv_append is told not to copy V (ifx_rope_grid.flags bit 0).  The two-destination launch must give the bits of the
+    plain launch column for column (q|k in `out`, v in the cache rows, nothing else of the cache touched), the V-less append the same
+    q and K as the full one, and a launch that the ping-pong tiles cannot serve must be refused, not silently drop the columns."""
+    from inferix_amd import _hip
+    g = torch.Generator().manual_seed(97)
+    d, heads, fsz = 1536, 12, 1560
+    for M in (4680, 2496, 640):                       # 640 rows: the launcher forces the 128-token ping-pong tile
+        x, w, b = gpu(rnd(g, M, d)), gpu(rnd(g, 3 * d, d, scale=d ** -0.5)), gpu(rnd(g, 3 * d, scale=0.1))
+        plain = ops.linear(x, w, b)
+        slots, start = M + 2 * fsz, fsz
+        kc = torch.full((slots, heads, 128), 7.0, dtype=BF, device="cuda")
+        vc = torch.full((slots, heads, 128), 7.0, dtype=BF, device="cuda")
+        out = torch.full((M, 3 * d), 3.0, dtype=BF, device="cuda")
+        got = ops.linear(x, w, b, out=out, out2=vc.view(slots, d)[start:start + M], split_col=2 * d)
+        assert got.data_ptr() == out.data_ptr()
+        assert torch.equal(out[:, :2 * d], plain[:, :2 * d]), f"{M} rows: q|k columns differ from the plain launch"
+        assert torch.equal(vc.view(slots, d)[start:start + M], plain[:, 2 * d:]), f"{M} rows: V rows in the cache differ"
+        assert bool((out[:, 2 * d:] == 3.0).all()), "the V columns of `out` must not be written"
+        assert bool((vc[:start] == 7.0).all()) and bool((vc[start + M:] == 7.0).all()), "cache rows outside the block were touched"
+        # append: full (copies V from the projection) against V-less (V already in place)
+        view_a = ops.KvCacheView(torch.zeros_like(kc), torch.zeros_like(vc))
+        rope = ops.RopeGridSpec(torch.view_as_real(O.rope_freqs(128)).contiguous().cuda(), 1, 30, 52)
+        wq, wk = gpu(rnd(g, d)), gpu(rnd(g, d))
+        q_a = ops.rmsnorm_rope_kv_append(plain, wq, wk, 1e-6, rope, view_a, start, d)
+        view_b = ops.KvCacheView(kc, vc)
+        q_b = ops.rmsnorm_rope_kv_append(out, wq, wk, 1e-6, rope, view_b, start, d, v_in_place=True)
+        assert torch.equal(q_a, q_b) and torch.equal(view_a.k[start:start + M], kc[start:start + M])
+        assert torch.equal(view_a.v[start:start + M], vc[start:start + M])
+        assert bool((kc[:start] == 7.0).all()) and bool((kc[start + M:] == 7.0).all())
+    x, w, b = gpu(rnd(g, 256, d)), gpu(rnd(g, 3 * d, d, scale=d ** -0.5)), gpu(rnd(g, 3 * d, scale=0.1))
+    with pytest.raises(_hip.HipKernelError, match="second destination"):       # a residual epilogue cannot carry it
+        ops.linear(x, w, b, epilogue=_hip.IFX_EPI_RESIDUAL, residual=gpu(rnd(g, 256, 3 * d)),
+                   out2=torch.empty(256, d, dtype=BF, device="cuda"), split_col=2 * d)
+    with pytest.raises(_hip.HipKernelError, match="second destination"):       # split_col must be a multiple of 256
+        ops.linear(x, w, b, out2=torch.empty(256, d + 64, dtype=BF, device="cuda"), split_col=2 * d - 64)
+
+
 def test_gemm_ping_pong_multi_part_split(ops):
     """Round 5: K split over 2 / 4 / 8 workgroups per tile on the 128-token ping-pong tile (gemm_variant 27 / 28 / 29): parts 1 .. ks-1 dump
     fp32 tile images and raise their own flags, part 0 adds them in part order.  Against F.linear in fp32 for every epilogue, the same bits

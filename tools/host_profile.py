@@ -24,8 +24,9 @@ def main():
     pc = ParallelConfig(rank=0, world_size=P, local_rank=0) if P > 1 else None
     model, gen, pipe = bench.build_pipeline(device, pc)
     if P > 1:
-        from inferix_amd.sequence_parallel import LoopbackExchange, attach_sequence_parallel
-        attach_sequence_parallel(model, exchange=LoopbackExchange(P, 0))
+        from inferix_amd.sequence_parallel import LoopbackExchange, PeerStoreExchange, attach_sequence_parallel
+        peer = PeerStoreExchange(emulate_world=P) if os.environ.get("SP_EXCHANGE", "peer") == "peer" else None     # as bench.py --sp-exchange peer
+        attach_sequence_parallel(model, exchange=LoopbackExchange(P, 0), peer=peer)
     g = torch.Generator().manual_seed(0)
     noise = torch.randn(1, bench.FRAMES, *bench.LATENT, generator=g).to(torch.bfloat16).to(device)
     kvm, reqs = KVCacheManager(device), [KVCacheRequest("bench")]
