@@ -15,9 +15,11 @@ class TensorMemo:
         self.capacity, self.entries = capacity, {}
 
     def get(self, t: torch.Tensor, extra, make):
-        key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, extra)
+        # (a VIEW of the same storage — `timestep.flatten(0, 1)` makes a new tensor object per call — is the same values: the entry's
+        #  tensor keeps that storage alive, views share its version counter, and shape + strides are part of the key)
+        key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, extra)
         hit = self.entries.get(key)
-        if hit is not None and hit[0] is t:
+        if hit is not None:
             return hit[1]
         v = make()
         if len(self.entries) >= self.capacity:

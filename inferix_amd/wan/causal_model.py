@@ -655,9 +655,9 @@ class HipCausalWanModel(torch.nn.Module):
         # counter (bumped by any in-place write) and shape — with the tensor itself kept alive in the entry, so that no other tensor can
         # come to live at that address while the entry exists.  ~16 glue launches (sinusoid, three small GEMMs, SiLUs, the two table
         # adds) per forward less; the same bits (the pipelines reuse one timestep tensor per step value, inferix_amd/pipeline).
-        tkey = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, self.g["time0_w"].data_ptr(), self.g.get("time0_fmt"))
+        tkey = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, self.g["time0_w"].data_ptr(), self.g.get("time0_fmt"))
         hit = self._temb_cache.get(tkey)
-        if hit is not None and hit[0] is t:
+        if hit is not None:
             E, eh = hit[1], hit[2]
         else:
             emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]

@@ -499,3 +499,39 @@ def test_quantize_dynamic_resolves_names_like_the_quantised_model_oracle():
     ex = dicts[0]
     assert [n for n in names if Q.config_for(n, ex) is None] == ["text_embedding.0", "text_embedding.2", "head.head"]
     assert Q.config_for("blocks.30.ffn.0", {"": 1, "blocks.3": None}) == 1          # a prefix match stops at a module boundary
+
+
+def test_tensor_memo_hits_on_identity_and_misses_on_writes():
+    """`schedulers.TensorMemo` (the sigma lookups of `add_noise` / the flow -> x0 conversion, and the same rule in the model's
+    modulation-table memo): a value derived from a timestep tensor is reused while that tensor — or a view of it — holds the same
+    storage at the same version; an in-place write, another tensor or another `extra` recomputes; the capacity bounds the entries."""
+    import torch
+    from inferix_amd.schedulers import FlowMatchScheduler, TensorMemo
+    calls = []
+
+    def make(v):
+        def f():
+            calls.append(v)
+            return v
+        return f
+    memo = TensorMemo(capacity=2)
+    t = torch.ones(2, 3) * 757.0
+    assert memo.get(t, "a", make(1)) == 1 and memo.get(t, "a", make(2)) == 1 and calls == [1]
+    assert memo.get(t.flatten(0, 1).view(2, 3), "a", make(3)) == 1, "a view of the same storage, shape and strides is the same values"
+    assert memo.get(t.flatten(0, 1), "a", make(4)) == 4, "another shape is another key"
+    t.mul_(2)
+    assert memo.get(t, "a", make(5)) == 5, "an in-place write must invalidate the entry"
+    assert memo.get(t, "b", make(6)) == 6
+    assert len(memo.entries) <= 2
+    u = torch.ones(2, 3) * 757.0
+    assert memo.get(u, "a", make(7)) == 7, "another tensor with equal values is not an identity hit"
+    # the scheduler's add_noise through the memo equals the direct formula
+    sch = FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    g = torch.Generator().manual_seed(0)
+    x0, eps = torch.randn(3, 4, 5, 6, generator=g).to(torch.bfloat16), torch.randn(3, 4, 5, 6, generator=g).to(torch.bfloat16)
+    tn = torch.ones(3, dtype=torch.long) * 750
+    first = sch.add_noise(x0, eps, tn)
+    again = sch.add_noise(x0, eps, tn)
+    sigma = sch.sigmas[sch._lookup(tn, x0.device)].reshape(-1, 1, 1, 1)
+    assert torch.equal(first, again) and torch.equal(first, ((1 - sigma) * x0 + sigma * eps).type_as(eps))
