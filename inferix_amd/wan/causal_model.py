@@ -657,8 +657,13 @@ class HipCausalWanModel(torch.nn.Module):
         # adds) per forward less; the same bits (the pipelines reuse one timestep tensor per step value, inferix_amd/pipeline).
         tkey = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, self.g["time0_w"].data_ptr(), self.g.get("time0_fmt"))
         hit = self._temb_cache.get(tkey)
+        stream_now = ops._stream()
         if hit is not None:
             E, eh = hit[1], hit[2]
+            if hit[3] != stream_now:                  # allocated on the other chain's stream: tell the allocator this stream reads them too
+                cur = torch.cuda.current_stream(dev)
+                E.record_stream(cur)
+                eh.record_stream(cur)
         else:
             emb = C.sinusoidal_embedding_1d(self.freq_dim, t.flatten()).to(BF16)      # [B*F, freq_dim]
             # time_embedding / time_projection (a handful of rows): the same MFMA GEMM as the block linears, SiLU is elementwise glue
@@ -668,7 +673,7 @@ class HipCausalWanModel(torch.nn.Module):
             eh = (self.g["head_mod"] + e.unsqueeze(1)).contiguous()                  # [B*Ft, 2, d]
             if len(self._temb_cache) >= 16:
                 self._temb_cache.pop(next(iter(self._temb_cache)))
-            self._temb_cache[tkey] = (t, E, eh)
+            self._temb_cache[tkey] = (t, E, eh, stream_now)
 
         need_ctx = any(not m["is_init"] for m in crossattn_cache_meta)
         ctx = None
