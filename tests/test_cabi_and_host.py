@@ -237,6 +237,81 @@ def test_pipeline_call_schedule_matches_reference_trace():
         assert pipe.kv_cache_meta is None           # free_cache_before_vae=True cleared the caches
 
 
+def test_pipeline_pairs_the_rerun_with_the_next_first_step_in_reference_order():
+    """With a generator that offers `forward_pair` the pipeline defers each block's clean-context re-run into the next block's first
+    denoising step (one `forward_pair(first, second)` call) — except the last block's, which runs alone.  The LOGICAL call sequence
+    (first before second inside a pair) must still be the reference's trace, the block callback must see every block once and in
+    order BEFORE its re-run, `pair_forwards=False` and `profile=True` must fall back to one call at a time, and the reused timestep
+    tensors must carry the reference's values."""
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausalInferencePipeline
+
+    class PairGen(_FakeGen):
+        def __init__(self):
+            super().__init__()
+            self.pairs = 0
+            self.events = []
+
+        def forward(self, **kw):
+            self.events.append(("call", kw["current_start"]))
+            return super().forward(**kw)
+
+        def forward_pair(self, first, second):
+            self.pairs += 1
+            assert first["kv_cache_manager"] is second["kv_cache_manager"] and first["current_start"] < second["current_start"]
+            assert float(first["timestep"].flatten()[0]) == 0.0, "the first of a pair is the clean-context re-run"
+            return super().forward(**first), super().forward(**second)
+
+    for name in ("rollout_tiny.npz", "rollout_tiny_prefill.npz"):
+        fx = golden(name)
+        ref_starts = fx["trace"][:, 0].tolist()
+        ref_t = [round(float(fx[f"call{i}_t"].flatten()[0]), 3) for i in range(int(fx["num_calls"]))]
+        nb = fx["noise"].shape[1] // 3
+        for pair_arg, profile, want_pairs in ((None, False, nb - 1), (False, False, 0), (True, True, 0)):
+            gen = PairGen()
+            args = SimpleNamespace(denoising_step_list=fx["steps"].tolist(), warp_denoising_step=True, num_frame_per_block=3,
+                                   independent_first_frame=False, context_noise=0, frame_seq_length=24, kv_cache_tokens=504,
+                                   pair_forwards=pair_arg)
+            gen.scheduler = __import__("inferix_amd.schedulers", fromlist=["x"]).FlowMatchScheduler(
+                shift=float(fx["shift"]), sigma_min=0.0, extra_one_step=True)
+            gen.scheduler.set_timesteps(1000, training=True)
+            pipe = CausalInferencePipeline(args, "cpu", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": None}, vae=None)
+            seen = []
+
+            def cb(lat, i, gen=gen, seen=seen):
+                seen.append((i, len(gen.calls)))
+            if profile:
+                import inferix_amd.pipeline.causal_inference as ci
+                real_event, real_sync = torch.cuda.Event, torch.cuda.synchronize
+
+                class _Ev:                       # the block timers of `profile=True` without a GPU
+                    def __init__(self, **kw):
+                        pass
+
+                    def record(self):
+                        pass
+
+                    def elapsed_time(self, other):
+                        return 0.0
+                torch.cuda.Event, torch.cuda.synchronize = _Ev, (lambda: None)
+            try:
+                pipe.inference(noise=fx["noise"], text_prompts=["x"], kv_cache_manager=KVCacheManager("cpu"),
+                               kv_cache_requests=[KVCacheRequest("r")], initial_latent=fx.get("initial_latent"),
+                               decode_mode=DecodeMode.NO_DECODE, block_callback=cb, profile=profile)
+            finally:
+                if profile:
+                    torch.cuda.Event, torch.cuda.synchronize = real_event, real_sync
+            assert gen.pairs == want_pairs, (name, pair_arg, profile, gen.pairs)
+            assert [c[0] for c in gen.calls] == ref_starts and [round(c[1], 3) for c in gen.calls] == ref_t, (name, pair_arg, profile)
+            assert [s_[0] for s_ in seen] == list(range(nb))
+            if want_pairs:
+                # a block's callback fires with its own steps issued and its re-run still pending (block 0 of the plain rollout: 3 calls)
+                per_block = len(fx["steps"])
+                n_pref = len(ref_starts) - nb * (per_block + 1)
+                assert [s_[1] for s_ in seen[:-1]] == [n_pref + per_block + b * (per_block + 1) for b in range(nb - 1)], seen
+
+
 def test_parallel_config_and_registry():
     from inferix_amd.attention import collect_supported_attn
     from inferix_amd.wan import ParallelConfig
