@@ -114,7 +114,7 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend
             if peer is not None:
                 idents.update(k[2] for k in peer._views)
         m._run_block = rec
-        assert pipe._pairing(), "a sequence-parallel model pairs its forwards by default"
+        assert pipe._pairing() or os.environ.get("IFX_PAIR_FORWARDS", "") in ("0", "false", "off"), "the pipeline pairs its forwards by default"
         renoise = [fx[f"renoise_{i}"] for i in range(int(fx["num_renoise"]))]
         mgr1 = KVCacheManager("cuda")
         out = pipe.inference(noise=fx["noise"].cuda(), text_prompts=["x"], kv_cache_manager=mgr1,
