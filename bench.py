@@ -65,7 +65,7 @@ def build_pipeline(device, parallel_config=None, num_layers=None):
     return model, gen, pipe
 
 
-def cpu_baseline(layers: int = 30):
+def cpu_baseline(layers: int = 30, weights=None, gpu_out=None):
     """BASELINE config 1 on this box's host cores, MEASURED end to end (nothing interpolated): Self-Forcing 480p, block_size 3,
     ONE denoise step (`denoising_step_list=[1000]`) + the clean-context re-run, one block of 3 latent frames, all 30 layers,
     NO_DECODE — `O.inference` of the CPU oracle (the port of the reference's CPU / PyTorch path that tests pin to the
@@ -73,7 +73,10 @@ def cpu_baseline(layers: int = 30):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wan_oracle as O
     cfg = O.WanConfig(num_layers=layers)
-    W = O.init_weights(cfg, seed=0)
+    # `weights` (the GPU model's own synthetic state dict, copied to the host) + `gpu_out` (the HIP path's latents of the SAME config on
+    # the same weights, noise and prompt: config1_gpu): the oracle is then also the CHECKER of the full-size, full-depth result of this
+    # very run — `parity_vs_gpu` below — not only the thing timed
+    W = weights if weights is not None else O.init_weights(cfg, seed=0)
     g = torch.Generator().manual_seed(0)
     noise = torch.randn(1, BLOCK, *LATENT, generator=g).to(torch.bfloat16)
     pe = torch.zeros(1, cfg.text_len, cfg.text_dim)
@@ -97,6 +100,13 @@ def cpu_baseline(layers: int = 30):
             break
     dt = min(runs)
     extra = {} if layers == 30 else {"INVALID": f"debug run with {layers} of 30 layers"}
+    if gpu_out is not None and weights is not None:
+        a, b = gpu_out.detach().cpu().double(), out.double()
+        rel = float((a - b).norm() / b.norm())
+        extra["parity_vs_gpu"] = {"rel_l2": round(rel, 6), "max_abs": round(float((a - b).abs().max()), 5), "rms_ref": round(float(b.pow(2).mean().sqrt()), 5),
+                                  "what": "latents of config 1 (1 denoise step + context re-run, 4680 tokens, 30 layers): HIP path vs this CPU oracle run, "
+                                          "same synthetic weights, noise and prompt; the bf16 rounding-noise floor of a 30-layer chain is ~1e-2 "
+                                          "(tests/test_hip_model.py measures it per block: 3.5e-3)"}
     return {**extra, "value": BLOCK / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "BASELINE config 1, measured: Self-Forcing 480p, block_size 3, 1 denoise step + clean-context re-run = 2 "
                       "generator forwards of the 30-layer Wan2.1-1.3B causal DiT over one 3-frame block (N = L_kv = 4680), "
@@ -354,9 +364,11 @@ def config1_gpu(model, gen, device):
         run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
+    out = run().detach().clone()
+    torch.cuda.synchronize()
     kvm.free(reqs[0])
     return {"workload": "BASELINE config 1 on the GPU: 1 denoise step + context re-run, one 3-frame block, 30 layers, NO_DECODE",
-            "ms": round(ms, 2), "latent_frames_per_s": round(BLOCK / ms * 1e3, 2)}
+            "ms": round(ms, 2), "latent_frames_per_s": round(BLOCK / ms * 1e3, 2), "_out": out}
 
 
 def quant_leg(fmt, gen, clip, rounds: int = 2, pipe_args=None):
@@ -862,8 +874,13 @@ def main():
             res["magi_cp8_emulated"] = magi_cp8_emulated_leg(device)                          # the named config: fp8_quant
             bf = magi_cp8_emulated_leg(device, fp8_quant=False, breakdown=False)
             res["magi_cp8_emulated"]["bf16_weights"] = {k: bf[k] for k in ("ms_clip_rank", "ms_per_denoise_forward_rank")}
+        gpu1 = res.get("config1_gpu", {}).pop("_out", None)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.cpu_layers)
+            w_host = None
+            if gpu1 is not None and a.cpu_layers == model.num_layers:
+                from inferix_amd.wan.synthetic import synthetic_state_dict
+                w_host = {k: v.cpu() for k, v in synthetic_state_dict(model, seed=0).items()}      # what build_pipeline loaded
+            res["cpu_baseline"] = cpu_baseline(a.cpu_layers, weights=w_host, gpu_out=gpu1 if w_host is not None else None)
             if "config1_gpu" in res:
                 res["cpu_baseline"]["gpu_same_config_frames_per_s"] = res["config1_gpu"]["latent_frames_per_s"]
         print(json.dumps(res), flush=True)

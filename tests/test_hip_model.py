@@ -364,6 +364,37 @@ def test_other_resolutions_vs_oracle(lat_h, lat_w, frames):
     assert r <= 1.25 * floor + 5e-4 and rx <= 1.25 * floor + 5e-4, f"{lat_h}x{lat_w}: floor {floor:.3e}, vs oracle {r:.3e}, vs exact {rx:.3e}"
 
 
+def test_full_depth_30_layers_real_channels_vs_oracle():
+    """The DEPTH of the BASELINE model: all 30 layers at the real channel geometry (dim 1536, 12 heads, ffn 8960, text 4096 / 512,
+    freq 256) on a small latent grid, a two-block rollout (2 denoise steps + context re-run each; the second block's first step runs
+    paired with the first block's re-run) against the CPU oracle.  Yardstick as everywhere: the oracle with the reference's bf16 SDPA sits
+    `floor` from the oracle with exact attention; the HIP rollout may be 1.25 x floor + 5e-4 from either.  (bench.py reports the same
+    comparison at the full 4680-token size inside `cpu_baseline.parity_vs_gpu`: 7.9e-3 on one run.)"""
+    from inferix_amd.core import DecodeMode
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    from inferix_amd.pipeline import CausalInferencePipeline
+    cfg = O.WanConfig(num_layers=30, latent_h=8, latent_w=12)
+    W = O.init_weights(cfg, seed=5)
+    m, gen, args = _pipeline(cfg, W, [1000, 500], 5.0)
+    args.kv_cache_tokens = 6 * cfg.frame_seqlen
+    g = torch.Generator().manual_seed(30)
+    noise = torch.randn(1, 6, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF)
+    pe = torch.zeros(1, cfg.text_len, cfg.text_dim)
+    pe[:, :12] = torch.randn(1, 12, cfg.text_dim, generator=g)
+    pe = pe.to(BF)
+    eps = [torch.randn(3, 16, cfg.latent_h, cfg.latent_w, generator=g).to(BF) for _ in range(2)]
+    pipe = CausalInferencePipeline(args, "cuda", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe.cuda()}, vae=None)
+    out = pipe.inference(noise=noise.cuda(), text_prompts=["x"], kv_cache_manager=KVCacheManager("cuda"),
+                         kv_cache_requests=[KVCacheRequest("r")], decode_mode=DecodeMode.NO_DECODE, renoise=list(eps))
+    torch.cuda.synchronize()
+    ref, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=5.0, num_frame_per_block=3)
+    exact, _ = O.inference(W, cfg, noise, list(pe), [1000, 500], renoise=list(eps), shift=5.0, num_frame_per_block=3, attn_impl="math")
+    floor, r, rx = rel_l2(ref, exact), rel_l2(out.cpu(), ref), rel_l2(out.cpu(), exact)
+    print(f"30 layers, real channels: floor (oracle bf16 SDPA vs exact attention) {floor:.3e}; HIP vs exact {rx:.3e}; HIP vs oracle {r:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert r <= 1.25 * floor + 5e-4 and rx <= 1.25 * floor + 5e-4, f"30 layers: floor {floor:.3e}, vs oracle {r:.3e}, vs exact {rx:.3e}"
+
+
 def test_wan_14b_channel_geometry_vs_oracle():
     """The 14B variant's channel geometry (dim 5120 = 40 heads x 128, ffn 13824) through the same kernels: one layer, a
     two-block rollout on a small latent grid against the CPU oracle."""
