@@ -549,6 +549,12 @@ typedef struct {
                                                  pairs with e + rope_half and the channels behind 2 * rope_half pass through.  0 = 64 (the whole
                                                  head).  MAGI's table covers 96 of the 128 head channels (3 axes x head_dim / 8 bands,
                                                  dit_module.py:673-720): rope_half = 48.  Multiple of 8. */
+  int32_t q_group;                            /* ABI 0.6, 0 = off: self-attention q head h is written at
+                                                 q_out + (h / q_group) * q_group_stride + r * ld_q + (h % q_group) * 128 — the send order of
+                                                 the head -> rank all-to-all ([(cp seq), heads / cp, 128]: q_group = heads / cp, ld_q = q_group *
+                                                 128, q_group_stride = rows * ld_q), so that no layout copy stands between this kernel and the
+                                                 collective (context_parallel.py:317-335's permute + contiguous) */
+  int64_t q_group_stride;
 } ifx_magi_head_prep_desc;
 int ifx_magi_head_prep(const ifx_magi_head_prep_desc* desc, void* stream);
 

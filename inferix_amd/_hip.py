@@ -68,7 +68,8 @@ class MagiHeadPrepDesc(C.Structure):
                 ("xn_w", C.c_void_p), ("xn_b", C.c_void_p), ("eps", C.c_float), ("layernorm_1p", C.c_int32),
                 ("q_out", C.c_void_p), ("ld_q", C.c_int32), ("qx_out", C.c_void_p), ("ld_qx", C.c_int32),
                 ("k_out", C.c_void_p), ("v_out", C.c_void_p), ("ld_kv", C.c_int32), ("kv_head_stride", C.c_int32),
-                ("row0", C.c_int32), ("split", C.c_int32), ("row1", C.c_int32), ("q_scale", C.c_float), ("rope_half", C.c_int32)]
+                ("row0", C.c_int32), ("split", C.c_int32), ("row1", C.c_int32), ("q_scale", C.c_float), ("rope_half", C.c_int32),
+                ("q_group", C.c_int32), ("q_group_stride", C.c_int64)]
 
 
 IFX_MAX_PEERS, IFX_PEER_HANDLE_BYTES = 8, 64

@@ -44,6 +44,8 @@ struct HeadPrepArgs {
   int ld_kv, kv_head_stride;
   int row0, split, row1;         // dest(r) = r < split ? row0 + r : row1 + (r - split)
   float q_scale;                 // self-attention q only: applied in fp32 before the rounding to bf16 (1 = the reference's q)
+  int q_group;                   // 0: head h of q at column h * 128 of row r; > 0: at (h / q_group) * q_group_stride + r * ld_q + (h % q_group) * 128
+  long long q_group_stride;      //    (the head -> rank all-to-all's send order)
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -138,8 +140,13 @@ __global__ __launch_bounds__(256) void magi_head_prep_kernel(HeadPrepArgs A) {
     const float out = !rot ? y[i] : (lo ? __fmul_rn(y[i], cs) - __fmul_rn(p, sn) : __fmul_rn(p, sn) + __fmul_rn(y[i], cs));
     o[i] = f2bf(type == HT_Q ? out * A.q_scale : out);
   }
-  if (type == HT_Q) *reinterpret_cast<u16x8*>(A.q_out + (size_t)r * A.ld_q + hidx * 128 + e0) = o;
-  else *reinterpret_cast<u16x8*>(A.k_out + (size_t)dest * A.ld_kv + hidx * A.kv_head_stride + e0) = o;
+  if (type == HT_Q) {
+    const size_t qcol = A.q_group > 0 ? (size_t)(hidx / A.q_group) * (size_t)A.q_group_stride + (size_t)(hidx % A.q_group) * 128
+                                      : (size_t)hidx * 128;
+    *reinterpret_cast<u16x8*>(A.q_out + (size_t)r * A.ld_q + qcol + e0) = o;
+  } else {
+    *reinterpret_cast<u16x8*>(A.k_out + (size_t)dest * A.ld_kv + hidx * A.kv_head_stride + e0) = o;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -344,7 +351,9 @@ extern "C" int ifx_magi_head_prep(const ifx_magi_head_prep_desc* d, void* stream
   if (d->layout == 0) {
     IFX_REQUIRE(a.hq > 0 && d->rope && d->qn_w && d->qn_b && d->kn_w && d->kn_b && d->xn_w && d->xn_b && d->q_out && d->qx_out,
                 "ifx_magi_head_prep: layout 0 needs q/qx outputs, rope and the three norms");
-    IFX_REQUIRE(d->ld_q >= a.hq * 128 && d->ld_qx >= a.hq * 128 && d->ld_q % 8 == 0 && d->ld_qx % 8 == 0,
+    IFX_REQUIRE(d->q_group >= 0 && (d->q_group == 0 || (a.hq % d->q_group == 0 && d->q_group_stride >= (int64_t)d->rows * d->ld_q && d->q_group_stride % 8 == 0)),
+                "ifx_magi_head_prep: q_group %d / q_group_stride %lld", d->q_group, (long long)d->q_group_stride);
+    IFX_REQUIRE(d->ld_q >= (d->q_group > 0 ? d->q_group : a.hq) * 128 && d->ld_qx >= a.hq * 128 && d->ld_q % 8 == 0 && d->ld_qx % 8 == 0,
                 "ifx_magi_head_prep: q row strides too small");
     a.n_heads = 2 * a.hq + 2 * a.hk;
   } else {
@@ -365,6 +374,7 @@ extern "C" int ifx_magi_head_prep(const ifx_magi_head_prep_desc* d, void* stream
   a.q_out = d->q_out, a.ld_q = d->ld_q, a.qx_out = d->qx_out, a.ld_qx = d->ld_qx;
   IFX_REQUIRE(d->q_scale >= 0.f && d->q_scale == d->q_scale, "ifx_magi_head_prep: q_scale must be >= 0 (0 = 1)");
   a.q_scale = d->q_scale > 0.f ? d->q_scale : 1.0f;
+  a.q_group = d->q_group, a.q_group_stride = d->q_group_stride;
   a.k_out = d->k_out, a.v_out = d->v_out, a.ld_kv = d->ld_kv, a.kv_head_stride = d->kv_head_stride;
   a.row0 = d->row0, a.split = d->split, a.row1 = d->row1;
   if (d->rows == 0) return IFX_OK;

@@ -774,8 +774,10 @@ F32 = torch.float32
 def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: int, eps: float, layernorm_1p: bool,
                    k_out: torch.Tensor, v_out: torch.Tensor, kv_head_stride: int, ld_kv: int, row0: int = 0,
                    split: Optional[int] = None, row1: int = 0, rope: Optional[torch.Tensor] = None, qn=None, kn=None, xn=None,
-                   q_out: Optional[torch.Tensor] = None, qx_out: Optional[torch.Tensor] = None, q_scale: float = 0.0) -> None:
+                   q_out: Optional[torch.Tensor] = None, qx_out: Optional[torch.Tensor] = None, q_scale: float = 0.0,
+                   q_group: int = 0) -> None:
     """ifx_magi_head_prep: per-head LayerNorm (+ rotary) of the fused projection row and the k / v scatter (include/inferix_hip.h).
+    `q_group` > 0: `q_out` is `[q_heads / q_group, rows, q_group * 128]` — the head -> rank all-to-all's send order — instead of `[rows, q_heads * 128]`.
     `qn` / `kn` = (weight, bias) fp32 `[128]`; `xn` = (weight, bias) bf16 `[128]`; `k_out` / `v_out` are base tensors of the
     destination (cache planes or a staging buffer), addressed dest(r) * ld_kv + head * kv_head_stride."""
     rows = mixed.shape[0]
@@ -791,9 +793,14 @@ def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: 
         d.rope_half = rope.shape[1] // 2            # partial rotary: MAGI's table covers 96 of the 128 head channels
         d.qn_w, d.qn_b = _dev(qn[0], "q_layernorm.weight", F32), _dev(qn[1], "q_layernorm.bias", F32)
         d.kn_w, d.kn_b = _dev(kn[0], "k_layernorm.weight", F32), _dev(kn[1], "k_layernorm.bias", F32)
-        d.q_out, d.ld_q = _dev(q_out, "q_out"), q_out.stride(0)
+        if q_group > 0:
+            assert q_out.dim() == 3 and q_out.is_contiguous() and q_out.shape == (q_heads // q_group, rows, q_group * 128), q_out.shape
+            d.q_out, d.ld_q, d.q_group, d.q_group_stride = _dev(q_out, "q_out"), q_group * 128, int(q_group), rows * q_group * 128
+        else:
+            d.q_out, d.ld_q = _dev(q_out, "q_out"), q_out.stride(0)
+            assert q_out.shape[0] >= rows
         d.qx_out, d.ld_qx = _dev(qx_out, "qx_out"), qx_out.stride(0)
-        assert q_out.shape[0] >= rows and qx_out.shape[0] >= rows
+        assert qx_out.shape[0] >= rows
     d.xn_w, d.xn_b = _dev(xn[0], "layernorm_xattn.weight"), _dev(xn[1], "layernorm_xattn.bias")
     d.k_out, d.v_out, d.ld_kv, d.kv_head_stride = _dev(k_out, "k_out"), _dev(v_out, "v_out"), int(ld_kv), int(kv_head_stride)
     d.row0, d.split, d.row1 = int(row0), int(rows if split is None else split), int(row1)

@@ -43,6 +43,10 @@ BF16 = torch.bfloat16
 # attention is called with scale = ln 2: the same softmax(q k^T / sqrt(128)), on the exponent fast path of the attention kernel.  The
 # cross-attention queries (qx) keep the reference's form.
 Q_SCALE, ATTN_SCALE = ops.attn_q_prescale(128) if os.environ.get("IFX_MAGI_Q_PRESCALE", "1") != "0" else (0.0, 0.0)
+import os as _os
+
+_ULYSSES_FAST = _os.environ.get("IFX_MAGI_ULYSSES_FAST", "1") != "0"     # the cp_ulysses layer with its layout copies folded away (_ulysses)
+
 FP32_PARAMS = ("self_attention.q_layernorm.", "self_attention.k_layernorm.", "self_attn_post_norm.", "mlp_post_norm.",
                "final_layernorm.")
 
@@ -182,13 +186,43 @@ class HipFullyParallelAttention:
         w = self.w
         s_len = mixed.shape[0]
         sizes = [int(v) for v in meta_args.cp_split_sizes]
+        cq = meta_args.core_attn_params.np_q_range
+        ck = meta_args.core_attn_params.np_k_range
+        overlap = getattr(self.engine_config, "ulysses_overlap_degree", 1)
+        if _ULYSSES_FAST and overlap == 1 and self.hk == cp and self.hq % cp == 0:
+            # Round 5: the same collectives with the layout copies folded into their neighbours.  The head -> rank all-to-alls send
+            # [(cp seq), heads / cp, hd] (context_parallel.py `_heads_to_ranks`: a permute + contiguous of q and of k|v per layer); the
+            # head-prep kernel writes both operands in that order directly (one kv head per rank: a head stride; q: ifx_magi_head_prep's
+            # q_group), and the way back — all-to-all pieces [cp, seq, hn hd] -> rows [seq, (cp hn hd)] of the projection input — is ONE
+            # strided copy instead of cat + permute + contiguous + copy.  Four ~12 us copies per layer and forward less; the bytes on
+            # the wire, the cache rule and the attention calls are those of the scheduler below (tests: the 2-rank goldens).
+            hpr = self.hq // cp
+            kv_send = torch.empty(cp, s_len, 1, 2 * self.hd, dtype=BF16, device=mixed.device)
+            q_send = torch.empty(cp, s_len, hpr * self.hd, dtype=BF16, device=mixed.device)
+            ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
+                               k_out=kv_send, v_out=kv_send.view(-1)[self.hd:], kv_head_stride=s_len * 2 * self.hd, ld_kv=2 * self.hd,
+                               rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"], xn=w["q_layernorm_xattn"], q_out=q_send,
+                               qx_out=qx_buf, q_scale=Q_SCALE, q_group=hpr)
+            total = sum(sizes)
+            kv_all = torch.empty(total, 1, 2 * self.hd, dtype=BF16, device=mixed.device)
+            q_all = torch.empty(total, hpr, self.hd, dtype=BF16, device=mixed.device)
+            hkv = cpl._a2a(kv_all, kv_send.view(cp * s_len, 1, 2 * self.hd), out_sizes=sizes)
+            hq_ = cpl._a2a(q_all, q_send.view(cp * s_len, hpr, self.hd), out_sizes=sizes)
+            hkv.wait()
+            key = self.kv_cache_manager.adjust_key_and_value_for_inference(kv_all, inference_params, meta_args)
+            hq_.wait()
+            out = torch.empty_like(q_all)
+            _range_attention(q_all.view(total, -1), key, cq, ck, meta_args.denoising_range_num, out.view(total, -1), hpr)
+            back, hb = cpl.all_to_all_output_split(out, sizes)                     # [(cp seq), hpr, hd], source-rank major
+            hb.wait()
+            Q = self.hq * self.hd
+            attn_cat[:, :Q].view(s_len, cp, hpr * self.hd).copy_(back.view(cp, s_len, hpr * self.hd).transpose(0, 1))
+            return
         kv_stage = torch.empty(s_len, self.hk, 2 * self.hd, dtype=BF16, device=mixed.device)
         ops.magi_head_prep(mixed, layout=0, q_heads=self.hq, kv_heads=self.hk, eps=eps, layernorm_1p=one_p,
                            k_out=kv_stage, v_out=kv_stage.view(-1)[self.hd:], kv_head_stride=2 * self.hd,
                            ld_kv=self.hk * 2 * self.hd, rope=rope, qn=w["q_layernorm"], kn=w["k_layernorm"],
                            xn=w["q_layernorm_xattn"], q_out=q_buf, qx_out=qx_buf, q_scale=Q_SCALE)
-        cq = meta_args.core_attn_params.np_q_range
-        ck = meta_args.core_attn_params.np_k_range
 
         def core(qc, key, value):
             out = torch.empty_like(qc)

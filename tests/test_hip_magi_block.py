@@ -137,6 +137,23 @@ def test_head_prep_vs_oracle():
     assert_bf16_parity(k_got, k_ref, max_ulp=1, floor=1.0, what="k (LayerNorm + rotary)")
     assert torch.equal(v_got.cpu(), v_ref), "v is a copy"
     assert int(kc[:100].abs().sum()) == 0 and int(kc[100 + split:cap].abs().sum()) == 0, "rows outside the destination touched"
+    # round 5: q (and k | v) written straight in the head -> rank all-to-all's send order — the bits of the plain launch, permuted
+    for cp in (2, 4, 8):
+        if hq % cp or hk != cp:
+            continue
+        hpr = hq // cp
+        q_send = torch.zeros(cp, rows, hpr * hd, dtype=BF, device="cuda")
+        kv_send = torch.zeros(cp, rows, 1, 2 * hd, dtype=BF, device="cuda")
+        qx2 = torch.empty_like(qx_out)
+        ops.magi_head_prep(mixed.cuda(), layout=0, q_heads=hq, kv_heads=hk, eps=1e-6, layernorm_1p=True, k_out=kv_send,
+                           v_out=kv_send.view(-1)[hd:], kv_head_stride=rows * 2 * hd, ld_kv=2 * hd, rope=rope.cuda(),
+                           qn=[t.cuda() for t in qn], kn=[t.cuda() for t in kn], xn=[t.cuda() for t in xn], q_out=q_send, qx_out=qx2,
+                           q_group=hpr)
+        want_q = q_out.view(rows, cp, hpr * hd).transpose(0, 1)
+        assert torch.equal(q_send, want_q), f"cp = {cp}: q in send order differs from the plain launch"
+        assert torch.equal(qx2, qx_out)
+        assert torch.equal(kv_send[:, :, 0, :hd].transpose(0, 1), k_got.cuda() if False else torch.cat([kc[100:100 + split], kc[cap:cap + rows - split]]))
+        assert torch.equal(kv_send[:, :, 0, hd:].transpose(0, 1).cpu(), v_ref)
     # layout 1: the caption keys / values
     yt = 77
     kvx = torch.randn(yt, 2 * KV, generator=g).to(BF)
