@@ -571,6 +571,12 @@ int ifx_magi_gate_norm_residual(const ifx_bf16* x, int32_t ldx, const ifx_bf16* 
  * IFX_ACT_TANH (softcap with cap 1, :363-364,:1300-1303). */
 enum { IFX_ACT_SILU = 0, IFX_ACT_TANH = 1 };
 int ifx_act_rows(const ifx_bf16* x, ifx_bf16* y, int64_t n, int32_t mode, void* stream);
+/* MagiKVCacheManager's store after the head -> rank all-to-all (inferix/models/magi/dit/dit_module.py:905-952: the K | V rows of the
+ * message go into the cache, the first `split` rows to the run that is kept, the rest to the scratch run behind it):
+ *   kv [rows, heads, 2 * 128] contiguous; row r -> cache row (r < split ? row0 + r : row1 + r - split) of k_cache / v_cache
+ *   [slots, heads, 128] (head_dim 128).  One launch instead of four strided copies per layer. */
+int ifx_kv_split_rows(const ifx_bf16* kv, ifx_bf16* k_cache, ifx_bf16* v_cache, int32_t rows, int32_t heads, int32_t row0,
+                      int32_t split, int32_t row1, void* stream);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ifx_magi_gate_norm_residual": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32,
                                               _vp]),
     "ifx_act_rows": (C.c_int, [_vp, _vp, C.c_int64, _i32, _vp]),
+    "ifx_kv_split_rows": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ifx_attn_fwd_dedup": (C.c_int, [_vp, _vp, C.POINTER(KvView), _i32, _i32, _i32, _i32, _f32, _vp]),
     "ifx_attn_fwd_ranges": (C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(KvView), _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _f32, _vp]),
     "ifx_gemm_workspace_bytes": (C.c_int64, [_i32, _i32, _i32]),

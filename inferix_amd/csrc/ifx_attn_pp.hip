@@ -1146,9 +1146,21 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots)
   if (tiles * 16 >= slots * 13 || nt < 16) return 1;   // >= ~80 % of the workgroup slots already busy / nothing to split
   int best = 1;
   float best_eff = (float)tiles / ((float)slots * ((tiles + slots - 1) / slots));
+  // per-chunk penalty: every chunk writes one fp32 partial per (row, head) and the merge reads it back — (128 + 1) x 4 bytes each.  1 % per
+  // chunk at the 3.6 MB of a sequence-parallel rank's launch (585 rows x 12 heads: where the constant was fitted), scaled with the
+  // partial's size: MAGI's range launches (12150 rows x 3 heads = 18.8 MB per chunk) then take 5 chunks instead of 7 — rank-clip 8.50 ->
+  // 8.36 s (round 5, `IFX_ATTN_SPLIT_PENALTY` sweep: 0.005 / 0.01 / 0.02 / 0.03 / 0.05 -> 8.45 / 8.50 / 8.49 / 8.37 / 8.36 s; the
+  // sharded rank is best at 0.01: 268 vs 289 / 273 ms at 0.03 / 0.05)
+  static float base = -1.f;
+  if (base < 0.f) {
+    const char* e = getenv("IFX_ATTN_SPLIT_PENALTY");  // lab: the base of the per-chunk cost
+    base = e ? (float)atof(e) : 0.01f;
+  }
+  const float part_mb = (float)q_rows * (float)heads * 516.f / 3.6e6f;
+  const float pen = base * (part_mb > 1.f ? part_mb : 1.f);
   for (int s = 2; s <= 32 && s * 8 <= nt; ++s) {        // chunks of >= 8 tiles (512 keys)
     const int wg = tiles * s, rounds = (wg + slots - 1) / slots;
-    const float eff = (float)wg / ((float)slots * rounds) * (1.f - 0.01f * s);   // small per-chunk prologue/merge penalty
+    const float eff = (float)wg / ((float)slots * rounds) * (1.f - pen * s);   // per-chunk prologue / partial / merge penalty
     if (eff > best_eff + 1e-3f) best_eff = eff, best = s;
   }
   return best;

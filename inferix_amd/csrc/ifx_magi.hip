@@ -400,6 +400,39 @@ extern "C" int ifx_magi_gate_norm_residual(const ifx_bf16* x, int32_t ldx, const
   });
 }
 
+// K | V rows of an all-to-all message -> the cache planes, with the store rule's two destination runs (MagiKVCacheManager): row r of
+// `kv` [n, heads, 2 * 128] goes to cache row dest(r) = r < split ? row0 + r : row1 + (r - split); K = the first 128 channels of a head,
+// V the second.  One launch for what four strided torch copies did (k / v x stored run / scratch run).
+namespace ifx {
+__global__ __launch_bounds__(256) void kv_split_rows_kernel(const unsigned short* __restrict__ kv, unsigned short* __restrict__ kc,
+                                                            unsigned short* __restrict__ vc, long n_chunks, int heads, int row0,
+                                                            int split, int row1) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk of K and the matching one of V per thread
+  if (c >= n_chunks) return;
+  const int ch = (int)(c & 15);                                 // chunk inside the 128-channel head
+  const long rh = c >> 4;                                       // (row, head)
+  const int h = (int)(rh % heads);
+  const long r = rh / heads;
+  const long dest = r < split ? (long)row0 + r : (long)row1 + (r - split);
+  const u16x8 k = *reinterpret_cast<const u16x8*>(kv + (rh * 2) * 128 + ch * 8);
+  const u16x8 v = *reinterpret_cast<const u16x8*>(kv + (rh * 2 + 1) * 128 + ch * 8);
+  *reinterpret_cast<u16x8*>(kc + (dest * heads + h) * 128 + ch * 8) = k;
+  *reinterpret_cast<u16x8*>(vc + (dest * heads + h) * 128 + ch * 8) = v;
+}
+}  // namespace ifx
+
+extern "C" int ifx_kv_split_rows(const ifx_bf16* kv, ifx_bf16* k_cache, ifx_bf16* v_cache, int32_t rows, int32_t heads, int32_t row0,
+                                 int32_t split, int32_t row1, void* stream) {
+  IFX_REQUIRE(kv && k_cache && v_cache && rows >= 0 && heads > 0 && row0 >= 0 && row1 >= 0 && split >= 0 && split <= rows,
+              "ifx_kv_split_rows: bad arguments (rows %d, heads %d, split %d)", rows, heads, split);
+  IFX_REQUIRE(!((uintptr_t)kv & 15) && !((uintptr_t)k_cache & 15) && !((uintptr_t)v_cache & 15), "ifx_kv_split_rows: 16-byte aligned tensors");
+  if (rows == 0) return IFX_OK;
+  const long n_chunks = (long)rows * heads * 16;
+  hipLaunchKernelGGL(ifx::kv_split_rows_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kv, k_cache,
+                     v_cache, n_chunks, heads, row0, split, row1);
+  return check_launch("ifx_kv_split_rows");
+}
+
 extern "C" int ifx_act_rows(const ifx_bf16* x, ifx_bf16* y, int64_t n, int32_t mode, void* stream) {
   IFX_REQUIRE(x && y && n >= 0 && (mode == IFX_ACT_SILU || mode == IFX_ACT_TANH), "ifx_act_rows: bad arguments (mode %d)", mode);
   if (n == 0) return IFX_OK;

@@ -810,6 +810,17 @@ def magi_head_prep(mixed: torch.Tensor, *, layout: int, q_heads: int, kv_heads: 
         _hip.check(_hip.load().ifx_magi_head_prep(C.byref(d), _stream()), "ifx_magi_head_prep")
 
 
+def kv_split_rows(kv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row0: int, split: int, row1: int) -> None:
+    """`kv` `[n, heads, 256]` (K | V per head) -> rows of the cache planes `[slots, heads, 128]`: row r to `row0 + r` for r < split, to
+    `row1 + r - split` behind it (ifx_kv_split_rows: MagiKVCacheManager's store rule in one launch)."""
+    n, heads, hd2 = kv.shape
+    assert hd2 == 256 and kv.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert k_cache.shape[1:] == (heads, 128) and v_cache.shape == k_cache.shape
+    assert 0 <= split <= n and row0 + split <= k_cache.shape[0] and row1 + (n - split) <= k_cache.shape[0]
+    _hip.check(_hip.load().ifx_kv_split_rows(_dev(kv, "kv"), _dev(k_cache, "k_cache"), _dev(v_cache, "v_cache"), n, heads, int(row0),
+                                             int(split), int(row1), _stream()), "ifx_kv_split_rows")
+
+
 def magi_gate_norm_residual(x: torch.Tensor, residual: torch.Tensor, condition_map: torch.Tensor, gate: torch.Tensor,
                             norm_w: torch.Tensor, norm_b: torch.Tensor, eps: float, layernorm_1p: bool,
                             out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -146,6 +146,10 @@ class MagiKVCacheManager:
         handle, (row0, split, row1) = self.prepare_append(n, hn, hd, key_and_value.dtype, key_and_value.device,
                                                           inference_params, meta_args)
         kc, vc = handle.view.k, handle.view.v
+        if (key_and_value.is_cuda and hd == 128 and key_and_value.dtype == torch.bfloat16 and key_and_value.is_contiguous()
+                and kc.is_contiguous() and vc.is_contiguous() and kc.dim() == 3):
+            ops.kv_split_rows(key_and_value, kc, vc, row0, split, row1)          # one launch (round 5) for the four copies below
+            return handle
         if split:
             kc[row0:row0 + split].copy_(key_and_value[:split, :, :hd])
             vc[row0:row0 + split].copy_(key_and_value[:split, :, hd:])

@@ -593,3 +593,21 @@ def test_fp8_quant_layer_stack_vs_reference_golden():
     written = int(fx["cache_written"])
     raw = ip.kv_cache_manager.get_raw(ip.kv_cache_request, "layer_1")           # K / V of the FP8 layer: fp8 GEMM outputs
     assert rel_l2(raw[:, :written].cpu(), fx["cache_l1"][:, :written]) < 1.5e-2
+
+
+def test_kv_split_rows_is_the_four_copies():
+    """ifx_kv_split_rows (round 5): the K | V rows of the all-to-all message into the cache planes under the store rule's two destination
+    runs, in one launch — bit-identical to the four strided copies it replaces, nothing else of the cache touched, ragged splits included."""
+    from inferix_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    for n, heads, row0, split, row1, slots in ((333, 1, 100, 200, 700, 900), (64, 2, 0, 64, 64, 128), (50, 3, 10, 0, 20, 80), (7, 1, 5, 7, 0, 16)):
+        kv = torch.randn(n, heads, 256, generator=g).to(BF).cuda()
+        kc = torch.full((slots, heads, 128), 3.0, dtype=BF, device="cuda")
+        vc = torch.full((slots, heads, 128), 5.0, dtype=BF, device="cuda")
+        kr, vr = kc.clone(), vc.clone()
+        kr[row0:row0 + split] = kv[:split, :, :128]
+        vr[row0:row0 + split] = kv[:split, :, 128:]
+        kr[row1:row1 + n - split] = kv[split:, :, :128]
+        vr[row1:row1 + n - split] = kv[split:, :, 128:]
+        ops.kv_split_rows(kv, kc, vc, row0, split, row1)
+        assert torch.equal(kc, kr) and torch.equal(vc, vr), (n, heads, row0, split, row1)
