@@ -168,7 +168,9 @@ def test_ulysses_scheduler_two_ranks_hip_attention_and_cache():
     """2 ranks (both on cuda:0; host-side gloo exchange): sharded sequence, one kv head per rank, 3 query heads each,
     cached prefix + new keys.  The gathered result equals plain grouped-query attention over prefix + sequence."""
     world = 2
-    with mp.Manager() as mgr:
+    # (a SPAWNED manager: forking the pytest process — HIP runtime, streams and events alive in it — for the manager server has
+    #  crashed in the child's garbage collector; the workers themselves are spawned by mp.spawn already)
+    with mp.get_context("spawn").Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_sched_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         outs = [ret[r] for r in range(world)]
@@ -214,7 +216,7 @@ def test_all_to_all_async_over_rccl_is_ordered_before_its_consumer():
     changing payloads, a GEMM in front, no host synchronisation between the wait and the consumer (a stale buffer would show).
     Only runs where two GPUs are visible; the 1-GPU boxes cover the same call through gloo in the two-rank layer tests."""
     world = 2
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_a2a_order_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
 
@@ -225,6 +227,6 @@ def test_all_to_all_async_over_rccl_one_rank_twin():
     same `cp._a2a` (`dist.all_to_all_single(async_op=True)` on the RCCL backend, its internal stream, `wait()` as a stream-level
     dependency) with a GEMM in front and the consumer enqueued right behind the wait, six rounds with changing payloads.  What this
     does not cover is bytes between two devices; everything on this side of the wire — backend call, work handle, stream ordering — runs."""
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_a2a_order_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
     assert ret[0] is True, dict(ret)

@@ -464,7 +464,7 @@ def test_layer_under_cp_ulysses_two_ranks_matches_single_device_golden():
     port = s.getsockname()[1]
     s.close()
     world = 2
-    with mp.Manager() as mgr:
+    with mp.get_context("spawn").Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_cp_worker, args=(world, port, ret), nprocs=world, join=True)
         outs = [ret[r] for r in range(world)]
@@ -487,7 +487,7 @@ def test_layer_under_cp_shuffle_overlap_two_ranks_matches_single_device_golden()
     port = s.getsockname()[1]
     s.close()
     world = 2
-    with mp.Manager() as mgr:
+    with mp.get_context("spawn").Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_cp_worker, args=(world, port, ret, "cp_shuffle_overlap"), nprocs=world, join=True)
         outs = [ret[r] for r in range(world)]

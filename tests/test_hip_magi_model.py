@@ -322,7 +322,7 @@ def test_model_under_context_parallelism_two_ranks_vs_reference_golden(strategy)
     s.close()
     world = 2
     fx = golden("magi_model_tiny.npz")
-    with mp.Manager() as mgr:
+    with mp.get_context("spawn").Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_model_cp_worker, args=(world, port, strategy, ret), nprocs=world, join=True)
         outs = [ret[r] for r in range(world)]

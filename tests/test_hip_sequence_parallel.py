@@ -174,7 +174,9 @@ def _worker(rank, world, port, overlap, name, ret, exchange="allgather", backend
 @pytest.mark.parametrize("name", ["rollout_tiny.npz", "rollout_tiny_local.npz"])
 def test_sequence_parallel_rollout_matches_single_device_golden(overlap, name):
     world = 2
-    ret = mp.Manager().dict()
+    # (a SPAWNED manager: forking the pytest process — HIP runtime, streams and events alive in it — for the manager server has
+    #  crashed in the child's garbage collector; the workers themselves are spawned by mp.spawn already)
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), overlap, name, ret), nprocs=world, join=True)
     for rank in range(world):
         ok_trace, r = ret[rank]
@@ -187,7 +189,7 @@ def test_sequence_parallel_peer_store_rollout(overlap, name):
     """The exchange without a collective: two PROCESSES (both on cuda:0) store their K/V rows into each other's cache through HIP IPC
     mappings, ordered by the ready / done flags — same golden, same tolerance as the all-gather path."""
     world = 2
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), overlap, name, ret, "peer"), nprocs=world, join=True)
     for rank in range(world):
         ok_trace, r = ret[rank]
@@ -202,7 +204,7 @@ def test_sequence_parallel_with_quantised_linears_matches_the_unsharded_quantise
     make every row independent of the sharding, so the sharded rollout has to land on the unsharded quantised one at the bf16 floor of
     a rollout (the attention key splits differ), and no block linear may run on the bf16 weights (every bf16 GEMM's weight shape is recorded)."""
     world = 2
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), True, "rollout_tiny.npz", ret, exchange, "gloo", "fp8"), nprocs=world, join=True)
     for rank in range(world):
         ok_trace, r, vs_single, single_vs_bf16 = ret[rank]
@@ -218,7 +220,7 @@ def test_sequence_parallel_rollout_over_rccl(exchange):
     """The same rollout with one GPU per rank: the all-gather over RCCL, the peer stores over HIP IPC between DEVICES, the preflight in
     front.  Runs only where two GPUs are visible (round-2 verdict: nothing had executed over RCCL)."""
     world = 2
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), True, "rollout_tiny.npz", ret, exchange, "nccl"), nprocs=world, join=True)
     for rank in range(world):
         ok_trace, r = ret[rank]
@@ -232,7 +234,7 @@ def test_reference_launcher_parallel_config_runs_the_sequence_parallel_exchange(
     exchange with a replicated full-size cache, the rollout equals the single-device golden, and a second call through a fresh
     manager with the same request id (what the pipelines do) reproduces it bit for bit."""
     world = 2
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), True, "rollout_tiny.npz", ret, exchange, "gloo", None, degrees, True), nprocs=world, join=True)
     for rank in range(world):
         ok_trace, r = ret[rank]
@@ -246,7 +248,7 @@ def test_sequence_parallel_rollout_over_rccl_one_rank_twin(overlap, name):
     sequence-parallel route — K/V-first projection, `dist.all_gather_into_tensor` on the RCCL backend from the side stream, the scatter
     into the replicated cache, prefix / new-block attention split + merge, the head gather, the preflight — against the single-device
     golden (with and without overlap, with the rolling window).  Not covered: bytes between two devices."""
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(1, _free_port(), overlap, name, ret, "allgather", "nccl"), nprocs=1, join=True)
     ok_trace, r = ret[0]
     assert ok_trace and r <= 1.0, (ok_trace, r)
@@ -310,6 +312,6 @@ def test_peer_store_push_two_processes_bit_exact():
     """`ifx_rmsnorm_rope_kv_push` through IPC mappings: after ready / push / done, each of the two processes' caches holds exactly
     the bytes one device writes with `ifx_rmsnorm_rope_kv_append` for the whole block."""
     world = 2
-    ret = mp.Manager().dict()
+    ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_push_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
