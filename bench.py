@@ -295,11 +295,20 @@ def per_block_decode_leg(clip_with_callback):
     vae = HipWanVAEWrapper(synthetic_decoder_state_dict(seed=0))
     frames = []
 
-    def cb(block_latent, block_index):
-        frames.append(vae.decode_to_pixel(block_latent, use_cache=True, chunk_size=1))
+    side = torch.cuda.Stream() if os.environ.get("IFX_BENCH_DECODE_STREAM") == "1" else None   # lab A/B (see the note below)
 
-    # (decoding block b on a second HIP stream while block b + 1 is denoised was measured too: 1494.8 vs 1498.9 ms per clip — both
-    #  workloads fill the chip, the streams serialise)
+    def cb(block_latent, block_index):
+        if side is None:
+            frames.append(vae.decode_to_pixel(block_latent, use_cache=True, chunk_size=1))
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        block_latent.record_stream(side)
+        with torch.cuda.stream(side):
+            frames.append(vae.decode_to_pixel(block_latent, use_cache=True, chunk_size=1))
+
+    # (decoding block b on a second HIP stream while block b + 1 is denoised — IFX_BENCH_DECODE_STREAM=1 — was measured in round 1
+    #  (1494.8 vs 1498.9 ms per clip) and again in round 5 (1284.0-1284.4 vs 1280.1-1281.6, tools/scratch/r5_ab_decode_stream.sh):
+    #  both workloads fill the chip at the power limit, the streams serialise)
     clip_with_callback(cb)
     torch.cuda.synchronize()
     frames.clear()
