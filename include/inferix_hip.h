@@ -67,7 +67,8 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   ifx_gemm_q8 reads the same option: 1 / 2 = register-staged 128x128 / 64-byte-row LDS-DMA tiles, 3 = the LDS-DMA
  *                   tiles, never the ping-pong tile, 22 / 23 / 24 = the ping-pong tile with 256 / 192 / 128 tokens (FP8 and INT8)
  *   "gemm_small_split": 1 lets the auto choice split K between the wave groups of one workgroup for launches of at most one workgroup
- *                   per CU (a sequence-parallel rank's 585 .. 2340 rows).  Off by default: those tiles sum K in a different order and
+ *                   per CU (a sequence-parallel rank's 585 .. 2340 rows).  PER HOST THREAD (set, read and applied on the calling
+ *                   thread only: launches another thread enqueues meanwhile keep their own value).  Off by default: those tiles sum K in a different order and
  *                   which launches get them depends on the row count, while the default auto choice keeps a row's bits independent
  *                   of the number of rows in the launch (its only K split, two workgroups per tile for N <= 2048 and K >= 4096
  *                   through ifx_gemm_bf16_ws, is a function of N and K).

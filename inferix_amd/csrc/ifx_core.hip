@@ -16,7 +16,10 @@ void set_error(const char* fmt, ...) {
 }
 
 // kernel-selection overrides (ifx_set_option); -1 = unset -> environment variable -> 0 (auto)
-static int g_gemm_variant = -1, g_attn_variant = -1, g_gemm_small_split = -1, g_spin_timeout_ms = -1, g_spin_fault = 0;
+static int g_gemm_variant = -1, g_attn_variant = -1, g_spin_timeout_ms = -1, g_spin_fault = 0;
+// gemm_small_split is a property of the CALLER (a sequence-parallel rank's block loop sets it around its own launches): per host thread,
+// so that launches another thread enqueues meanwhile (a VAE decode, a text encoder) keep the row-count independent choice
+static thread_local int g_gemm_small_split = -1;
 static int opt_or_env(int& slot, const char* env, int dflt = 0) {
   if (slot < 0) {
     const char* e = getenv(env);

@@ -7,6 +7,7 @@ path here by design (the CPU restatement lives in oracle/, for tests only).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Sequence, Optional, Tuple
 
@@ -271,7 +272,17 @@ def get_option(key: str) -> int:
     v = C.c_int32(0)
     _hip.check(_hip.load().ifx_get_option(key.encode(), C.byref(v)), "ifx_get_option")
     _OPTIONS[key] = int(v.value)
+    if key == "gemm_small_split":
+        _TLS.small_split = int(v.value)
     return int(v.value)
+
+
+_TLS = threading.local()     # gemm_small_split is per host thread in the library (ifx_core.hip); so is its mirror here
+
+
+def _small_split() -> int:
+    v = getattr(_TLS, "small_split", None)
+    return get_option("gemm_small_split") if v is None else v
 
 
 def device_error(clear: bool = True) -> int:
@@ -292,6 +303,8 @@ def set_option(key: str, value: int) -> None:
     'spin_timeout_ms', 'spin_fault' (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
     _OPTIONS[key] = int(value)
+    if key == "gemm_small_split":
+        _TLS.small_split = int(value)
     if key == "attn_variant":
         _SPLIT_PLAN.clear()      # the split plan depends on the attention schedule
     if key == "gemm_variant":
@@ -524,7 +537,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, ep
         r2, c2, ld2 = _rows2d(out2, "out2")
         assert r2 == M and c2 == N - split_col and 0 < split_col < N, (out2.shape, M, N, split_col)
         epi.y2, epi.ldy2, epi.split_col = _dev(out2, "out2"), ld2, int(split_col)
-    wkey = (M, N, K, _OPTIONS.get("gemm_small_split", 0))
+    wkey = (M, N, K, _small_split())
     need = _GEMM_WS_NEED.get(wkey) if out2 is None else 0          # the two-destination launch takes no workspace (bias epilogue, unsplit)
     if need is None:
         need = _GEMM_WS_NEED[wkey] = int(lib.ifx_gemm_workspace_bytes(M, N, K))
@@ -586,7 +599,7 @@ def linear_q8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale
         assert mod.dim() == 3 and mod.shape[-1] == N and mod.is_contiguous()
         assert rows_per_group > 0 and M <= mod.shape[0] * rows_per_group, "mod table does not cover every output row"
         epi.mod, epi.mod_slots, epi.gate_slot, epi.rows_per_group = _dev(mod, "mod"), mod.shape[1], gate_slot, rows_per_group
-    wkey = ("q8", M, N, K, _OPTIONS.get("gemm_small_split", 0))
+    wkey = ("q8", M, N, K, _small_split())
     need = _GEMM_WS_NEED.get(wkey)
     if need is None:
         need = _GEMM_WS_NEED[wkey] = int(lib.ifx_gemm_q8_workspace_bytes(M, N, K))

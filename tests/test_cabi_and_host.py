@@ -470,6 +470,13 @@ def test_get_option_reads_the_library_and_option_scope_restores_what_it_found():
         with ops.option_scope("gemm_small_split", 0):
             assert ops.get_option("gemm_small_split") == 0
         assert ops.get_option("gemm_small_split") == 1, "the scope must restore the value it found in the library"
+        # ... and it is the CALLER's property: a launch another host thread enqueues meanwhile (VAE, text encoder) keeps its own value
+        import threading
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(ops.get_option("gemm_small_split")))
+        th.start()
+        th.join()
+        assert seen == [0], "gemm_small_split must be per host thread"
     finally:
         assert lib.ifx_set_option(b"gemm_small_split", 0) == 0
     assert ops.get_option("gemm_small_split") == 0
