@@ -30,6 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver stack
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # a sequence-parallel rank runs two launch chains + two exchange streams whose wait kernels spin on device: with the runtime's
+    # default of 4 hardware queues torch's pool streams share queues (tools/probe_stream_queues.py: pool2 / pool3, pool0 / pool5 ...)
+    # and everything enqueued behind a spinning wait in the same queue stands still; 8 queues keep the first five streams apart
+    # (measured neutral on one GPU: profiles/r5_stream_queues.md)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 # gfx950 peaks (MI355X_MICROARCH.md): dense bf16 MFMA ~2.5 PFLOP/s, HBM3E 8 TB/s
