@@ -366,6 +366,14 @@ class PeerStoreExchange:
             self.flags.free()
 
 
+def _comm_priority() -> int:
+    """Priority of the exchange streams (lab switch IFX_SP_COMM_PRIORITY: 0 = default, -1 = high).  The exchange launches are short and
+    everything behind them waits for the peers' rows; with a second launch chain on the chip their workgroups otherwise queue behind the
+    other chain's long kernels."""
+    import os
+    return int(os.environ.get("IFX_SP_COMM_PRIORITY", "0"))
+
+
 def _lab_single_attention() -> bool:
     import os
     return os.environ.get("IFX_SP_SINGLE_ATTN", "") == "1"
@@ -443,7 +451,7 @@ class HipSequenceParallel:
         if side:
             comm = self._comm_streams.get(chain)
             if comm is None:
-                comm = self._comm_streams[chain] = torch.cuda.Stream(device=dev)
+                comm = self._comm_streams[chain] = torch.cuda.Stream(device=dev, priority=_comm_priority())
                 if chain == 0:
                     self.comm_stream = comm
             comm.wait_stream(main)
