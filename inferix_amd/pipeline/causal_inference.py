@@ -211,6 +211,9 @@ class CausalInferencePipeline(torch.nn.Module):
             if block_callback is not None and x0 is not None:
                 block_callback(output[:, cur - nf:cur], block_index)
 
+        cp = getattr(getattr(self.generator, "model", None), "cp", None)
+        if cp is not None and hasattr(cp, "check_now"):
+            cp.check_now()             # a sequence-parallel rank: a peer-store wait that gave up is reported before the clip is handed out
         if free_cache_before_vae:
             self.clear_cache(kv_cache_manager, kv_cache_requests)
         if decode_mode == DecodeMode.NO_DECODE:

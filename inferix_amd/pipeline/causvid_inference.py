@@ -156,6 +156,9 @@ class CausVidInferencePipeline(torch.nn.Module):
                 pending = self._gen_kw(x0, cond, t0, blk, kv_cache_manager, kv_cache_requests)
             else:
                 self._gen(x0, cond, t0, blk, kv_cache_manager, kv_cache_requests)
+        cp = getattr(getattr(self.generator, "model", None), "cp", None)
+        if cp is not None and hasattr(cp, "check_now"):
+            cp.check_now()             # a sequence-parallel rank: a peer-store wait that gave up is reported before the clip is handed out
         if not decode or self.vae is None:
             return (output, output) if return_latents else output
         chunk = vae_chunk_size if vae_chunk_size is not None else 2

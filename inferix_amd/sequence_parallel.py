@@ -366,6 +366,11 @@ class PeerStoreExchange:
             self.flags.free()
 
 
+def _lab_emulated_check() -> bool:
+    import os
+    return os.environ.get("IFX_SP_LAB_CHECK") == "1"
+
+
 def _comm_priority() -> int:
     """Priority of the exchange streams (lab switch IFX_SP_COMM_PRIORITY: 0 = default, -1 = high).  The exchange launches are short and
     everything behind them waits for the peers' rows; with a second launch chain on the chip their workgroups otherwise queue behind the
@@ -404,6 +409,13 @@ class HipSequenceParallel:
         # front of the peer stores (two flag round trips + 3.6 MB per link), which the prefix attention covers from the second block on.
         self.kv_first = (peer is None) if kv_first is None else kv_first
         self.overlap = overlap
+        # the peer-store waits report a timeout through a status word; reading it is a host synchronisation (+ one small collective so
+        # that every rank raises together).  Once per forward would drain the launch queue 35 times per clip: the word is sticky, every
+        # rank runs the same collectives whether or not a wait gave up, so the check runs every `check_every` forwards (default: a
+        # block's five) and once more when the pipeline finishes a clip (`check_now`).
+        import os
+        self.check_every = max(1, int(os.environ.get("IFX_SP_CHECK_EVERY", "5")))
+        self._forwards_since_check = 0
         self.comm_stream: Optional[torch.cuda.Stream] = None      # chain 0's side stream (kept under this name for the tests / tools)
         self._comm_streams: Dict[int, torch.cuda.Stream] = {}     # chain -> side stream (HipCausalWanModel.forward_pair runs two chains)
         self._buf: Dict[Tuple, torch.Tensor] = {}
@@ -531,9 +543,21 @@ class HipSequenceParallel:
 
     def gather_head(self, y_local: torch.Tensor, batch: int, frames: int) -> torch.Tensor:
         out = self.ex.gather_head(y_local, batch, frames)
-        if self.peer is not None and not self.peer.emulated:
-            self.peer.check()
+        self._forwards_since_check += 1
+        if self._forwards_since_check >= self.check_every:
+            self.check_now()
         return out
+
+    def check_now(self) -> None:
+        """Raise on every rank together if a peer-store wait gave up since the last check (collective + host synchronisation; a no-op
+        without a peer-store exchange).  The pipelines call it at the end of a clip."""
+        self._forwards_since_check = 0
+        if self.peer is None:
+            return
+        if not self.peer.emulated:
+            self.peer.check()
+        elif _lab_emulated_check():
+            int(self.peer.status.item())       # LAB (IFX_SP_LAB_CHECK=1): the host synchronisation of a real rank's check, without the collective
 
     def preflight(self, model, height: int, width: int, frames: int = 3, reps: int = 3) -> dict:
         """First contact with the interconnect, before anything is timed (collective: every rank calls it).  ONE layer's exchange of a
@@ -632,12 +656,11 @@ def attach_sequence_parallel(model, group=None, overlap: bool = True,
     """Enable sequence parallelism on a HipCausalWanModel whose ParallelConfig has world_size > 1."""
     sp = HipSequenceParallel(group, overlap, exchange, peer, kv_first)
     # a rank's launches have 4680 / P rows: the GEMM tile choice may split K inside a workgroup for them (row-count dependent bits,
-    # which the default choice avoids; the row count of a rank is fixed by P).  The option is process-global in the library, so it is
-    # scoped to THIS model's forwards (HipCausalWanModel.forward: hip_ops.option_scope, which reads the library's own value back on
-    # entry: ifx_get_option) and every other GEMM enqueued by this thread OUTSIDE those forwards — a second, unsharded model, the umT5
-    # encoder, the VAE — keeps its row-count-invariant summation order.  What the scope cannot cover (ADVICE r4): GEMMs enqueued by
-    # ANOTHER host thread while this model is inside its forward see the option too (tile selection happens at enqueue time, per
-    # process); run such work from the thread that drives the model, as the pipelines do.
+    # which the default choice avoids; the row count of a rank is fixed by P).  The option is scoped to THIS model's forwards
+    # (HipCausalWanModel.forward: hip_ops.option_scope, which reads the library's own value back on entry: ifx_get_option): every other
+    # GEMM enqueued by this thread OUTSIDE those forwards — a second, unsharded model, the umT5 encoder, the VAE — keeps its
+    # row-count-invariant summation order, and so does whatever ANOTHER host thread enqueues meanwhile: the library keeps the option per
+    # host thread (ifx_core.hip; ADVICE r4).
     sp.gemm_small_split = True
     pc = model.parallel_config
     if pc.world_size != sp.ex.world or pc.rank != sp.ex.rank:

@@ -153,3 +153,36 @@ def test_reference_launcher_parallel_config_two_ranks():
     ret = mp.Manager().dict()
     mp.spawn(_launcher_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_peer_store_timeout_check_runs_once_per_block_and_at_the_end_of_a_clip():
+    """The peer-store waits report a timeout through a sticky status word; reading it synchronises the host and runs a small collective.
+    `HipSequenceParallel` does that every `check_every` forwards (default 5 = a block) and when the pipeline finishes a clip
+    (`check_now`), not once per forward — every rank runs the same collectives either way, so the cadence cannot split the group."""
+    from inferix_amd.sequence_parallel import HipSequenceParallel, LoopbackExchange
+
+    class FakePeer:
+        emulated, world, rank = False, 2, 0
+
+        def __init__(self):
+            self.checks = 0
+
+        def check(self):
+            self.checks += 1
+
+    peer = FakePeer()
+    sp = HipSequenceParallel(exchange=LoopbackExchange(2, 0), peer=peer)
+    assert sp.check_every == 5
+    y = torch.zeros(3 * 4, 2)
+    for i in range(12):
+        sp.gather_head(y, 1, 3)
+        assert peer.checks == (i + 1) // 5
+    sp.check_now()                                   # what the pipelines call before they hand a clip out
+    assert peer.checks == 3
+    for _ in range(4):
+        sp.gather_head(y, 1, 3)
+    assert peer.checks == 3, "check_now restarts the count"
+    sp.gather_head(y, 1, 3)
+    assert peer.checks == 4
+    sp.peer = None
+    sp.check_now()                                   # no peer-store exchange: nothing to read
