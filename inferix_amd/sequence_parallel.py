@@ -502,9 +502,15 @@ class HipSequenceParallel:
         scale = getattr(model, "_attn_scale", 0.0)    # ln 2 when q carries scale * log2(e) (hip_ops.attn_q_prescale), else the default
 
         def arrived():
+            # the wait for the peers' rows goes on the EXCHANGE stream, behind this rank's own push: the main stream then has one
+            # cross-stream dependency in front of the attention over the new block instead of that dependency + a wait launch of its own
+            # (one dependent launch less per layer on the critical path of a real rank; the emulated rank has no wait kernels at all)
             if st["side"]:
+                if self.peer is not None:
+                    with torch.cuda.stream(st["comm"]):
+                        self.peer.wait_done(st["layer"], st["epoch"])
                 torch.cuda.current_stream(dev).wait_stream(st["comm"])
-            if self.peer is not None:
+            elif self.peer is not None:
                 self.peer.wait_done(st["layer"], st["epoch"])
 
         if st["side"] and st["have_prefix"] and _lab_single_attention():
