@@ -291,9 +291,16 @@ def device_error(clear: bool = True) -> int:
     return int(_hip.load().ifx_device_error(1 if clear else 0))
 
 
-def check_device(what: str = "") -> None:
-    """Raise if a kernel gave up a device-side wait since the last check (call after a synchronisation)."""
+def check_device(what: str = "", sync: bool = False) -> None:
+    """Raise if a kernel gave up a device-side wait since the last check.  The word is meaningful for work that has completed:
+    `sync=True` synchronises the current stream first (the pipelines do this once per clip, before the clip is handed out — a split-K
+    consumer that gave up leaves garbage in its tile, and without this check the clip would ship silently corrupt: ADVICE r5).
+    On an error the split-K workspaces are dropped before raising: the consumer that gave up zeroed the tile's flags, a late
+    producer may have raised one afterwards, and the next launch on that workspace relies on 'all flags zero on entry'."""
+    if sync and torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
     if device_error(clear=False):
+        _GEMM_WS.clear()
         msg = _hip.load().ifx_last_error().decode("utf-8", "replace")       # reports and clears the word
         raise _hip.HipKernelError(f"{what + ': ' if what else ''}{msg}")
 

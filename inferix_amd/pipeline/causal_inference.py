@@ -21,6 +21,8 @@ from typing import Callable, List, Optional, Sequence, Union
 
 import torch
 
+from ..schedulers import const_timestep
+
 from ..core.types import DecodeMode
 from ..kvcache_manager import KVCacheManager, KVCacheRequest
 
@@ -65,14 +67,15 @@ class CausalInferencePipeline(torch.nn.Module):
 
     def _timestep(self, value, shape, device, dtype=torch.int64) -> torch.Tensor:
         """`torch.ones(shape) * value` (CausalInferencePipeline.py:330,371), ONE tensor per (value, shape) reused across blocks: the
-        model and the x0 / add_noise conversions memoise what they derive from a timestep tensor on its identity (the modulation
-        tables, the sigma lookups) — ~25 glue launches per forward less.  Never written in place."""
+        model and the x0 / add_noise conversions memoise what they derive from a timestep tensor (the modulation tables, the sigma
+        lookups) on the scalar it holds — `schedulers.const_timestep` tags the tensor with it — ~25 glue launches per forward less.
+        A tagged tensor is a constant: never written, in place or through a raw pointer."""
         key = (float(value), tuple(shape), str(device), dtype)
         t = self._ts_cache.get(key)
         if t is None:
             if len(self._ts_cache) >= 32:
                 self._ts_cache.clear()
-            t = self._ts_cache[key] = torch.ones(list(shape), device=device, dtype=dtype) * value
+            t = self._ts_cache[key] = const_timestep(value, shape, device, dtype)
         return t
 
     def _gen(self, x, cond, timestep, start_frame, kvm, reqs):
@@ -214,6 +217,9 @@ class CausalInferencePipeline(torch.nn.Module):
         cp = getattr(getattr(self.generator, "model", None), "cp", None)
         if cp is not None and hasattr(cp, "check_now"):
             cp.check_now()             # a sequence-parallel rank: a peer-store wait that gave up is reported before the clip is handed out
+        if output.is_cuda:
+            from .. import hip_ops
+            hip_ops.check_device("CausalInferencePipeline.inference", sync=True)    # a split-K wait that gave up: the clip is garbage — raise, do not ship it
         if free_cache_before_vae:
             self.clear_cache(kv_cache_manager, kv_cache_requests)
         if decode_mode == DecodeMode.NO_DECODE:

@@ -17,6 +17,8 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
+from ..schedulers import const_timestep
+
 from ..kvcache_manager import KVCacheManager, KVCacheRequest
 
 
@@ -93,14 +95,15 @@ class CausVidInferencePipeline(torch.nn.Module):
 
     def _timestep(self, value, shape, device, dtype=torch.int64) -> torch.Tensor:
         """`torch.ones(shape) * value`, one tensor per (value, shape) reused across blocks (the model memoises its modulation tables
-        and the sigma lookups on the timestep tensor's identity; see CausalInferencePipeline._timestep).  Never written in place."""
+        and the sigma lookups on the scalar a `schedulers.const_timestep` tensor holds; see CausalInferencePipeline._timestep).
+        Never written, in place or through a raw pointer."""
         cache = self.__dict__.setdefault("_ts_cache", {})
         key = (float(value), tuple(shape), str(device), dtype)
         t = cache.get(key)
         if t is None:
             if len(cache) >= 32:
                 cache.clear()
-            t = cache[key] = torch.ones(list(shape), device=device, dtype=dtype) * value
+            t = cache[key] = const_timestep(value, shape, device, dtype)
         return t
 
     def inference(self, noise: torch.Tensor, text_prompts: List[str], start_latents: Optional[torch.Tensor],
@@ -159,6 +162,9 @@ class CausVidInferencePipeline(torch.nn.Module):
         cp = getattr(getattr(self.generator, "model", None), "cp", None)
         if cp is not None and hasattr(cp, "check_now"):
             cp.check_now()             # a sequence-parallel rank: a peer-store wait that gave up is reported before the clip is handed out
+        if output.is_cuda:
+            from .. import hip_ops
+            hip_ops.check_device("CausVidInferencePipeline.inference", sync=True)    # a split-K wait that gave up: the clip is garbage — raise, do not ship it
         if not decode or self.vae is None:
             return (output, output) if return_latents else output
         chunk = vae_chunk_size if vae_chunk_size is not None else 2

@@ -415,6 +415,13 @@ class HipSequenceParallel:
         # block's five) and once more when the pipeline finishes a clip (`check_now`).
         import os
         self.check_every = max(1, int(os.environ.get("IFX_SP_CHECK_EVERY", "5")))
+        if peer is not None and not peer.emulated and dist.is_available() and dist.is_initialized() and self.ex.world > 1:
+            # `peer.check()` is a collective: ranks that disagree on the cadence would issue it at different forwards and deadlock
+            # (ADVICE r5).  The environment is per process, so the value is validated over the group once, here.
+            seen = [None] * self.ex.world
+            dist.all_gather_object(seen, self.check_every, group=self.ex.group)
+            if len(set(seen)) != 1:
+                raise ValueError(f"IFX_SP_CHECK_EVERY differs between ranks {seen}: the peer-store status check is a collective")
         self._forwards_since_check = 0
         self.comm_stream: Optional[torch.cuda.Stream] = None      # chain 0's side stream (kept under this name for the tests / tools)
         self._comm_streams: Dict[int, torch.cuda.Stream] = {}     # chain -> side stream (HipCausalWanModel.forward_pair runs two chains)

@@ -411,8 +411,10 @@ class HipCausalWanModel(torch.nn.Module):
             # V straight into the cache (ifx_epilogue.y2): one sample, a contiguous cache (no page table / segment map), a launch the
             # ping-pong tiles serve, bf16 weights.  The rope / append kernel then moves q and K only: a third of its 86 MB less.
             step0, view0 = planned[0]
+            # (ifx_gemm_bf16 serves y2 on the automatic selection and the ping-pong variants 22..25 only: under a lab variant — the tools'
+            #  IFX_GEMM_VARIANT sweeps — the V columns take the copy path instead of failing the forward)
             if (self.v_direct and len(samples) == 1 and B * N >= 2048 and "qkv_q" not in w and view0.page_table is None
-                    and not view0.seg_split and d % 256 == 0):
+                    and not view0.seg_split and d % 256 == 0 and ops.get_option("gemm_variant") in (0, 22, 23, 24, 25)):
                 v_direct = view0.v.view(view0.v.shape[0], d)[step0.local_start:step0.local_start + N]
         if not kv_first:
             extra = dict(out2=v_direct, split_col=2 * d) if v_direct is not None else {}
@@ -647,21 +649,27 @@ class HipCausalWanModel(torch.nn.Module):
             patches = patches.view(B * F_, fs, -1)[:, cp_rank * hw_local:(cp_rank + 1) * hw_local].reshape(B * N, -1)
         xact = ops.linear(patches.contiguous(), self.g["patch_w"], self.g["patch_b"],
                           out=self._buf("x", B * N, d) if xact_out is None else xact_out)
-        t = t.to(dev)
         Ft = t.shape[1]                                                          # frames carrying a timestep (F or 1)
         rows_per_group = (F_ // Ft) * fs_l
-        # The modulation tables are a function of the timestep tensor alone (and of the weights): a clip has five distinct ones (four
-        # denoising steps + the clean-context re-run) over 35 forwards.  Memoised on the tensor's identity — storage address, version
-        # counter (bumped by any in-place write) and shape — with the tensor itself kept alive in the entry, so that no other tensor can
-        # come to live at that address while the entry exists.  ~16 glue launches (sinusoid, three small GEMMs, SiLUs, the two table
-        # adds) per forward less; the same bits (the pipelines reuse one timestep tensor per step value, inferix_amd/pipeline).
-        tkey = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, self.g["time0_w"].data_ptr(), self.g.get("time0_fmt"))
-        hit = self._temb_cache.get(tkey)
+        # The modulation tables are a function of the timestep VALUES alone (and of the weights): a clip has five distinct ones (four
+        # denoising steps + the clean-context re-run) over 35 forwards.  Memoised for the pipelines' own constant timestep tensors only
+        # (schedulers.const_timestep: every entry = one scalar the host knows), keyed on that scalar + shape — never on a storage
+        # address or a version counter, which a raw-pointer write would not move and inference tensors do not have.  Any other
+        # timestep tensor is embedded every call.  ~16 glue launches (sinusoid, three small GEMMs, SiLUs, the two table adds) per
+        # forward less; the same bits.
+        from ..schedulers import carry_tag, const_tag
+        t_in = t
+        t = carry_tag(t_in, t.to(dev))
+        tc = const_tag(t)
+        tkey = None if tc is None else (tc, tuple(t.shape), t.dtype, self.g["time0_w"].data_ptr(), self.g.get("time0_fmt"))
+        hit = self._temb_cache.get(tkey) if tkey is not None else None
         stream_now = ops._stream()
         if hit is not None:
             E, eh = hit[1], hit[2]
-            if hit[3] != stream_now:                  # allocated on the other chain's stream: tell the allocator this stream reads them too
-                cur = torch.cuda.current_stream(dev)
+            if hit[3] != stream_now:                  # made on the other chain's stream: order this stream behind the kernels that wrote
+                cur = torch.cuda.current_stream(dev)  # them (record_stream guards the allocation, not the data) and tell the
+                if hit[0] is not None:                # allocator this stream reads them too
+                    cur.wait_event(hit[0])
                 E.record_stream(cur)
                 eh.record_stream(cur)
         else:
@@ -671,9 +679,13 @@ class HipCausalWanModel(torch.nn.Module):
             e0 = self._lin(self.g, "tproj", F.silu(e)).unflatten(1, (6, d))                         # [B*Ft, 6, d]
             E = (self.mod_all + e0.unsqueeze(0)).contiguous()                        # [L, B*Ft, 6, d] bf16
             eh = (self.g["head_mod"] + e.unsqueeze(1)).contiguous()                  # [B*Ft, 2, d]
-            if len(self._temb_cache) >= 16:
-                self._temb_cache.pop(next(iter(self._temb_cache)))
-            self._temb_cache[tkey] = (t, E, eh, stream_now)
+            if tkey is not None:
+                if len(self._temb_cache) >= 16:
+                    self._temb_cache.pop(next(iter(self._temb_cache)))
+                ready = torch.cuda.Event() if t.is_cuda else None
+                if ready is not None:
+                    ready.record(torch.cuda.current_stream(dev))
+                self._temb_cache[tkey] = (ready, E, eh, stream_now)
 
         need_ctx = any(not m["is_init"] for m in crossattn_cache_meta)
         ctx = None

@@ -64,11 +64,13 @@ class HipWanDiffusionWrapper(torch.nn.Module):
     def _convert_flow_pred_to_x0(self, flow_pred: torch.Tensor, xt: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
         """x0 = x_t - sigma_t * flow in fp64, sigma picked by nearest timestep (wrapper.py:259-283)."""
         dev = flow_pred.device
-        if self._sig64 is None or self._sig64[0].device != dev:
-            self._sig64 = (self.scheduler.sigmas.double().to(dev), self.scheduler.timesteps.double().to(dev))
-        sig, ts = self._sig64
-        # the sigma of a timestep tensor is looked up once per tensor (memoised on its identity: a clip reuses five of them)
-        sigma = self._sigma_memo.get(timestep, (str(dev), sig.data_ptr()), lambda: sig[torch.argmin(
+        epoch = getattr(self.scheduler, "table_epoch", 0)
+        if self._sig64 is None or self._sig64[0].device != dev or self._sig64[2] != epoch:
+            self._sig64 = (self.scheduler.sigmas.double().to(dev), self.scheduler.timesteps.double().to(dev), epoch)
+        sig, ts, _ = self._sig64
+        # the sigma of a pipeline-made constant timestep tensor is looked up once per value (schedulers.TensorMemo: keyed on the
+        # host-known scalar, never on a storage address; any other tensor is looked up every call)
+        sigma = self._sigma_memo.get(timestep, (str(dev), epoch), lambda: sig[torch.argmin(
             (ts.unsqueeze(0) - timestep.to(dev).double().unsqueeze(1)).abs(), dim=1)].reshape(-1, 1, 1, 1))
         return (xt.double() - sigma * flow_pred.double()).to(flow_pred.dtype)
 
@@ -88,8 +90,9 @@ class HipWanDiffusionWrapper(torch.nn.Module):
                           current_start=current_start, cache_start=cache_start,
                           kv_cache_manager=kv_cache_manager, kv_cache_requests=kv_cache_requests
                           ).permute(0, 2, 1, 3, 4)
+        from ..schedulers import carry_tag
         x0 = self._convert_flow_pred_to_x0(flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1).to(flow.device),
-                                           timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])
+                                           carry_tag(timestep, timestep.flatten(0, 1))).unflatten(0, flow.shape[:2])
         return flow, x0
 
 
