@@ -151,6 +151,7 @@ int gemm_small_split();   // 1: launches of at most one workgroup per CU may spl
 unsigned* device_error_word();    // pinned host word, mapped into every device, that a kernel raises when it gives up a wait (ifx_core.hip); may be nullptr
 long long spin_timeout_ticks();   // budget of a device-side wait in ticks of the 100 MHz wall clock (option "spin_timeout_ms", default 2000 ms)
 int spin_fault();                 // lab / tests: 1 = split-K producers do not raise their flag, so that the consumer's wait runs into its budget
+int conv_variant();   // 0 auto (persistent ping-pong kernel where it applies), 1 the lock-step kernel of round 1
 int attn_variant();   // 0 auto (= 7 for large launches), 1 four-wave kernel, 2 ping-pong, 3 three groups, 4 free-running, 5 software-pipelined, 6 its two-per-CU form, 7 its four-times-unrolled form
 
 }  // namespace ifx

@@ -45,6 +45,7 @@ struct ConvArgs {
   int in_slot[MAXF], out_slot[MAXF];
   int Hs, Ws, Cin, Ho, Wo, Cout, KT, t_out;
   int tiles_w, tiles_h, tiles_n, per_xcd, total;
+  unsigned long long* trace;      // lab builds (-DIFX_CONVPP_TRACE=1): segment cycle sums of workgroup 0's waves 0 and 4
   int ablate;      // IFX_CONV_ABLATE bit mask (timing experiments only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no stores
 };
 
@@ -337,6 +338,504 @@ static void launch(const ConvArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((conv_cl_kernel<BN, UPS, KS>), dim3(a.per_xcd * 8), dim3(512), G::LDS, s, a);
 }
 
+// =====================================================================================================================
+// Round 6: the same convolution as a PERSISTENT PING-PONG kernel (`conv_pp_kernel`), the structure of ifx_gemm_pp.hip.
+//
+// Why (tools/ablate_conv.sh, round 6, 96 -> 96 @ 480 x 832 x 12 frames): with the kernel's parts switched off one at a time the
+// lock-step loop above loses 25 % without MFMAs, 25 % without fragment reads, 27 % without DMA and 13 % without the epilogue — the
+// four serialise instead of overlapping (both waves of a SIMD issue DMA, then both read fragments, then both want the matrix pipe;
+// the epilogue of a tile runs with the matrix pipe idle because the rings double as its transpose scratch: one workgroup per CU).
+// Here, per SIMD, the two waves alternate roles every phase (one barrier per phase):
+//
+//   phase 2g   : group 0 (waves 0-3, tile rows 0-3)  36 MFMAs of step g from registers | group 1 (rows 4-7)  patch DMA, fragments of step g
+//   phase 2g+1 : group 0  weight DMA, fragment reads of step g+1                     | group 1  36 MFMAs of step g
+//
+//   * a step = one kernel row (3 taps) of one stage (input frame dt, 32-channel chunk cc): 12 patch + 18 weight ds_read_b128 = 120
+//     fragment registers, ALL read in the wave's loader phase; the MFMA phase holds nothing but MFMAs.  (A first version issued the
+//     weight DMA at the head of group 1's MFMA phase: an LDS-DMA instruction blocks its wave until the CU's vector-memory path takes
+//     it — 200-380 cycles per 1 KiB piece in this loop, s_memtime trace in DESIGN.md — and that wave's MFMAs wait behind it.)
+//   * LDS: two patch slots (the (8+2) x (64+2) halo of a stage, as above), a weight ring of TWO steps, and four 32-pixel transpose
+//     regions for the epilogue that are NOT part of the rings — so the request stream runs across output tiles: the first stages of
+//     tile i+1 are in flight while tile i's last steps are multiplied, and a group's epilogue (bias, bf16, + residual, whole-pixel
+//     stores) runs in its loader phase under the other group's MFMAs.
+//   * group 0 requests the weights of step g+2 in its loader phase 2g+1 (the slot's last reader was group 1 in phase 2g) and waits
+//     vmcnt(0) at the end of its MFMA phase 2g+2: visible from phase 2g+3, where group 0 itself reads them.  Group 1 requests the
+//     patch of stage t+1 in its loader phases 6t and 6t+2 (half of its pieces each; the slot's last reader was group 1 itself in phase
+//     6t-2) and waits at the head of its loader phase 6t+4: visible from phase 6t+5, where group 0 reads the first fragments of
+//     stage t+1.  Every request has at least one whole MFMA phase (>= 1152 matrix-pipe cycles) to land, the patch (HBM) three.
+//   * DMA by inline asm through buffer descriptors (hipcc fences every later ds_read behind a `global_load_lds` builtin with
+//     vmcnt(0)); padding pixels and the zero frames in front of the stream are out-of-range offsets / empty descriptors, which
+//     return zeros: no zero page.  A loader wave interleaves its DMA instructions with its fragment reads (the reads do not wait
+//     for the vector-memory path).
+//   * patch swizzle by COLUMN ((col >> 2) & 3, not by linear patch pixel): a fragment address is a wave-uniform row base + a
+//     lane term that does not depend on the row — half the address arithmetic of the lock-step kernel's loader.
+//   * tile order: channel tile fastest, then OUTPUT FRAME, then the spatial tile: the workgroups resident on an XCD work on
+//     consecutive ids = the same spatial tile of consecutive frames, whose three input frames overlap two by two in that XCD's L2.
+//   * arithmetic, K order (dt, cc, dh, dw, 16-channel k-step), epilogue rounding: those of conv_cl_kernel — bit-identical outputs
+//     (tools/bench_conv.py compares the two kernels bit for bit on every shape it times).
+namespace pp {
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+#ifndef IFX_CONVPP_TRACE
+#define IFX_CONVPP_TRACE 0      // 1: s_memtime segment sums of workgroup 0 (printed by the launcher after a synchronisation; lab only)
+#endif
+#if IFX_CONVPP_TRACE
+#define CP_STAMP(i)                                                \
+  do {                                                             \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    seg[i] += t_now - t_last;                                      \
+    t_last = t_now;                                                \
+  } while (0)
+#else
+#define CP_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
+__device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ v4i make_rsrc(const void* base, unsigned num_bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xffffu);      // stride 0: raw buffer, byte offsets, reads past num_bytes return 0
+  r[2] = (int)num_bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }       // lgkmcnt(0), known to hipcc's scoreboard
+
+template <int BN, int UPS>
+struct GeoP {
+  static constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2;
+  static constexpr int NP = PH * PW, NPI = (NP + 15) / 16;
+  static constexpr int PPW = (NPI + 3) / 4;             // patch piece slots per wave of group 1 and stage
+  static constexpr int QA = (PPW + 1) / 2;              // of which in the first of the stage's two batches
+  static constexpr int P_SLOT = NPI * 1024;
+  static constexpr int WP = BN / 16;                    // 1 KiB weight pieces per tap
+  static constexpr int W_TAP = BN * 64, W_STEP = 3 * W_TAP;
+  static constexpr int WPS = 3 * WP, WPW = (WPS + 3) / 4;      // weight pieces per step / piece slots per wave of group 0 and step
+  static constexpr int PITCH = BN * 2 + 16, SCR = 32 * PITCH;  // transpose region of one wave: 32 pixels x BN channels
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, E_OFF = W_OFF + 2 * W_STEP, LDS = E_OFF + 4 * SCR;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(SCR % 16 == 0 && P_SLOT % 16 == 0 && W_STEP % 16 == 0, "alignment");
+};
+
+struct Tile {
+  int to, h0, w0, n_base;
+};
+
+template <int BN, int UPS>
+__global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
+  using G = GeoP<BN, UPS>;
+  constexpr int TI = BN / 32, TJ = 2, PW = G::PW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+
+  // ---- this workgroup's tiles: XCD (bid & 7) owns ids [xcd * per_xcd, ...), its workgroups take them round-robin
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3, wgx = (int)gridDim.x >> 3;
+  const int id_first = xcd * A.per_xcd + slot_i;
+  const int id_end = min(xcd * A.per_xcd + A.per_xcd, A.total);
+  if (id_first >= id_end) return;
+  const int n_my = (id_end - id_first + wgx - 1) / wgx;
+  const int CC = A.Cin >> 5, S = A.KT * CC, U = 3 * S, GT = n_my * U;
+  const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem;
+  auto tile_of = [&](int i) __attribute__((always_inline)) {
+    int rem = id_first + i * wgx;
+    Tile t;
+    const int nt = rem % A.tiles_n;
+    rem /= A.tiles_n;
+    t.to = rem % A.t_out;
+    rem /= A.t_out;
+    const int tw = rem % A.tiles_w;
+    t.h0 = (rem / A.tiles_w) * TH;
+    t.w0 = tw * TW;
+    t.n_base = nt * BN;
+    return t;
+  };
+
+  // ---- reader side.  (Lane-derived addressing is re-derived from an opaque lane id at every call: hipcc otherwise hoists the
+  //      per-tap pixel columns and the weight-row offsets out of the step loop — ~20 registers held across a loop that runs at 96
+  //      accumulators + 120 fragment registers — and spills fragments into the MFMA phase.)
+  bf16x8 fa[3][2][TJ], fb[3][2][TI];
+  // fragments of kernel row r of the stage in patch slot ps, weights in ring slot ws; `between(tg)` runs ahead of tap tg's reads (the
+  // loader's DMA instructions go there: the reads queue up at the LDS while the wave sits in a DMA issue stall)
+  auto read_frags = [&](int r, int ps, int ws, auto between) __attribute__((always_inline)) {
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
+    const int f31 = ln & 31, fhi = ln >> 5;
+    const unsigned char* pb = smem + G::P_OFF + ps * G::P_SLOT + (UPS ? (wave + r + 1) >> 1 : wave + r) * (PW * 64);
+    const unsigned char* wg = smem + G::W_OFF + ws * G::W_STEP;
+#pragma unroll
+    for (int tg = 0; tg < 3; ++tg) {
+      between(tg);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = UPS ? (j * 32 + f31 + tg + 1) >> 1 : j * 32 + f31 + tg;
+        const int sw = (col >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fa[tg][ks][j] = *reinterpret_cast<const bf16x8*>(pb + col * 64 + (((2 * ks + fhi) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int n = i * 32 + f31;
+        const int bo = n * 64 + (((n >> 2) & 3) << 4);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fb[tg][ks][i] = *reinterpret_cast<const bf16x8*>(wg + tg * G::W_TAP + (bo ^ ((2 * ks + fhi) << 4)));
+      }
+    }
+  };
+  f32x16 acc[TI][TJ];
+  auto mfma_first = [&]() __attribute__((always_inline)) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][0][i], fa[0][0][j], z, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][1][i], fa[0][1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int tg = 1; tg < 3; ++tg)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tg][ks][i], fa[tg][ks][j], acc[i][j], 0, 0, 0);
+  };
+  auto mfma_next = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tg = 0; tg < 3; ++tg)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tg][ks][i], fa[tg][ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- epilogue of tile `t` for this wave (image row `wave` of the tile): 32-pixel blocks one at a time through the wave's transpose
+  //      region (shared by wave w4 of both groups: their epilogues run in different phases), whole pixel rows out, as above.  The
+  //      residual rows of BOTH blocks are requested first (one memory round trip per epilogue; the fragment registers are free here).
+  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));                      // lane-derived addressing re-derived here: it would stay live across the K loop
+    const int e31 = ln & 31, ehi = ln >> 5;
+    constexpr int PITCH = G::PITCH, CR = BN / 8, NIT = (32 * CR + 63) / 64;
+    unsigned char* tr = smem + G::E_OFF + w4 * G::SCR;
+    const int oh = t.h0 + wave;
+#ifdef IFX_CONVPP_NORES
+    const unsigned short* rf = nullptr;               // lab: what does the epilogue cost without the residual rows?
+#else
+    const unsigned short* rf = A.res ? A.res + (long long)t.to * A.Ho * A.Wo * A.Cout : nullptr;
+#endif
+    const bool row_ok = oh < A.Ho;
+    u16x8 rv[TJ][NIT];
+    if (rf != nullptr) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int idx = it * 64 + ln;
+          const int p = idx / CR, c = idx - p * CR;
+          const int ow = t.w0 + j * 32 + p;
+          const bool ok = row_ok && p < 32 && ow < A.Wo;
+          const size_t off = ok ? ((size_t)oh * A.Wo + ow) * A.Cout + t.n_base + c * 8 : 0;
+          rv[j][it] = *reinterpret_cast<const u16x8*>(rf + off);
+        }
+    }
+    const unsigned short* bias_p = A.bias ? A.bias : A.w;          // any valid address: masked to +0.0 without a bias
+    const unsigned bias_mask = A.bias ? 0xffffffffu : 0u;
+    u32x2 e_bias[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + t.n_base + i * 32 + g * 8 + ehi * 4);
+        e_bias[i][g] = u32x2{b[0] & bias_mask, b[1] & bias_mask};
+      }
+    unsigned short* yf = A.y + (long long)A.out_slot[t.to] * A.out_frame_stride;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          const u32x2 b = e_bias[i][g];
+          v[0] += __builtin_bit_cast(float, b[0] << 16);
+          v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, b[1] << 16);
+          v[3] += __builtin_bit_cast(float, b[1] & 0xffff0000u);
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          *reinterpret_cast<u16x4*>(tr + e31 * PITCH + (i * 32 + g * 8 + ehi * 4) * 2) = o;
+        }
+      wait_lds();                                     // wave-private region: no barrier
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 64 + ln;
+        const int p = idx / CR, c = idx - p * CR;
+        const int ow = t.w0 + j * 32 + p;
+        const bool ok = row_ok && p < 32 && ow < A.Wo;
+        u16x8 v = *reinterpret_cast<const u16x8*>(tr + min(p, 31) * PITCH + c * 16);
+        if (rf != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[j][it][e]));
+        }
+#ifdef IFX_CONVPP_NOSTORE
+        if (ok && v[0] == 0x7fc1) *reinterpret_cast<u16x8*>(yf + ((size_t)oh * A.Wo + ow) * A.Cout + t.n_base + c * 8) = v;      // lab: (almost) never
+#else
+        if (ok) *reinterpret_cast<u16x8*>(yf + ((size_t)oh * A.Wo + ow) * A.Cout + t.n_base + c * 8) = v;
+#endif
+      }
+      // (the LDS operations of one wave execute in order: the next block's writes cannot overtake these reads)
+    }
+  };
+
+  const unsigned frame_bytes = (unsigned)((long long)A.Hs * A.Ws * A.Cin * 2);
+  // compute-side cursor: step c_g of the stream = kernel row c_r of stage c_s of tile c_it; c_sg = global stage index
+  int c_it = 0, c_s = 0, c_r = 0, c_sg = 0;
+  Tile c_t = tile_of(0);
+  auto c_first = [&]() __attribute__((always_inline)) { return c_s == 0 && c_r == 0; };
+  auto c_last = [&]() __attribute__((always_inline)) { return c_s == S - 1 && c_r == 2; };
+  auto c_next = [&]() __attribute__((always_inline)) {
+    if (++c_r == 3) {
+      c_r = 0;
+      ++c_sg;
+      if (++c_s == S) c_s = 0, ++c_it;
+    }
+  };
+#if IFX_CONVPP_TRACE
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+
+  if (grp == 0) {
+    // ---- weight requests: a cursor over the steps of the stream; wave w4 moves pieces w4, w4 + 4, ... of a step's 3 x WP
+    int ln0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int lane_w = (ln0 >> 2) * 64 + (((ln0 & 3) ^ ((ln0 >> 4) & 3)) << 4);
+    const v4i w_rs = make_rsrc(A.w, (unsigned)((long long)A.KT * 9 * CC * A.Cout * 64));
+    const int tap_stride = CC * A.Cout * 64;
+    int w_it = 0, w_dt = 0, w_cc = 0, w_r = 0, w_g = 0;
+    int w_nb = c_t.n_base;
+    auto w_piece = [&](int q) __attribute__((always_inline)) {       // piece slot q of the cursor's step
+      const int idx = w4 + 4 * q;
+      if (w_it >= n_my || idx >= G::WPS) return;
+      const int tg = idx / G::WP, pr = idx - tg * G::WP;
+      const int base = ((w_dt * 9 + w_r * 3 + tg) * CC + w_cc) * (A.Cout * 64) + w_nb * 64 + pr * 1024;
+      (void)tap_stride;
+      dma16(w_rs, lds0 + G::W_OFF + (w_g & 1) * G::W_STEP + tg * G::W_TAP + pr * 1024, lane_w, base);
+    };
+    auto w_next = [&]() __attribute__((always_inline)) {
+      ++w_g;
+      if (++w_r == 3) {
+        w_r = 0;
+        if (++w_cc == CC) {
+          w_cc = 0;
+          if (++w_dt == A.KT) {
+            w_dt = 0;
+            if (++w_it < n_my) w_nb = tile_of(w_it).n_base;
+          }
+        }
+      }
+    };
+    auto w_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < G::WPW; ++q) w_piece(q);
+      w_next();
+    };
+    // pieces of the cursor's step spread over the three taps' reads of a loader phase
+    auto w_between = [&](int tg) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < G::WPW; ++q)
+        if (q * 3 / G::WPW == tg) w_piece(q);
+      if (tg == 2) w_next();
+    };
+    w_all(), w_all();                                 // steps 0 and 1
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();                     // B0: patch 0, weights 0 and 1 are in LDS
+    read_frags(0, 0, 0, [&](int) __attribute__((always_inline)) {});      // phase -1
+    wait_lds();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CP_STAMP(7);
+    for (int g = 0; g < GT; ++g) {
+      // ---------------- phase 2g: MFMA ----------------
+      if (c_first()) mfma_first();
+      else mfma_next();
+      const bool tile_done = c_last();
+      c_next();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(0);
+      wait_vm0();                                     // the weights of step g+1 (requested one phase ago) have landed; so have an epilogue's stores
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(1);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(2);
+      // ---------------- phase 2g+1: loader ----------------
+      if (tile_done) {
+        epilogue(c_t);
+        if (c_it < n_my) c_t = tile_of(c_it);
+      }
+      CP_STAMP(3);
+      // (the reads are unconditional: behind the last step they fetch stale LDS that nobody multiplies — a conditional read would keep the
+      //  OLD fragments alive through the epilogue on the not-taken path, 120 registers next to the accumulators)
+      read_frags(c_r, c_sg & 1, (g + 1) & 1, w_between);          // + the weights of step g+2 into the slot step g was read from
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(4);
+      wait_lds();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(5);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(6);
+    }
+#if IFX_CONVPP_TRACE
+    if (blockIdx.x == 0 && wave == 0 && ln0 == 0 && A.trace != nullptr)
+      for (int i = 0; i < 8; ++i) A.trace[i] = seg[i];
+#endif
+  } else {
+    // ---- patch requests: a cursor over the stages of the stream; wave w4 moves pieces w4, w4 + 4, ... of a stage's NPI, in two batches
+    int p_it = 0, p_dt = 0, p_cc = 0, p_sg = 0;
+    Tile p_t = c_t;
+    v4i p_rs;
+    auto p_desc = [&]() __attribute__((always_inline)) {
+      const int f = A.in_slot[p_t.to + p_dt];
+      p_rs = make_rsrc(A.x + (long long)max(f, 0) * A.in_frame_stride, f < 0 ? 0u : frame_bytes);
+    };
+    auto p_piece = [&](int q) __attribute__((always_inline)) {
+      const int p = w4 + 4 * q;
+      if (p_it >= n_my || p >= G::NPI) return;
+      // (the piece -> pixel arithmetic is re-derived from an opaque lane id at every call: hoisted out of the step loop it would hold
+      //  ~3 registers per piece across it and spill)
+      int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(ln));
+      const int ph0 = UPS ? p_t.h0 / 2 - 1 : p_t.h0 - 1, pw0 = UPS ? p_t.w0 / 2 - 1 : p_t.w0 - 1;
+      const int px = p * 16 + (ln >> 2);
+      const int pr = px / PW, pc = px - pr * PW;
+      const int sh = ph0 + pr, sw = pw0 + pc;
+      const bool ok = px < G::NP && (unsigned)sh < (unsigned)A.Hs && (unsigned)sw < (unsigned)A.Ws;
+      const int voff = ok ? ((sh * A.Ws + sw) * A.Cin + p_cc * 32) * 2 + (((ln & 3) ^ ((pc >> 2) & 3)) << 4) : (int)0x80000000;
+      dma16(p_rs, lds0 + G::P_OFF + (p_sg & 1) * G::P_SLOT + p * 1024, voff, 0);
+    };
+    auto p_next = [&]() __attribute__((always_inline)) {
+      ++p_sg;
+      if (++p_cc == CC) {
+        p_cc = 0;
+        if (++p_dt == A.KT) {
+          p_dt = 0;
+          if (++p_it < n_my) p_t = tile_of(p_it);
+        }
+      }
+      if (p_it < n_my) p_desc();
+    };
+    p_desc();
+#pragma unroll
+    for (int q = 0; q < G::PPW; ++q) p_piece(q);      // stage 0
+    p_next();
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();                     // B0
+    __builtin_amdgcn_s_barrier();                     // phase -1: nothing to read yet
+    CP_STAMP(7);
+    for (int g = 0; g < GT; ++g) {
+      // ---------------- phase 2g: loader ----------------
+      // head of phase 6t+4: this wave's pieces of stage t+1 (requested in phases 6t and 6t+2) have landed
+      if (c_r == 2) wait_vm0();
+      CP_STAMP(0);
+      if (g > 0 && c_first()) {                        // (c_t still names the tile that ended one phase ago)
+        epilogue(c_t);
+        c_t = tile_of(c_it);
+      }
+      CP_STAMP(1);
+      const int batch = c_r;                          // 0 / 1: that half of the next stage's pieces; 2: none
+      read_frags(c_r, c_sg & 1, g & 1, [&](int tg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < G::PPW; ++q) {
+          const int b = q < G::QA ? 0 : 1, qq = b == 0 ? q : q - G::QA, nb = b == 0 ? G::QA : G::PPW - G::QA;
+          if (b == batch && qq * 3 / nb == tg) p_piece(q);
+        }
+        if (tg == 2 && batch == 1) p_next();
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(2);
+      wait_lds();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(3);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(4);
+      // ---------------- phase 2g+1: MFMA ----------------
+      if (c_first()) mfma_first();
+      else mfma_next();
+      c_next();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(5);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      CP_STAMP(6);
+    }
+#if IFX_CONVPP_TRACE
+    if (blockIdx.x == 0 && wave == 4 && (threadIdx.x & 63) == 0 && A.trace != nullptr)
+      for (int i = 0; i < 8; ++i) A.trace[8 + i] = seg[i];
+#endif
+    epilogue(c_t);
+  }
+}
+
+template <int BN, int UPS>
+static void launch(const ConvArgs& a, hipStream_t s) {
+  using G = GeoP<BN, UPS>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_pp_kernel<BN, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    attr = true;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int wgx = max(1, min(cus / 8, a.per_xcd));     // one workgroup per CU (LDS), the same number on every XCD
+#if IFX_CONVPP_TRACE
+  static unsigned long long* tr = nullptr;
+  if (tr == nullptr) (void)hipMalloc((void**)&tr, 16 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(tr, 0, 16 * sizeof(unsigned long long), s);
+  ConvArgs b = a;
+  b.trace = tr;
+  hipLaunchKernelGGL((conv_pp_kernel<BN, UPS>), dim3(wgx * 8), dim3(512), G::LDS, s, b);
+  unsigned long long h[16];
+  (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  const int n_my = (a.per_xcd + wgx - 1) / wgx, steps = n_my * 3 * a.KT * (a.Cin >> 5);
+  fprintf(stderr, "conv_pp<%d,%d> %dx%d cin %d cout %d t %d: %d tiles/wg, %d steps; cycles per step\n  G0: mfma %.0f  wait_vm %.0f  barrier %.0f  epilogue %.0f  "
+          "dma+frags %.0f  wait_lds %.0f  barrier %.0f  (prologue %.0f)\n  G1: wait_vm %.0f  epilogue %.0f  dma+frags %.0f  wait_lds %.0f  barrier %.0f  mfma %.0f  barrier %.0f  (prologue %.0f)\n",
+          BN, UPS, a.Ho, a.Wo, a.Cin, a.Cout, a.t_out, n_my, steps, (double)h[0] / steps, (double)h[1] / steps, (double)h[2] / steps, (double)h[3] / steps,
+          (double)h[4] / steps, (double)h[5] / steps, (double)h[6] / steps, (double)h[7], (double)h[8] / steps, (double)h[9] / steps, (double)h[10] / steps,
+          (double)h[11] / steps, (double)h[12] / steps, (double)h[13] / steps, (double)h[14] / steps, (double)h[15]);
+#else
+  hipLaunchKernelGGL((conv_pp_kernel<BN, UPS>), dim3(wgx * 8), dim3(512), G::LDS, s, a);
+#endif
+}
+}  // namespace pp
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Per-pixel channel RMS norm (+ SiLU) on channels-last frames, written into caller-chosen frame slots.
 // Follows the bf16 op chain of `RMS_norm.forward` (vae.py:52-55) + `nn.SiLU`: n = bf16(||x||), y = bf16(x / max(n, eps)),
@@ -504,7 +1003,16 @@ extern "C" int ifx_conv3d_cl(const ifx_conv3d_desc* d, void* stream) {
     ablate = e ? atoi(e) : 0;
   }
   a.ablate = ablate;
+  a.trace = nullptr;
   hipStream_t s = (hipStream_t)stream;
+  // the persistent ping-pong kernel serves the 3 x 3 spatial kernels on 96-channel tiles (every expensive layer of the decoder);
+  // option conv_variant = 1 keeps the lock-step kernel (A/B, tools/bench_vae.py --variant)
+  if (d->ks == 3 && bn == 96 && conv_variant() != 1 && (long long)d->hs * d->ws * d->cin * 2 < (1ll << 31) &&
+      (long long)d->kt * 9 * d->cin * d->cout * 2 < (1ll << 31)) {
+    if (d->upsample) pp::launch<96, 1>(a, s);
+    else pp::launch<96, 0>(a, s);
+    return check_launch("ifx_conv3d_cl");
+  }
 #define IFX_CONV_BN(UPS, KS)                              \
   switch (bn) {                                           \
     case 32: launch<32, UPS, KS>(a, s); break;            \

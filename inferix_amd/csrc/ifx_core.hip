@@ -16,7 +16,7 @@ void set_error(const char* fmt, ...) {
 }
 
 // kernel-selection overrides (ifx_set_option); -1 = unset -> environment variable -> 0 (auto)
-static int g_gemm_variant = -1, g_attn_variant = -1, g_spin_timeout_ms = -1, g_spin_fault = 0;
+static int g_gemm_variant = -1, g_attn_variant = -1, g_conv_variant = -1, g_spin_timeout_ms = -1, g_spin_fault = 0;
 // gemm_small_split is a property of the CALLER (a sequence-parallel rank's block loop sets it around its own launches): per host thread,
 // so that launches another thread enqueues meanwhile (a VAE decode, a text encoder) keep the row-count independent choice
 static thread_local int g_gemm_small_split = -1;
@@ -29,6 +29,7 @@ static int opt_or_env(int& slot, const char* env, int dflt = 0) {
 }
 int gemm_variant() { return opt_or_env(g_gemm_variant, "IFX_GEMM_VARIANT"); }
 int attn_variant() { return opt_or_env(g_attn_variant, "IFX_ATTN_VARIANT"); }
+int conv_variant() { return opt_or_env(g_conv_variant, "IFX_CONV_VARIANT"); }
 int gemm_small_split() { return opt_or_env(g_gemm_small_split, "IFX_GEMM_SMALL_SPLIT"); }
 
 // ---- device-side waits are BOUNDED.  A kernel that waits for another workgroup (the split-K / stream-K hand-off of ifx_gemm_pp.hip)
@@ -85,6 +86,7 @@ extern "C" int ifx_set_option(const char* key, int32_t value) {
   if (key && !strcmp(key, "gemm_variant") && value >= 0 && value <= 29) { ifx::g_gemm_variant = value; return IFX_OK; }
   if (key && !strcmp(key, "gemm_small_split") && (value == 0 || value == 1)) { ifx::g_gemm_small_split = value; return IFX_OK; }
   if (key && !strcmp(key, "attn_variant") && value >= 0 && value <= 7) { ifx::g_attn_variant = value; return IFX_OK; }
+  if (key && !strcmp(key, "conv_variant") && value >= 0 && value <= 1) { ifx::g_conv_variant = value; return IFX_OK; }
   if (key && !strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 600000) { ifx::g_spin_timeout_ms = value; return IFX_OK; }
   if (key && !strcmp(key, "spin_fault") && (value == 0 || value == 1)) { ifx::g_spin_fault = value; return IFX_OK; }
   ifx::set_error("ifx_set_option: unknown key or value out of range: %s = %d", key ? key : "(null)", (int)value);
@@ -95,6 +97,7 @@ extern "C" int ifx_get_option(const char* key, int32_t* value) {
   if (!strcmp(key, "gemm_variant")) { *value = ifx::gemm_variant(); return IFX_OK; }
   if (!strcmp(key, "gemm_small_split")) { *value = ifx::gemm_small_split(); return IFX_OK; }
   if (!strcmp(key, "attn_variant")) { *value = ifx::attn_variant(); return IFX_OK; }
+  if (!strcmp(key, "conv_variant")) { *value = ifx::conv_variant(); return IFX_OK; }
   if (!strcmp(key, "spin_timeout_ms")) { *value = (int32_t)(ifx::spin_timeout_ticks() / 100000LL); return IFX_OK; }
   if (!strcmp(key, "spin_fault")) { *value = ifx::spin_fault(); return IFX_OK; }
   ifx::set_error("ifx_get_option: unknown key: %s", key);
