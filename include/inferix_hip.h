@@ -41,7 +41,7 @@ typedef uint16_t ifx_bf16;
  * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static; 0.6: ifx_get_option, ifx_device_error, bounded device waits).  Callers built against another minor
  * must not call in: zero-initialise every struct (new fields default to 0 = off) and compare IFX_ABI_MINOR with
  * (ifx_version() >> 8) & 255 at load time, as inferix_amd/_hip.py does. */
-#define IFX_ABI_MINOR 6
+#define IFX_ABI_MINOR 7
 int ifx_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* ifx_last_error(void);      /* thread-local, never NULL */
 const char* ifx_arch(void);            /* "gfx950" */
@@ -448,6 +448,10 @@ int ifx_peer_wait(const int32_t* flags, int32_t count, int32_t value, int32_t ti
  *   x          frames [slot][hs][ws][cin] bf16; logical input frame f (0 .. t_out+kt-2: for kt = 3 the two
  *              history frames, then the new ones) lives at x + in_slots[f] * in_frame_stride; in_slots[f] < 0
  *              = an all-zero frame (the causal padding in front of the stream)
+ *   in_planar  1: the input frames are [cin/32][hs][ws][32] instead (32-channel planes: the halo patch of one
+ *              channel chunk is then rows of contiguous 64-byte pixels — LDS-DMA moves 64-byte rows that lie
+ *              192+ bytes apart at a third of the rate of contiguous ones, round 6; the frame rings in front of
+ *              the 3x3x3 convs use this layout, written by ifx_rmsnorm_cl with IFX_NORM_OUT_PLANAR)
  *   upsample   1: the 3x3 taps read the nearest-2x upsampled frame (output 2hs x 2ws), never materialised
  *   w          [kt*ks*ks][cin/32][cout][32] bf16: tap-major, 32-channel-chunk-major repack of the torch
  *              [cout][cin][kt][ks][ks] weight (a DMA piece of 16 output channels x 32 input channels is contiguous)
@@ -470,15 +474,20 @@ typedef struct {
   int32_t cout, t_out;
   const ifx_bf16* residual;
   const void* zero_page;
+  int32_t in_planar;            /* ABI minor 7; 0 = channels-last input frames */
 } ifx_conv3d_desc;
 int ifx_conv3d_cl(const ifx_conv3d_desc* desc, void* stream);
 
 /* Per-pixel channel RMS norm (+ SiLU) of channels-last frames x [frames][frame_pixels][channels], with the bf16 op
  * chain of RMS_norm.forward (vae.py:52-55) and nn.SiLU; frame f is written to y + out_slots[f] * out_frame_stride
- * (the ring buffer that holds the next conv's input and its two-frame history).  out_slots is a HOST array. */
+ * (the ring buffer that holds the next conv's input and its two-frame history).  out_slots is a HOST array.
+ * flags: IFX_NORM_SILU (1) applies SiLU; IFX_NORM_OUT_PLANAR (2; channels % 32 == 0) writes the frame as
+ * [channels/32][frame_pixels][32] (ifx_conv3d_desc.in_planar) instead of channels-last. */
+#define IFX_NORM_SILU 1
+#define IFX_NORM_OUT_PLANAR 2
 int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16* y, int64_t out_frame_stride,
                    const int32_t* out_slots, int32_t frames, int32_t frame_pixels, int32_t channels,
-                   int32_t silu, void* stream);
+                   int32_t flags, void* stream);
 
 /* probs = softmax(scores * scale) row-wise, bf16 [rows][ld] (single-head attention of the VAE middle block,
  * vae.py:250-254, between the two ifx_gemm_bf16 launches that form QK^T and PV). */

@@ -50,7 +50,8 @@ class Conv3dDesc(C.Structure):
                 ("hs", C.c_int32), ("ws", C.c_int32), ("cin", C.c_int32), ("upsample", C.c_int32),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("kt", C.c_int32), ("ks", C.c_int32),
                 ("y", C.c_void_p), ("out_frame_stride", C.c_int64), ("out_slots", C.POINTER(C.c_int32)),
-                ("cout", C.c_int32), ("t_out", C.c_int32), ("residual", C.c_void_p), ("zero_page", C.c_void_p)]
+                ("cout", C.c_int32), ("t_out", C.c_int32), ("residual", C.c_void_p), ("zero_page", C.c_void_p),
+                ("in_planar", C.c_int32)]
 
 
 class Epilogue(C.Structure):
@@ -146,7 +147,7 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
-ABI_MINOR = 6      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
+ABI_MINOR = 7      # = IFX_ABI_MINOR of include/inferix_hip.h (checked against the header in tests/test_cabi_and_host.py)
 
 
 def load() -> C.CDLL:

@@ -46,6 +46,7 @@ struct ConvArgs {
   int Hs, Ws, Cin, Ho, Wo, Cout, KT, t_out;
   int tiles_w, tiles_h, tiles_n, per_xcd, total;
   unsigned long long* trace;      // lab builds (-DIFX_CONVPP_TRACE=1): segment cycle sums of workgroup 0's waves 0 and 4
+  int in_planar;   // input frames [Cin/32][Hs][Ws][32] instead of [Hs][Ws][Cin]
   int ablate;      // IFX_CONV_ABLATE bit mask (timing experiments only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no stores
 };
 
@@ -134,14 +135,14 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
     const int pr = px / PW, pc = px - pr * PW;
     const int sh = ph0 + pr, sw = pw0 + pc;
     const bool ok = p < G::NPI && px < G::NP && sh >= 0 && sh < A.Hs && sw >= 0 && sw < A.Ws;
-    poff[r] = ok ? (sh * A.Ws + sw) * A.Cin + (((lane & 3) ^ ((px >> 2) & 3)) << 3) : -1;
+    poff[r] = ok ? (sh * A.Ws + sw) * (A.in_planar ? 32 : A.Cin) + (((lane & 3) ^ ((px >> 2) & 3)) << 3) : -1;
   }
   const int CC = A.Cin >> 5;
   const int S = A.KT * CC, totalG = S * GPS;
   auto issue_patch = [&](int s, int r) {            // piece r of this wave for stage s
     const int dt = s / CC, cc = s - dt * CC;
     const int f = A.in_slot[to + dt];
-    const unsigned short* base = A.x + (long long)f * A.in_frame_stride + cc * 32;
+    const unsigned short* base = A.x + (long long)f * A.in_frame_stride + (A.in_planar ? (long long)cc * A.Hs * A.Ws * 32 : cc * 32);
     const int p = wave + LW * r;
     const unsigned short* src = (poff[r] < 0 || f < 0) ? A.zero : base + poff[r];
     unsigned char* dst = p < G::NPI ? smem + G::P_OFF + (s & 1) * G::P_SLOT + p * 1024 : smem + G::S_OFF + wave * 1024;
@@ -398,6 +399,9 @@ __device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, int voff, int soff
                : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory");
 }
+__device__ __forceinline__ void dma4(v4i rsrc, unsigned lds, int voff) {      // 4 bytes per lane (a cache-line touch: the data is not used)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(lds), "v"(voff), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ v4i make_rsrc(const void* base, unsigned num_bytes) {
   const unsigned long long a = (unsigned long long)base;
   v4i r;
@@ -414,14 +418,22 @@ template <int BN, int UPS>
 struct GeoP {
   static constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2;
   static constexpr int NP = PH * PW, NPI = (NP + 15) / 16;
-  static constexpr int PPW = (NPI + 3) / 4;             // patch piece slots per wave of group 1 and stage
+  // a stage's NPI patch pieces: group 0 moves the first 4 * PG0 (one per wave in each of its loader phases 6t-1, 6t+1, 6t+3: its loader
+  // phases carry the 4-5 weight pieces per wave, ~90 cycles each, and a patch piece costs ~300 — 64-byte rows 192+ bytes apart), group 1
+  // the rest in two batches (loader phases 6t, 6t+2)
+  static constexpr int PG0 = UPS ? 1 : 3;
+  static constexpr int NP1 = NPI - 4 * PG0;
+  static constexpr int PPW = (NP1 + 3) / 4;             // patch piece slots per wave of group 1 and stage
   static constexpr int QA = (PPW + 1) / 2;              // of which in the first of the stage's two batches
   static constexpr int P_SLOT = NPI * 1024;
   static constexpr int WP = BN / 16;                    // 1 KiB weight pieces per tap
   static constexpr int W_TAP = BN * 64, W_STEP = 3 * W_TAP;
   static constexpr int WPS = 3 * WP, WPW = (WPS + 3) / 4;      // weight pieces per step / piece slots per wave of group 0 and step
   static constexpr int PITCH = BN * 2 + 16, SCR = 32 * PITCH;  // transpose region of one wave: 32 pixels x BN channels
-  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, E_OFF = W_OFF + 2 * W_STEP, LDS = E_OFF + 4 * SCR;
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, E_OFF = W_OFF + 2 * W_STEP;
+  static constexpr int B_OFF = E_OFF + 4 * SCR;         // the launch's bias vector (Cout <= 512 channels) as bf16
+  static constexpr int S_OFF = B_OFF + 1024;            // 256-byte sinks of the residual warm-up requests, one per wave
+  static constexpr int LDS = S_OFF + 8 * 256;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(SCR % 16 == 0 && P_SLOT % 16 == 0 && W_STEP % 16 == 0, "alignment");
 };
@@ -465,33 +477,47 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
   //      per-tap pixel columns and the weight-row offsets out of the step loop — ~20 registers held across a loop that runs at 96
   //      accumulators + 120 fragment registers — and spills fragments into the MFMA phase.)
   bf16x8 fa[3][2][TJ], fb[3][2][TI];
+  // The column swizzle makes a fragment address = wave-uniform base (slot, patch row) + a lane term that depends on (tap, block, k-step)
+  // only: the 12 + 6 lane terms live in registers across the loop (the loop then runs at ~240 of 256) and a loader phase spends 18
+  // v_add instead of ~100 VALU operations on addresses (s_memtime trace: a loader phase was ~800 cycles of reads + address arithmetic
+  // against the 1152 of the MFMA phase it must hide under).
+  // (k-step 1 of a fragment is k-step 0's address with bit 5 flipped — the chunk index is (2 ks + hi) ^ swizzle — so only the
+  //  k-step-0 terms are kept: 9 registers, and one v_xor per k-step-1 read)
+  int a_term[3][TJ], b_term[TI];
+  {
+    const int f31 = (int)(threadIdx.x & 31), fhi = (int)((threadIdx.x >> 5) & 1);
+#pragma unroll
+    for (int tg = 0; tg < 3; ++tg)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = UPS ? (j * 32 + f31 + tg + 1) >> 1 : j * 32 + f31 + tg;
+        a_term[tg][j] = col * 64 + ((fhi ^ ((col >> 2) & 3)) << 4);
+      }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int n = i * 32 + f31;
+      b_term[i] = (n * 64 + (((n >> 2) & 3) << 4)) ^ (fhi << 4);
+    }
+  }
   // fragments of kernel row r of the stage in patch slot ps, weights in ring slot ws; `between(tg)` runs ahead of tap tg's reads (the
   // loader's DMA instructions go there: the reads queue up at the LDS while the wave sits in a DMA issue stall)
   auto read_frags = [&](int r, int ps, int ws, auto between) __attribute__((always_inline)) {
-    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(ln));
-    const int f31 = ln & 31, fhi = ln >> 5;
     const unsigned char* pb = smem + G::P_OFF + ps * G::P_SLOT + (UPS ? (wave + r + 1) >> 1 : wave + r) * (PW * 64);
     const unsigned char* wg = smem + G::W_OFF + ws * G::W_STEP;
 #pragma unroll
     for (int tg = 0; tg < 3; ++tg) {
       between(tg);
+#ifdef IFX_CONVPP_NOFRAG
+      continue;                                       // lab: DMA (and MFMAs on stale registers) only
+#endif
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int col = UPS ? (j * 32 + f31 + tg + 1) >> 1 : j * 32 + f31 + tg;
-        const int sw = (col >> 2) & 3;
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          fa[tg][ks][j] = *reinterpret_cast<const bf16x8*>(pb + col * 64 + (((2 * ks + fhi) ^ sw) << 4));
-      }
+        for (int ks = 0; ks < 2; ++ks) fa[tg][ks][j] = *reinterpret_cast<const bf16x8*>(pb + (a_term[tg][j] ^ (ks << 5)));
 #pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const int n = i * 32 + f31;
-        const int bo = n * 64 + (((n >> 2) & 3) << 4);
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          fb[tg][ks][i] = *reinterpret_cast<const bf16x8*>(wg + tg * G::W_TAP + (bo ^ ((2 * ks + fhi) << 4)));
-      }
+        for (int ks = 0; ks < 2; ++ks) fb[tg][ks][i] = *reinterpret_cast<const bf16x8*>(wg + tg * G::W_TAP + (b_term[i] ^ (ks << 5)));
     }
   };
   f32x16 acc[TI][TJ];
@@ -516,6 +542,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tg][ks][i], fa[tg][ks][j], acc[i][j], 0, 0, 0);
   };
   auto mfma_next = [&]() __attribute__((always_inline)) {
+#ifdef IFX_CONVPP_NOMFMA
+    return;                                           // lab
+#endif
 #pragma unroll
     for (int tg = 0; tg < 3; ++tg)
 #pragma unroll
@@ -557,16 +586,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
           rv[j][it] = *reinterpret_cast<const u16x8*>(rf + off);
         }
     }
-    const unsigned short* bias_p = A.bias ? A.bias : A.w;          // any valid address: masked to +0.0 without a bias
-    const unsigned bias_mask = A.bias ? 0xffffffffu : 0u;
-    u32x2 e_bias[TI][4];
+    u32x2 e_bias[TI][4];                               // from the copy the workgroup made in LDS (zeros without a bias): no memory round trip
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x2 b = *reinterpret_cast<const u32x2*>(bias_p + t.n_base + i * 32 + g * 8 + ehi * 4);
-        e_bias[i][g] = u32x2{b[0] & bias_mask, b[1] & bias_mask};
-      }
+      for (int g = 0; g < 4; ++g)
+        e_bias[i][g] = *reinterpret_cast<const u32x2*>(smem + G::B_OFF + (t.n_base + i * 32 + g * 8 + ehi * 4) * 2);
     unsigned short* yf = A.y + (long long)A.out_slot[t.to] * A.out_frame_stride;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -620,6 +645,77 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       if (++c_s == S) c_s = 0, ++c_it;
     }
   };
+  // ---- patch requests: every wave runs its own cursor over the stages of the stream (group 0 and group 1 advance it at different
+  //      phases); piece p = 16 patch pixels x 64 B
+  int p_it = 0, p_dt = 0, p_cc = 0, p_sg = 0;
+  Tile p_t = c_t;
+  v4i p_rs;
+  auto p_desc = [&]() __attribute__((always_inline)) {             // planar frames: one descriptor per 32-channel plane
+    const int f = A.in_slot[p_t.to + p_dt];
+    const long long plane = (long long)A.Hs * A.Ws * 32;
+    p_rs = make_rsrc(A.x + (long long)max(f, 0) * A.in_frame_stride + (A.in_planar ? p_cc * plane : 0),
+                     f < 0 ? 0u : (A.in_planar ? (unsigned)(plane * 2) : frame_bytes));
+  };
+  // A piece's source offsets split into a TILE-INVARIANT lane term — (patch row * Ws + patch column) pixels + the swizzled 16-byte chunk,
+  // computed once per kernel and kept in a register per piece slot — and a wave-uniform term (tile origin, channel chunk) added per
+  // request.  Rows above / below the image fall outside the descriptor (negative or past-the-end offsets: zeros); the halo COLUMNS of
+  // the first / last tile column do not, so the lane term carries two flags in its free low bits — bit 0: patch column 0, bit 1: a
+  // column at or beyond the right image edge as seen from the LAST tile column — that the request masks with the tile's position.
+  // (The first version derived row, column, bounds and address per request: ~25 dependent VALU operations, 200-500 cycles per piece in
+  //  the s_memtime trace against ~90 for a weight piece whose address is scalar.)
+  const int pix_bytes = A.in_planar ? 64 : A.Cin * 2;
+  const int w0_last = (A.tiles_w - 1) * TW;
+  const int col_limit_last = A.Ws + 1 - (UPS ? w0_last / 2 : w0_last);         // first invalid patch column of the last tile column
+  auto p_lane_term = [&](int p) __attribute__((always_inline)) {
+    const int ln = (int)(threadIdx.x & 63);
+    const int px = p * 16 + (ln >> 2);
+    const int pr = px / PW, pc = px - pr * PW;
+    if (p >= G::NPI || px >= G::NP) return (int)0x80000000;
+    return (pr * A.Ws + pc) * pix_bytes + (((ln & 3) ^ ((pc >> 2) & 3)) << 4) + (pc == 0 ? 1 : 0) + (pc >= col_limit_last ? 2 : 0);
+  };
+  int p_tile = 0, p_edge = 0;                          // wave-uniform term of the cursor's tile / its edge mask (bit 0: first, bit 1: last tile column)
+  auto p_tile_terms = [&]() __attribute__((always_inline)) {
+    const int ph0 = UPS ? p_t.h0 / 2 - 1 : p_t.h0 - 1, pw0 = UPS ? p_t.w0 / 2 - 1 : p_t.w0 - 1;
+    p_tile = (ph0 * A.Ws + pw0) * pix_bytes;
+    p_edge = (p_t.w0 == 0 ? 1 : 0) | (p_t.w0 == w0_last ? 2 : 0);
+  };
+  auto p_piece = [&](int p, int lane_term) __attribute__((always_inline)) {
+    if (p_it >= n_my || p >= G::NPI) return;
+    const int voff = (lane_term & p_edge) ? (int)0x80000000 : (lane_term & ~3) + p_tile + (A.in_planar ? 0 : p_cc * 64);
+    dma16(p_rs, lds0 + G::P_OFF + (p_sg & 1) * G::P_SLOT + p * 1024, voff, 0);
+  };
+  auto p_next = [&]() __attribute__((always_inline)) {
+    ++p_sg;
+    if (++p_cc == CC) {
+      p_cc = 0;
+      if (++p_dt == A.KT) {
+        p_dt = 0;
+        if (++p_it < n_my) p_t = tile_of(p_it), p_tile_terms();
+      }
+    }
+    if (p_it < n_my) p_desc();
+  };
+  p_desc();
+  p_tile_terms();
+  // ---- residual warm-up: three steps before a tile's epilogue every wave touches the cache lines of its residual row (64 pixels x BN
+  //      channels: two lines per pixel) with two 4-byte-per-lane DMA requests into a sink — the epilogue's own loads then hit in L2
+  //      instead of paying an HBM round trip inside the phase the other group sits out (trace: 4.7k of the epilogue's 12k cycles)
+  auto res_warm = [&](const Tile& t) __attribute__((always_inline)) {
+    if (A.res == nullptr) return;
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
+    const v4i rs = make_rsrc(A.res + (long long)t.to * A.Ho * A.Wo * A.Cout, (unsigned)((long long)A.Ho * A.Wo * A.Cout * 2));
+    const int oh = t.h0 + wave, ow = t.w0 + ln;
+    const int voff = (oh < A.Ho && ow < A.Wo) ? ((oh * A.Wo + ow) * A.Cout + t.n_base) * 2 : (int)0x80000000;
+    dma4(rs, lds0 + G::S_OFF + wave * 256, voff);
+    dma4(rs, lds0 + G::S_OFF + wave * 256, voff + 128);
+  };
+  // ---- the launch's bias vector into LDS (zeros without one); visible behind barrier B0
+  if (tid < 64) {
+    u16x8 bv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (A.bias != nullptr && tid * 8 < A.Cout) bv = *reinterpret_cast<const u16x8*>(A.bias + tid * 8);
+    *reinterpret_cast<u16x8*>(smem + G::B_OFF + tid * 16) = bv;
+  }
 #if IFX_CONVPP_TRACE
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_readcyclecounter();
@@ -666,10 +762,24 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
         if (q * 3 / G::WPW == tg) w_piece(q);
       if (tg == 2) w_next();
     };
+    // this group's patch pieces: w4 + 4 k, k < PG0, of every stage; piece k in the k-th of the three loader phases in front of the stage
+    int p_k = 0;
+    int p_lt[G::PG0];
+#pragma unroll
+    for (int k = 0; k < G::PG0; ++k) p_lt[k] = p_lane_term(w4 + 4 * k);
+    auto p_mine = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < G::PG0; ++k)
+        if (p_k == k) p_piece(w4 + 4 * k, p_lt[k]);
+      if (++p_k == 3) p_k = 0, p_next();
+    };
     w_all(), w_all();                                 // steps 0 and 1
+    p_mine(), p_mine(), p_mine();                     // stage 0
+    wait_lds();                                       // (the bias copy)
     wait_vm0();
-    __builtin_amdgcn_s_barrier();                     // B0: patch 0, weights 0 and 1 are in LDS
-    read_frags(0, 0, 0, [&](int) __attribute__((always_inline)) {});      // phase -1
+    __builtin_amdgcn_s_barrier();                     // B0: patch 0, weights 0 and 1, the bias are in LDS
+    p_mine();                                         // phase -1: stage 1
+    read_frags(0, 0, 0, [&](int) __attribute__((always_inline)) {});
     wait_lds();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -695,6 +805,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
         if (c_it < n_my) c_t = tile_of(c_it);
       }
       CP_STAMP(3);
+      if (c_s == S - 1 && c_r == 1) res_warm(c_t);
+      p_mine();
+      CP_STAMP(7);
       // (the reads are unconditional: behind the last step they fetch stale LDS that nobody multiplies — a conditional read would keep the
       //  OLD fragments alive through the epilogue on the not-taken path, 120 registers next to the accumulators)
       read_frags(c_r, c_sg & 1, (g + 1) & 1, w_between);          // + the weights of step g+2 into the slot step g was read from
@@ -712,44 +825,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       for (int i = 0; i < 8; ++i) A.trace[i] = seg[i];
 #endif
   } else {
-    // ---- patch requests: a cursor over the stages of the stream; wave w4 moves pieces w4, w4 + 4, ... of a stage's NPI, in two batches
-    int p_it = 0, p_dt = 0, p_cc = 0, p_sg = 0;
-    Tile p_t = c_t;
-    v4i p_rs;
-    auto p_desc = [&]() __attribute__((always_inline)) {
-      const int f = A.in_slot[p_t.to + p_dt];
-      p_rs = make_rsrc(A.x + (long long)max(f, 0) * A.in_frame_stride, f < 0 ? 0u : frame_bytes);
-    };
-    auto p_piece = [&](int q) __attribute__((always_inline)) {
-      const int p = w4 + 4 * q;
-      if (p_it >= n_my || p >= G::NPI) return;
-      // (the piece -> pixel arithmetic is re-derived from an opaque lane id at every call: hoisted out of the step loop it would hold
-      //  ~3 registers per piece across it and spill)
-      int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      asm volatile("" : "+v"(ln));
-      const int ph0 = UPS ? p_t.h0 / 2 - 1 : p_t.h0 - 1, pw0 = UPS ? p_t.w0 / 2 - 1 : p_t.w0 - 1;
-      const int px = p * 16 + (ln >> 2);
-      const int pr = px / PW, pc = px - pr * PW;
-      const int sh = ph0 + pr, sw = pw0 + pc;
-      const bool ok = px < G::NP && (unsigned)sh < (unsigned)A.Hs && (unsigned)sw < (unsigned)A.Ws;
-      const int voff = ok ? ((sh * A.Ws + sw) * A.Cin + p_cc * 32) * 2 + (((ln & 3) ^ ((pc >> 2) & 3)) << 4) : (int)0x80000000;
-      dma16(p_rs, lds0 + G::P_OFF + (p_sg & 1) * G::P_SLOT + p * 1024, voff, 0);
-    };
-    auto p_next = [&]() __attribute__((always_inline)) {
-      ++p_sg;
-      if (++p_cc == CC) {
-        p_cc = 0;
-        if (++p_dt == A.KT) {
-          p_dt = 0;
-          if (++p_it < n_my) p_t = tile_of(p_it);
-        }
-      }
-      if (p_it < n_my) p_desc();
-    };
-    p_desc();
+    // ---- this group's patch pieces: 4 PG0 + w4 + 4 q, q < PPW, of every stage, in two batches (loader phases 6t and 6t+2)
+    int p_lt[G::PPW];
 #pragma unroll
-    for (int q = 0; q < G::PPW; ++q) p_piece(q);      // stage 0
+    for (int q = 0; q < G::PPW; ++q) p_lt[q] = p_lane_term(4 * G::PG0 + w4 + 4 * q);
+#pragma unroll
+    for (int q = 0; q < G::PPW; ++q) p_piece(4 * G::PG0 + w4 + 4 * q, p_lt[q]);      // stage 0
     p_next();
+    wait_lds();                                       // (the bias copy)
     wait_vm0();
     __builtin_amdgcn_s_barrier();                     // B0
     __builtin_amdgcn_s_barrier();                     // phase -1: nothing to read yet
@@ -769,10 +852,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
 #pragma unroll
         for (int q = 0; q < G::PPW; ++q) {
           const int b = q < G::QA ? 0 : 1, qq = b == 0 ? q : q - G::QA, nb = b == 0 ? G::QA : G::PPW - G::QA;
-          if (b == batch && qq * 3 / nb == tg) p_piece(q);
+          if (b == batch && qq * 3 / nb == tg) p_piece(4 * G::PG0 + w4 + 4 * q, p_lt[q]);
         }
         if (tg == 2 && batch == 1) p_next();
       });
+      if (c_s == S - 1 && c_r == 1) res_warm(c_t);
       __builtin_amdgcn_sched_barrier(0);
       CP_STAMP(2);
       wait_lds();
@@ -826,9 +910,9 @@ static void launch(const ConvArgs& a, hipStream_t s) {
   (void)hipStreamSynchronize(s);
   const int n_my = (a.per_xcd + wgx - 1) / wgx, steps = n_my * 3 * a.KT * (a.Cin >> 5);
   fprintf(stderr, "conv_pp<%d,%d> %dx%d cin %d cout %d t %d: %d tiles/wg, %d steps; cycles per step\n  G0: mfma %.0f  wait_vm %.0f  barrier %.0f  epilogue %.0f  "
-          "dma+frags %.0f  wait_lds %.0f  barrier %.0f  (prologue %.0f)\n  G1: wait_vm %.0f  epilogue %.0f  dma+frags %.0f  wait_lds %.0f  barrier %.0f  mfma %.0f  barrier %.0f  (prologue %.0f)\n",
+          "dma+frags %.0f  wait_lds %.0f  barrier %.0f  (patch piece %.0f)\n  G1: wait_vm %.0f  epilogue %.0f  dma+frags %.0f  wait_lds %.0f  barrier %.0f  mfma %.0f  barrier %.0f  (prologue %.0f)\n",
           BN, UPS, a.Ho, a.Wo, a.Cin, a.Cout, a.t_out, n_my, steps, (double)h[0] / steps, (double)h[1] / steps, (double)h[2] / steps, (double)h[3] / steps,
-          (double)h[4] / steps, (double)h[5] / steps, (double)h[6] / steps, (double)h[7], (double)h[8] / steps, (double)h[9] / steps, (double)h[10] / steps,
+          (double)h[4] / steps, (double)h[5] / steps, (double)h[6] / steps, (double)h[7] / steps, (double)h[8] / steps, (double)h[9] / steps, (double)h[10] / steps,
           (double)h[11] / steps, (double)h[12] / steps, (double)h[13] / steps, (double)h[14] / steps, (double)h[15]);
 #else
   hipLaunchKernelGGL((conv_pp_kernel<BN, UPS>), dim3(wgx * 8), dim3(512), G::LDS, s, a);
@@ -846,7 +930,7 @@ struct NormArgs {
   unsigned short* y;
   long long out_frame_stride;
   int out_slot[MAXF];
-  int frame_pixels, C, silu;
+  int frame_pixels, C, silu, planar;
   long long pixels;
   float scale;
 };
@@ -896,7 +980,9 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(NormArgs A) {
     // the correctly rounded quotient except for ties no bf16 rounding can see
     const float rn = __builtin_amdgcn_rcpf(n);
     const int f = pix / A.frame_pixels, pp = pix - f * A.frame_pixels;
-    unsigned short* yp = A.y + (long long)A.out_slot[f] * A.out_frame_stride + (long long)pp * A.C;
+    // planar output: 16-byte chunk ch of the pixel goes to plane ch >> 2, [plane][pixel][32]
+    unsigned short* yf = A.y + (long long)A.out_slot[f] * A.out_frame_stride;
+    unsigned short* yp = yf + (long long)pp * A.C;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       if (!on[k]) continue;
@@ -912,7 +998,9 @@ __global__ __launch_bounds__(256) void rmsnorm_cl_kernel(NormArgs A) {
         if (A.silu) v = v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
         o[e] = f2bf(v);
       }
-      *reinterpret_cast<u16x8*>(yp + (k * G + lane_in) * 8) = o;
+      const int ch = k * G + lane_in;
+      if (A.planar) *reinterpret_cast<u16x8*>(yf + ((long long)(ch >> 2) * A.frame_pixels + pp) * 32 + (ch & 3) * 8) = o;
+      else *reinterpret_cast<u16x8*>(yp + ch * 8) = o;
     }
   }
 }
@@ -962,6 +1050,7 @@ extern "C" int ifx_conv3d_cl(const ifx_conv3d_desc* d, void* stream) {
   IFX_REQUIRE(d->ks == 1 || d->ks == 3, "ifx_conv3d_cl: spatial kernel %d not built (1 or 3)", d->ks);
   IFX_REQUIRE(d->upsample == 0 || (d->upsample == 1 && d->ks == 3), "ifx_conv3d_cl: upsample needs the 3x3 kernel");
   IFX_REQUIRE(d->cin > 0 && d->cin % 32 == 0, "ifx_conv3d_cl: cin %d must be a multiple of 32", d->cin);
+  IFX_REQUIRE(d->in_planar == 0 || d->in_planar == 1, "ifx_conv3d_cl: in_planar %d (0 or 1)", d->in_planar);
   IFX_REQUIRE(d->cout > 0 && (d->cout % 4 == 0 || d->cout < 4), "ifx_conv3d_cl: cout %d must be a multiple of 4 (or < 4)", d->cout);
   IFX_REQUIRE(d->t_out >= 1 && d->t_out + d->kt - 1 <= MAXF, "ifx_conv3d_cl: %d output frames per call (max %d inputs)",
               d->t_out, MAXF);
@@ -1004,11 +1093,12 @@ extern "C" int ifx_conv3d_cl(const ifx_conv3d_desc* d, void* stream) {
   }
   a.ablate = ablate;
   a.trace = nullptr;
+  a.in_planar = d->in_planar ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   // the persistent ping-pong kernel serves the 3 x 3 spatial kernels on 96-channel tiles (every expensive layer of the decoder);
   // option conv_variant = 1 keeps the lock-step kernel (A/B, tools/bench_vae.py --variant)
-  if (d->ks == 3 && bn == 96 && conv_variant() != 1 && (long long)d->hs * d->ws * d->cin * 2 < (1ll << 31) &&
-      (long long)d->kt * 9 * d->cin * d->cout * 2 < (1ll << 31)) {
+  if (d->ks == 3 && bn == 96 && conv_variant() != 1 && d->cout <= 512 && (long long)d->hs * d->ws * d->cin * 2 < (1ll << 31) &&
+      (long long)a.Ho * a.Wo * d->cout * 2 < (1ll << 31) && (long long)d->kt * 9 * d->cin * d->cout * 2 < (1ll << 31)) {
     if (d->upsample) pp::launch<96, 1>(a, s);
     else pp::launch<96, 0>(a, s);
     return check_launch("ifx_conv3d_cl");
@@ -1033,7 +1123,7 @@ extern "C" int ifx_conv3d_cl(const ifx_conv3d_desc* d, void* stream) {
 
 extern "C" int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16* y, int64_t out_frame_stride,
                               const int32_t* out_slots, int32_t frames, int32_t frame_pixels, int32_t channels,
-                              int32_t silu, void* stream) {
+                              int32_t flags, void* stream) {
   IFX_REQUIRE(x && gamma && y && out_slots, "ifx_rmsnorm_cl: null argument");
   IFX_REQUIRE(frames >= 1 && frames <= MAXF && frame_pixels > 0, "ifx_rmsnorm_cl: %d frames per call (max %d)", frames, MAXF);
   IFX_REQUIRE((long long)frames * frame_pixels < (1ll << 31) - (1 << 16), "ifx_rmsnorm_cl: too many pixels per call");
@@ -1046,7 +1136,10 @@ extern "C" int ifx_rmsnorm_cl(const ifx_bf16* x, const ifx_bf16* gamma, ifx_bf16
   for (int i = 0; i < MAXF; ++i) a.out_slot[i] = i < frames ? out_slots[i] : 0;
   a.frame_pixels = frame_pixels;
   a.C = channels;
-  a.silu = silu;
+  IFX_REQUIRE((flags & ~3) == 0 && (!(flags & IFX_NORM_OUT_PLANAR) || channels % 32 == 0),
+              "ifx_rmsnorm_cl: flags %d (IFX_NORM_SILU | IFX_NORM_OUT_PLANAR; planar output needs channels %% 32 == 0)", flags);
+  a.silu = flags & IFX_NORM_SILU;
+  a.planar = (flags & IFX_NORM_OUT_PLANAR) ? 1 : 0;
   a.pixels = (long long)frames * frame_pixels;
   a.scale = sqrtf((float)channels);
   const int chunks = channels / 8;

@@ -683,14 +683,28 @@ def _slots(v) -> "C.Array":
     return (C.c_int32 * len(v))(*[int(i) for i in v])
 
 
+def to_planar(x: torch.Tensor) -> torch.Tensor:
+    """channels-last frames `[t, h, w, c]` (c % 32 == 0) -> the 32-channel-plane layout `[t, c/32, h, w, 32]` of
+    `ifx_conv3d_desc.in_planar` (a copy)."""
+    t, h, w, c = x.shape
+    return x.view(t, h, w, c // 32, 32).permute(0, 3, 1, 2, 4).contiguous()
+
+
 def conv3d_cl(x: torch.Tensor, in_slots, w: torch.Tensor, bias: Optional[torch.Tensor], *, kt: int, ks: int,
               y: torch.Tensor, out_slots, upsample: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Causal conv on channels-last frames (ifx_conv3d_cl).  `x` `[slots, hs, ws, cin]`, logical input frame f at
+    """Causal conv on channels-last frames (ifx_conv3d_cl).  `x` `[slots, hs, ws, cin]` — or, 5-D, the planar layout
+    `[slots, cin/32, hs, ws, 32]` (`to_planar`, `rmsnorm_cl(out_planar=True)`) — logical input frame f at
     `x[in_slots[f]]` (negative slot = zero frame; `t_out + kt - 1` entries); `w` `[kt*ks*ks, cin/32, cout, 32]`; output frame t
     goes to `y[out_slots[t]]` `[ho, wo, cout]`; `residual` `[t_out, ho, wo, cout]`."""
     t_out = len(out_slots)
     assert len(in_slots) == t_out + kt - 1, (len(in_slots), t_out, kt)
-    _, hs, ws, cin = x.shape
+    in_planar = x.dim() == 5
+    if in_planar:
+        _, planes, hs, ws, c32 = x.shape
+        assert c32 == 32
+        cin = planes * 32
+    else:
+        _, hs, ws, cin = x.shape
     taps, cc, cout, c32 = w.shape
     assert taps == kt * ks * ks and c32 == 32 and cc * 32 == cin and x.is_contiguous() and y.is_contiguous() and w.is_contiguous()
     ho, wo = (hs * 2, ws * 2) if upsample else (hs, ws)
@@ -702,7 +716,7 @@ def conv3d_cl(x: torch.Tensor, in_slots, w: torch.Tensor, bias: Optional[torch.T
     d = _hip.Conv3dDesc(_dev(x, "x"), hs * ws * cin, ins, hs, ws, cin, 1 if upsample else 0, _dev(w, "w"),
                         _dev(bias, "bias") if bias is not None else None, kt, ks, _dev(y, "y"), ho * wo * cout, outs, cout,
                         t_out, _dev(residual, "residual") if residual is not None else None,
-                        _zero_page(x.device).data_ptr())
+                        _zero_page(x.device).data_ptr(), 1 if in_planar else 0)
     flops = 2.0 * t_out * ho * wo * cout * cin * taps
     with _timed("conv3d", flops, 0.0):
         _hip.check(_hip.load().ifx_conv3d_cl(C.byref(d), _stream()), "ifx_conv3d_cl")
@@ -710,13 +724,16 @@ def conv3d_cl(x: torch.Tensor, in_slots, w: torch.Tensor, bias: Optional[torch.T
 
 
 def rmsnorm_cl(x: torch.Tensor, gamma: torch.Tensor, y: torch.Tensor, out_slots, silu: bool) -> torch.Tensor:
-    """Per-pixel channel RMS norm (+ SiLU) of `x` `[frames, h, w, c]` into `y[out_slots[f]]` (ifx_rmsnorm_cl)."""
+    """Per-pixel channel RMS norm (+ SiLU) of `x` `[frames, h, w, c]` into `y[out_slots[f]]` (ifx_rmsnorm_cl); a 5-D `y`
+    `[slots, c/32, h, w, 32]` takes the frames in the planar layout (IFX_NORM_OUT_PLANAR)."""
     frames, h, w_, c = x.shape
-    assert x.is_contiguous() and y.is_contiguous() and tuple(y.shape[1:]) == (h, w_, c) and len(out_slots) == frames
+    out_planar = y.dim() == 5
+    assert x.is_contiguous() and y.is_contiguous() and len(out_slots) == frames
+    assert tuple(y.shape[1:]) == ((c // 32, h, w_, 32) if out_planar else (h, w_, c)), (tuple(y.shape), tuple(x.shape))
     assert gamma.numel() == c and max(out_slots) < y.shape[0]
     with _timed("rmsnorm_cl", 0.0, 4.0 * x.numel()):
         _hip.check(_hip.load().ifx_rmsnorm_cl(_dev(x, "x"), _dev(gamma, "gamma"), _dev(y, "y"), h * w_ * c, _slots(out_slots),
-                                              frames, h * w_, c, 1 if silu else 0, _stream()), "ifx_rmsnorm_cl")
+                                              frames, h * w_, c, (1 if silu else 0) | (2 if out_planar else 0), _stream()), "ifx_rmsnorm_cl")
     return y
 
 

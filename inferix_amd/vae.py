@@ -158,8 +158,11 @@ class FrameRing:
     """Input frames of one causal conv: `2 + cap` physical slots; `hist` = slots of the last two frames of the stream
     (-1 = a zero frame in front of the stream)."""
 
-    def __init__(self, cap: int, h: int, w: int, c: int, device):
-        self.buf = torch.empty(cap + 2, h, w, c, dtype=BF16, device=device)
+    def __init__(self, cap: int, h: int, w: int, c: int, device, planar: bool = False):
+        # planar: frames as 32-channel planes `[c/32, h, w, 32]` (ifx_conv3d_desc.in_planar) — the layout the 3x3x3 convs read their
+        # halo patches from at the full LDS-DMA rate (contiguous 64-byte pixels per channel chunk)
+        self.planar = planar
+        self.buf = torch.empty((cap + 2, c // 32, h, w, 32) if planar else (cap + 2, h, w, c), dtype=BF16, device=device)
         self.cap = cap
         self.hist = [-1, -1]
 
@@ -210,13 +213,13 @@ class _VaeLayers:
         W[f"{p}.proj.b"] = g(f"{p}.proj.bias").to(BF16).contiguous()
 
     # ---- buffers ----------------------------------------------------------------------------------------------------
-    def _ring(self, name: str, cap: int, h: int, w: int, c: int) -> FrameRing:
+    def _ring(self, name: str, cap: int, h: int, w: int, c: int, planar: bool = False) -> FrameRing:
         key = (name, h, w)
         r = self._rings.get(key)
         if r is None or r.cap < cap:
             hist = r.hist if r is not None else None
             assert hist is None or hist == [-1, -1], "frame ring would have to grow mid-stream: raise max_frames_per_call"
-            r = self._rings[key] = FrameRing(cap, h, w, c, self.device)
+            r = self._rings[key] = FrameRing(cap, h, w, c, self.device, planar)
         return r
 
     def _tmp(self, tag: str, *shape) -> torch.Tensor:
@@ -237,10 +240,12 @@ class _VaeLayers:
                      residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[norm + SiLU ->] ring -> 3x3x3 causal conv.  `src` plain `[t, h, w, cin]`; `out` plain `[t, h, w, cout]`."""
         t, h, w, c = src.shape
-        ring = self._ring(name, self._cap(h), h, w, c)
+        ring = self._ring(name, self._cap(h), h, w, c, planar=c % 32 == 0)
         new = ring.new_slots(t)
         if gamma is not None:
-            ops.rmsnorm_cl(src, self.W[gamma], ring.buf, new, silu=True)
+            ops.rmsnorm_cl(src, self.W[gamma], ring.buf, new, silu=True)          # (planar ring: 5-D buffer -> IFX_NORM_OUT_PLANAR)
+        elif ring.planar:
+            ring.buf[new] = src.view(t, h, w, c // 32, 32).permute(0, 3, 1, 2, 4)
         else:
             ring.buf[new] = src
         ins = ring.commit(new)

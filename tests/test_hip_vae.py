@@ -58,8 +58,20 @@ CASES = [
 ]
 
 
+# the ping-pong kernel's shapes (3 x 3 spatial, cout % 96 == 0): several tiles per workgroup, ragged tiles, many stages, both layouts
+CASES += [
+    (3, 3, 0, 96, 96, 40, 150, 3, True),
+    (3, 3, 0, 384, 192, 11, 70, 2, True),
+    (3, 3, 0, 32, 96, 21, 130, 1, False),
+    (1, 3, 1, 384, 192, 9, 40, 2, False),
+    (1, 3, 0, 96, 96, 17, 64, 2, True),
+]
+
+
+@pytest.mark.parametrize("planar", [False, True])
 @pytest.mark.parametrize("kt,ks,ups,cin,cout,h,w,t,res", CASES)
-def test_conv3d_cl_against_torch(ops, kt, ks, ups, cin, cout, h, w, t, res):
+def test_conv3d_cl_against_torch(ops, kt, ks, ups, cin, cout, h, w, t, res, planar):
+    """`planar`: the input frames in the 32-channel-plane layout of the frame rings (ifx_conv3d_desc.in_planar) — the same bits."""
     g = torch.Generator().manual_seed(kt * 1000 + ks * 100 + cin + cout + h + w)
     n_in = t + kt - 1
     frames = rnd(g, n_in, h, w, cin)
@@ -75,13 +87,24 @@ def test_conv3d_cl_against_torch(ops, kt, ks, ups, cin, cout, h, w, t, res):
     out_slots = torch.randperm(t + 1, generator=g)[:t].tolist()
     y = torch.zeros(t + 1, ho, wo, cout, dtype=BF, device="cuda")
     from inferix_amd.vae import _repack_conv
-    ops.conv3d_cl(buf.cuda(), perm, _repack_conv(wt).cuda(), b.cuda(), kt=kt, ks=ks, y=y, out_slots=out_slots,
+    xin = ops.to_planar(buf.cuda()) if planar else buf.cuda()
+    ops.conv3d_cl(xin, perm, _repack_conv(wt).cuda(), b.cuda(), kt=kt, ks=ks, y=y, out_slots=out_slots,
                   upsample=bool(ups), residual=residual.cuda() if res else None)
     ref = ref_conv(frames, wt, b, kt, ks, ups, residual)
     got = torch.stack([y[s] for s in out_slots]).cpu()
     assert_bf16_parity(got, ref, max_ulp=2 if res else 1, floor=1.0, what=f"conv kt{kt} ks{ks} ups{ups} {cin}->{cout}")
     untouched = [s for s in range(t + 1) if s not in out_slots]
     assert all(float(y[s].abs().max()) == 0.0 for s in untouched)
+    if ks == 3 and cout % 96 == 0:
+        # the lock-step kernel of round 1 on the same launch: the same K order and epilogue rounding, bit for bit
+        y1 = torch.zeros_like(y)
+        ops.set_option("conv_variant", 1)
+        try:
+            ops.conv3d_cl(xin, perm, _repack_conv(wt).cuda(), b.cuda(), kt=kt, ks=ks, y=y1, out_slots=out_slots,
+                          upsample=bool(ups), residual=residual.cuda() if res else None)
+        finally:
+            ops.set_option("conv_variant", 0)
+        assert torch.equal(y.view(torch.int16), y1.view(torch.int16)), "ping-pong and lock-step conv kernels differ"
 
 
 def test_conv3d_cl_zero_history_is_causal_padding(ops):
@@ -128,6 +151,10 @@ def test_rmsnorm_cl(ops, c, silu):
     got = torch.stack([y[4], y[0], y[2]]).cpu()
     assert_bf16_parity(got, ref, max_ulp=2, floor=0.05, what=f"rmsnorm_cl c{c} silu{silu}")
     assert float(y[1].abs().max()) == 0.0 and float(y[3].abs().max()) == 0.0
+    # the planar output layout (IFX_NORM_OUT_PLANAR): the same values, 32-channel planes
+    yp = torch.zeros(5, c // 32, 7, 9, 32, dtype=BF, device="cuda")
+    ops.rmsnorm_cl(x.cuda(), gamma.cuda(), yp, [4, 0, 2], silu=silu)
+    assert torch.equal(yp.view(torch.int16), ops.to_planar(y).view(torch.int16))
 
 
 @pytest.mark.parametrize("rows,cols", [(96, 96), (130, 250), (7, 6240)])

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--shapes", default="main")
 ap.add_argument("--variants", default="0,1")
+ap.add_argument("--cl", action="store_true", help="channels-last input frames (default: the planar layout of the frame rings)")
 a = ap.parse_args()
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
@@ -34,6 +35,9 @@ print(f"{'shape':44s}" + "".join(f"  v{v}: us/launch  TFLOP/s" for v in variants
 for cin, cout, h, w_, t, kt, ups, has_res in SHAPES:
     ho, wo = (2 * h, 2 * w_) if ups else (h, w_)
     ring = rnd(t + kt - 1, h, w_, cin)
+    ring_cl = ring
+    if not a.cl and not ups:
+        ring = ops.to_planar(ring)                        # as the decoder's frame rings hand the frames over (not the upsample convs' inputs)
     wt = (rnd(kt * 9, cin // 32, cout, 32) * (kt * 9 * cin) ** -0.5).contiguous()
     b = rnd(cout)
     res = rnd(t, ho, wo, cout) if has_res else None
@@ -57,8 +61,12 @@ for cin, cout, h, w_, t, kt, ups, has_res in SHAPES:
         us = e0.elapsed_time(e1) * 1e3 / a.reps
         line += f"  {us:12.1f} {flops / us * 1e-6:8.1f}"
         outs.append(y)
+    if ring is not ring_cl:                               # the channels-last form of the same launch: the same bits
+        ycl = torch.empty_like(outs[0])
+        ops.conv3d_cl(ring_cl, slots, wt, b, kt=kt, ks=3, y=ycl, out_slots=list(range(t)), upsample=bool(ups), residual=res)
+        outs.append(ycl)
     same = all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:])
     nan = any(bool(torch.isnan(o.float()).any()) for o in outs)
     print(line + ("   identical" if same else "   DIFFERENT") + ("  NaN!" if nan else ""), flush=True)
-    del ring, res, outs, y
+    del ring, ring_cl, res, outs, y
 ops.set_option("conv_variant", 0)
