@@ -100,6 +100,12 @@ struct AttnArgsPP {
   // [rt0[r], rt0[r + 1]) of a head belong to range r (MAGI: the denoising chunks of one forward in ONE launch)
   int n_ranges;
   int rq0[8], rq1[8], rk0[8], rk1[8], rt0[9];
+  // paged views with a table (round 6): every workgroup copies the table into LDS at `pt_lds_off` (bytes; < 0: not available, look it
+  // up in global memory per key) and translates key -> page with a multiply-high by `ps_magic` = floor(2^32 / page_size) + 1 (exact
+  // while key * page_size < 2^32).  Before: a runtime integer division and a DEPENDENT global load of the table entry per lane in
+  // front of every K/V piece request — the paged kernel ran at 0.54x the contiguous one (943 -> 1746 us over 32760 keys).
+  int pt_lds_off, n_pages;
+  unsigned ps_magic;
 };
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
@@ -231,6 +237,15 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   // carries them as "maybe pending" around the loop back-edge and protects every first use of qf in the loop with
   // vmcnt(7..0) — which, since the asm-issued DMA below shares the counter, drains the K/V prefetch queue every tile.
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  const int* pt_lds = nullptr;
+  if constexpr (PAGED) {
+    if (A.pt_lds_off >= 0) {
+      int* dst = reinterpret_cast<int*>(smem + A.pt_lds_off);
+      for (int i = tid; i < A.n_pages; i += NG * 256) dst[i] = A.ka.pt[i];
+      __syncthreads();                               // (workgroup-uniform: before the first request)
+      pt_lds = dst;
+    }
+  }
 
   // ---- LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): a tile is 16 K pieces + 16 V pieces of
   //      1 KiB (4 key rows x 256 B); wave w moves pieces w and w+8.  Per lane only a 32-bit voffset per piece is
@@ -268,7 +283,14 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int key = min(kv_s + t * KT + d_row0 + 32 * r, last_key);
-        const int delta = (A.ka.slot(key) - d_row0) * row_bytes;         // physical row instead of tile row
+        int phys;
+        if (pt_lds != nullptr) {
+          const int pg = (int)__umulhi((unsigned)key, A.ps_magic);
+          phys = pt_lds[pg] * A.ka.ps + (key - pg * A.ka.ps);
+        } else {
+          phys = A.ka.slot(key);
+        }
+        const int delta = (phys - d_row0) * row_bytes;                  // physical row instead of tile row
         if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff + delta, 0);
         if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff + delta, 0);
       }
@@ -1190,45 +1212,51 @@ static void launch_pp_dual(const AttnArgsPP& a, bool paged, bool split, dim3 gri
   }
 }
 
+constexpr int PT_LDS_BYTES = 4096;       // LDS copy of a page table: up to 1024 pages, behind the K/V rings of the one-per-CU schedules
+
 template <int FR>
-static void launch_pp_fr(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
+static void launch_pp_fr(AttnArgsPP a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   using namespace pp;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
     attr_set = true;
   }
   const dim3 block(512);
+  int lds = LDS_ALLOC;
+  if (paged && a.ka.pt != nullptr && a.n_pages * 4 <= PT_LDS_BYTES && a.ps_magic != 0) a.pt_lds_off = LDS_ALLOC, lds += PT_LDS_BYTES;
   if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 2, FR>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 2, FR>), grid, block, LDS_ALLOC, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 2, FR>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 2, FR>), grid, block, lds, stream, a);
   } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2, FR>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 2, FR>), grid, block, LDS_ALLOC, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2, FR>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 2, FR>), grid, block, lds, stream, a);
   }
 }
 
 template <int NG>
-static void launch_pp_ng(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
+static void launch_pp_ng(AttnArgsPP a, bool paged, bool split, dim3 grid, hipStream_t stream) {
   using namespace pp;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
     attr_set = true;
   }
   const dim3 block(NG * 256);
+  int lds = LDS_ALLOC;
+  if (paged && a.ka.pt != nullptr && a.n_pages * 4 <= PT_LDS_BYTES && a.ps_magic != 0) a.pt_lds_off = LDS_ALLOC, lds += PT_LDS_BYTES;
   if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, NG>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, NG>), grid, block, LDS_ALLOC, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, NG>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, NG>), grid, block, lds, stream, a);
   } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, NG>), grid, block, LDS_ALLOC, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, NG>), grid, block, LDS_ALLOC, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, NG>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, NG>), grid, block, lds, stream, a);
   }
 }
 
@@ -1261,6 +1289,9 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.kv_heads = kv->kv_heads;
   a.q_per_kv = heads / kv->kv_heads;
   a.q_tiles = (q_rows + QT - 1) / QT;
+  a.pt_lds_off = -1;                                 // the launchers of the one-per-CU schedules turn the LDS table on
+  a.n_pages = kv->page_table ? (kv->num_slots + kv->page_size - 1) / kv->page_size : 0;
+  a.ps_magic = (kv->page_table && kv->page_size >= 2 && (long long)kv->num_slots * kv->page_size < (1ll << 32)) ? (unsigned)((1ull << 32) / (unsigned)kv->page_size) + 1u : 0u;
   a.n_ranges = 0;
   if (n_ranges > 0) {
     // longest key ranges first: tile ids are handed out in order, so the expensive tiles must not be the tail of the launch
