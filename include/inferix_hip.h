@@ -38,7 +38,7 @@ typedef uint16_t ifx_bf16;
 
 /* library identity ------------------------------------------------------- */
 /* The MINOR number is the ABI generation: it changes whenever an argument struct gains a field or an entry point changes its
- * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static; 0.6: ifx_get_option, ifx_device_error, bounded device waits).  Callers built against another minor
+ * signature (0.2: ifx_kv_view.seg_split / seg_delta, ifx_rope_grid.q_scale; 0.3: ifx_magi_head_prep_desc.rope_half, gemm_small_split; 0.4: ifx_gemm_q8_quant_out, ifx_layernorm_quant_static; 0.6: ifx_get_option, ifx_device_error, bounded device waits; 0.7: ifx_conv3d_desc.in_planar, IFX_NORM_OUT_PLANAR, conv_variant, attn_debug_counters).  Callers built against another minor
  * must not call in: zero-initialise every struct (new fields default to 0 = off) and compare IFX_ABI_MINOR with
  * (ifx_version() >> 8) & 255 at load time, as inferix_amd/_hip.py does. */
 #define IFX_ABI_MINOR 7
@@ -76,6 +76,11 @@ const char* ifx_arch(void);            /* "gfx950" */
  *                   4 free-running schedule, 5 software-pipelined schedule, 6 software-pipelined in four-wave workgroups, two per CU,
  *                   7 software-pipelined and unrolled four times over constant LDS slots (what 0 = auto picks for large launches)
  * Results are identical across variants up to fp32 summation order.  Returns IFX_EINVAL for unknown keys. */
+/*   "conv_variant":     0 = auto (round 6: the persistent ping-pong kernel for 3x3 spatial kernels with cout % 96 == 0), 1 = the lock-step
+ *                       kernel of round 1 everywhere (A/B: tools/bench_conv.py; the two produce identical bits).
+ *   "attn_debug_counters": tests only — 1 allocates and zeroes a device word that the ping-pong attention kernels increment once per
+ *                       (wave, key tile) that takes the rescale branch of the lazy row maximum; read it with
+ *                       ifx_get_option("attn_rescale_count") (synchronises the device); 0 turns the counting off. */
 int ifx_set_option(const char* key, int32_t value);
 /* The value an option has NOW in the library (set through ifx_set_option by anyone in the process, or its environment default):
  * what a scoped override has to put back (a Python-side mirror misses options set through another binding).

@@ -106,6 +106,9 @@ struct AttnArgsPP {
   // front of every K/V piece request — the paged kernel ran at 0.54x the contiguous one (943 -> 1746 us over 32760 keys).
   int pt_lds_off, n_pages;
   unsigned ps_magic;
+  // tests (option "attn_debug_counters"): a device word that counts the (wave, tile) pairs that took the rescale branch of the lazy
+  // row maximum; nullptr in every normal launch (the increment sits inside the rare branch only)
+  unsigned* dbg_rescales;
 };
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
     exp_block(1);
     float tile_sum = v_acc[0] + v_acc[1];
     if (__any(!(tile_sum < kLazyLimit))) {         // rare: this tile outgrew the reference (inf / NaN land here too)
+      if (A.dbg_rescales != nullptr && lane == 0) atomicAdd(A.dbg_rescales, 1u);
       const float m_new = tile_max();              // >= m_run, identical in lane and lane^32
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
       m_run = m_new;
@@ -792,6 +796,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       }
       if (PRE) {
         if (__any(!(tile_sum < kLazyLimit))) {         // rare: sC holds S(t) - m_run, sN already holds S(t+1) - m_run
+          if (A.dbg_rescales != nullptr && lane == 0) atomicAdd(A.dbg_rescales, 1u);
           const float d = true_max(sC, 0.f);           // >= 0: how far this tile's maximum lies above the reference
           const float alpha = __builtin_amdgcn_exp2f(-d);
           tile_sum = exp_plain(sC, pC, d);
@@ -805,6 +810,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
             for (int r = 0; r < 16; ++r) sN[b][r] -= d;
         }
       } else if (__any(!(tile_sum < kLazyLimit))) {    // rare: this tile outgrew the reference maximum
+        if (A.dbg_rescales != nullptr && lane == 0) atomicAdd(A.dbg_rescales, 1u);
         const float m_new = true_max(sC, m_run);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
         m_run = m_new;
@@ -1289,6 +1295,7 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.kv_heads = kv->kv_heads;
   a.q_per_kv = heads / kv->kv_heads;
   a.q_tiles = (q_rows + QT - 1) / QT;
+  a.dbg_rescales = attn_debug_counter();
   a.pt_lds_off = -1;                                 // the launchers of the one-per-CU schedules turn the LDS table on
   a.n_pages = kv->page_table ? (kv->num_slots + kv->page_size - 1) / kv->page_size : 0;
   a.ps_magic = (kv->page_table && kv->page_size >= 2 && (long long)kv->num_slots * kv->page_size < (1ll << 32)) ? (unsigned)((1ull << 32) / (unsigned)kv->page_size) + 1u : 0u;

@@ -152,6 +152,7 @@ unsigned* device_error_word();    // pinned host word, mapped into every device,
 long long spin_timeout_ticks();   // budget of a device-side wait in ticks of the 100 MHz wall clock (option "spin_timeout_ms", default 2000 ms)
 int spin_fault();                 // lab / tests: 1 = split-K producers do not raise their flag, so that the consumer's wait runs into its budget
 int conv_variant();   // 0 auto (persistent ping-pong kernel where it applies), 1 the lock-step kernel of round 1
+unsigned* attn_debug_counter();   // tests: device word counting lazy-maximum rescales of the ping-pong attention kernels (option "attn_debug_counters"), else nullptr
 int attn_variant();   // 0 auto (= 7 for large launches), 1 four-wave kernel, 2 ping-pong, 3 three groups, 4 free-running, 5 software-pipelined, 6 its two-per-CU form, 7 its four-times-unrolled form
 
 }  // namespace ifx

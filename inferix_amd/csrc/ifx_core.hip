@@ -30,6 +30,12 @@ static int opt_or_env(int& slot, const char* env, int dflt = 0) {
 int gemm_variant() { return opt_or_env(g_gemm_variant, "IFX_GEMM_VARIANT"); }
 int attn_variant() { return opt_or_env(g_attn_variant, "IFX_ATTN_VARIANT"); }
 int conv_variant() { return opt_or_env(g_conv_variant, "IFX_CONV_VARIANT"); }
+// tests: ifx_set_option("attn_debug_counters", 1) allocates (and zeroes) a device word that the ping-pong attention kernels increment once
+// per (wave, key tile) that takes the rescale branch of the lazy row maximum; ifx_get_option("attn_rescale_count") synchronises the device
+// and reads it; ifx_set_option("attn_debug_counters", 0) turns the counting off again.  One word per process (the current device's).
+static unsigned* g_attn_dbg = nullptr;
+static bool g_attn_dbg_on = false;
+unsigned* attn_debug_counter() { return g_attn_dbg_on ? g_attn_dbg : nullptr; }
 int gemm_small_split() { return opt_or_env(g_gemm_small_split, "IFX_GEMM_SMALL_SPLIT"); }
 
 // ---- device-side waits are BOUNDED.  A kernel that waits for another workgroup (the split-K / stream-K hand-off of ifx_gemm_pp.hip)
@@ -87,6 +93,19 @@ extern "C" int ifx_set_option(const char* key, int32_t value) {
   if (key && !strcmp(key, "gemm_small_split") && (value == 0 || value == 1)) { ifx::g_gemm_small_split = value; return IFX_OK; }
   if (key && !strcmp(key, "attn_variant") && value >= 0 && value <= 7) { ifx::g_attn_variant = value; return IFX_OK; }
   if (key && !strcmp(key, "conv_variant") && value >= 0 && value <= 1) { ifx::g_conv_variant = value; return IFX_OK; }
+  if (key && !strcmp(key, "attn_debug_counters") && (value == 0 || value == 1)) {
+    if (value == 1) {
+      if (ifx::g_attn_dbg == nullptr && hipMalloc((void**)&ifx::g_attn_dbg, 64) != hipSuccess) {
+        ifx::g_attn_dbg = nullptr;
+        ifx::set_error("ifx_set_option: attn_debug_counters: hipMalloc failed");
+        return IFX_ELAUNCH;
+      }
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(ifx::g_attn_dbg, 0, 64);
+    }
+    ifx::g_attn_dbg_on = value == 1;
+    return IFX_OK;
+  }
   if (key && !strcmp(key, "spin_timeout_ms") && value >= 1 && value <= 600000) { ifx::g_spin_timeout_ms = value; return IFX_OK; }
   if (key && !strcmp(key, "spin_fault") && (value == 0 || value == 1)) { ifx::g_spin_fault = value; return IFX_OK; }
   ifx::set_error("ifx_set_option: unknown key or value out of range: %s = %d", key ? key : "(null)", (int)value);
@@ -98,6 +117,16 @@ extern "C" int ifx_get_option(const char* key, int32_t* value) {
   if (!strcmp(key, "gemm_small_split")) { *value = ifx::gemm_small_split(); return IFX_OK; }
   if (!strcmp(key, "attn_variant")) { *value = ifx::attn_variant(); return IFX_OK; }
   if (!strcmp(key, "conv_variant")) { *value = ifx::conv_variant(); return IFX_OK; }
+  if (!strcmp(key, "attn_debug_counters")) { *value = ifx::g_attn_dbg_on ? 1 : 0; return IFX_OK; }
+  if (!strcmp(key, "attn_rescale_count")) {
+    unsigned v = 0;
+    if (ifx::g_attn_dbg != nullptr) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(&v, ifx::g_attn_dbg, sizeof(v), hipMemcpyDeviceToHost);
+    }
+    *value = (int32_t)(v & 0x7fffffffu);
+    return IFX_OK;
+  }
   if (!strcmp(key, "spin_timeout_ms")) { *value = (int32_t)(ifx::spin_timeout_ticks() / 100000LL); return IFX_OK; }
   if (!strcmp(key, "spin_fault")) { *value = ifx::spin_fault(); return IFX_OK; }
   ifx::set_error("ifx_get_option: unknown key: %s", key);

@@ -306,8 +306,8 @@ def check_device(what: str = "", sync: bool = False) -> None:
 
 
 def set_option(key: str, value: int) -> None:
-    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..29, 'attn_variant' 0..7, 'gemm_small_split' 0/1,
-    'spin_timeout_ms', 'spin_fault' (include/inferix_hip.h); 0 = choose by shape."""
+    """Kernel-selection override (`ifx_set_option`): 'gemm_variant' 0..29, 'attn_variant' 0..7, 'conv_variant' 0/1, 'gemm_small_split' 0/1,
+    'spin_timeout_ms', 'spin_fault', 'attn_debug_counters' (include/inferix_hip.h); 0 = choose by shape."""
     _hip.check(_hip.load().ifx_set_option(key.encode(), int(value)), "ifx_set_option")
     _OPTIONS[key] = int(value)
     if key == "gemm_small_split":

@@ -1,5 +1,7 @@
 """GPU parity tests of the host-side mirror (HipCausalWanModel / HipWanDiffusionWrapper /
 CausalInferencePipeline) against the reference-generated golden vectors and the CPU oracle."""
+import os
+import sys
 from types import SimpleNamespace
 
 import pytest
@@ -503,7 +505,7 @@ def test_config1_full_size_full_depth_vs_reference_golden():
     pipe = CausalInferencePipeline(args, "cuda", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": pe.cuda()}, vae=None)
     kvm, reqs = KVCacheManager("cuda"), [KVCacheRequest("r")]
     out = pipe.inference(noise=noise.cuda(), text_prompts=["x"], kv_cache_manager=kvm, kv_cache_requests=reqs,
-                         decode_mode=DecodeMode.NO_DECODE)
+                         decode_mode=DecodeMode.NO_DECODE, free_cache_before_vae=False)
     torch.cuda.synchronize()
     ref, exact, floor = fx["out"], fx["out_exact"], float(fx["floor"])
     assert float(fx["oracle_maxdiff"]) == 0.0, "the CPU oracle is pinned to the reference at this size and depth too"
@@ -583,3 +585,111 @@ def test_block_720p_full_size_vs_reference_golden(case):
     if start:
         assert torch.equal(raw[0, :start, 0].cpu(), d["prefix_k"]), "the prefix must not be touched"
     assert not bool(raw[:, end:].any()), "slots behind kv_end must stay untouched"
+
+
+def _heavy_block_run(m, d, cfg, n, fs):
+    """Two consecutive 3-frame blocks of the heavy-tailed fixture through `m`'s layer 0; returns the outputs and the cache tensor."""
+    from inferix_amd import hip_ops as ops
+    from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
+    kvm, req = KVCacheManager("cuda"), [KVCacheRequest("r")]
+    ad = m.blocks[0].kv_cache_manager
+    ad.allocate_kv_cache(kv_cache_manager=kvm, kv_cache_request=req[0], sequence_length=2 * n, dtype=BF)
+    ad.allocate_crossattn_cache(kv_cache_manager=kvm, kv_cache_request=req[0], crossattn_length=cfg.text_len, dtype=BF)
+    meta = {"global_end_index": torch.tensor([0]), "local_end_index": torch.tensor([0])}
+    cmeta = {"is_init": False}
+    ctx = d["context"][0].cuda()
+    outs = []
+    for b in range(2):
+        x = d[f"x{b}"][0].cuda().clone()
+        El = (m.mod_all[0] + d[f"e0_{b}"][0].cuda()).contiguous()
+        rope = ops.RopeGridSpec(m.freqs, b * 3, cfg.latent_h // 2, cfg.latent_w // 2)
+        st = dict(B=1, N=n, F_=3, fs=fs, rows_per_group=fs, rope=rope, sink_tokens=0, current_start=b * n, ctx=ctx)
+        m._run_block(0, x, El, st, meta, cmeta, kvm, req)
+        outs.append(x.cpu())
+    torch.cuda.synchronize()
+    return outs, kvm.get_raw(req[0], "layer_0")
+
+
+def test_block_heavy_tailed_statistics_vs_reference_golden():
+    """Realistic magnitudes (round-5 verdict, item 4): one block at the real channel geometry with OUTLIER statistics generated through
+    the reference (tests/golden/block_heavy_tail.npz, oracle/gen_golden_block_heavy.py): norm_q / norm_k channels x 50 (scores spanning
+    hundreds of nats), FFN rows x 50, a x 100 text token, activations up to 2^8, one frame with 4x modulation.  The paths that depend
+    on magnitudes — the attention kernel's lazy row maximum with its rescale branch, q pre-multiplied by scale * log2 e, the bf16
+    gate x residual epilogues — against the reference's rows by the floor rule, on the output AND on the block's update `out - x`
+    (the input's own 2^8 entries dominate the output's norm).  A debug counter proves the rescale branch ran."""
+    import gen_golden_block_heavy as GH
+    from fixture_io import weights_checksum
+    from inferix_amd import hip_ops as ops
+    fx = golden("block_heavy_tail.npz")
+    cfg = GH.config()
+    W = GH.heavy_weights(cfg)
+    assert weights_checksum(W) == int(fx["weights_checksum"]), "seeded weights drifted from the generator's"
+    d = GH.make_inputs(cfg)
+    assert all(torch.equal(d[k], fx[k]) for k in ("context", "x0", "x1", "e0_0", "e0_1")), "seeded inputs drifted from the generator's"
+    m = build(cfg, W)
+    fs = cfg.frame_seqlen
+    n = 3 * fs
+    # twice: the kernel the shape-based choice picks for a 288-row launch (the four-wave kernel, which tracks the row maximum per 32-key
+    # block), and the software-pipelined ping-pong kernel of the full-size launches (attn_variant 7: lazy maximum + rescale branch)
+    for variant in (0, 7):
+        ops.set_option("attn_variant", variant)
+        ops.set_option("attn_debug_counters", 1)
+        try:
+            outs, raw = _heavy_block_run(m, d, cfg, n, fs)
+            rescales = ops.get_option("attn_rescale_count")
+        finally:
+            ops.set_option("attn_debug_counters", 0)
+            ops.set_option("attn_variant", 0)
+        print(f"heavy-tailed block, attn_variant {variant}: {rescales} (wave, key tile) pairs took the lazy-maximum rescale branch")
+        if variant == 7:
+            assert rescales > 0, "the fixture is meant to drive the ping-pong attention kernel through its rescale branch"
+        for b in range(2):
+            ref, exact, x = fx[f"out{b}"][0], fx[f"out{b}_exact"][0], fx[f"x{b}"][0]
+            assert torch.isfinite(outs[b].float()).all()
+            floor, r, rx = rel_l2(ref, exact), rel_l2(outs[b], ref), rel_l2(outs[b], exact)
+            upd = lambda t: t.double() - x.double()
+            floor_u, r_u, rx_u = rel_l2(upd(ref), upd(exact)), rel_l2(upd(outs[b]), upd(ref)), rel_l2(upd(outs[b]), upd(exact))
+            print(f"heavy-tailed block #{b}: output floor {floor:.3e}, HIP vs reference {r:.3e}, vs exact {rx:.3e}; update (out - x) floor {floor_u:.3e}, "
+                  f"HIP vs reference {r_u:.3e}, vs exact {rx_u:.3e}; {ulp_report(outs[b], ref)}")
+            assert r <= 1.25 * floor + 5e-4 and rx <= 1.25 * floor + 5e-4, (variant, b, floor, r, rx)
+            assert r_u <= 1.25 * floor_u + 5e-4 and rx_u <= 1.25 * floor_u + 5e-4, (variant, b, floor_u, r_u, rx_u)
+    k_rel, v_rel = rel_l2(raw[0, :2 * n, 0].cpu(), fx["cache_k"]), rel_l2(raw[1, :2 * n, 0].cpu(), fx["cache_v"])
+    print(f"heavy-tailed cache rows vs reference: K rel-L2 {k_rel:.3e} ({ulp_report(raw[0, :2 * n, 0].cpu(), fx['cache_k'])}), V {v_rel:.3e}")
+    assert k_rel <= 1e-3 and v_rel <= 1e-3
+
+
+@pytest.mark.parametrize("which", ["fp8", "int8"])
+def test_block_heavy_tailed_statistics_quantised_vs_quantised_oracle(which):
+    """The same heavy-tailed block on the 8-bit path (per-token x per-channel dynamic quantisation of all ten linears: the e4m3 clamp
+    and the per-token scales see rows whose maximum is 2^8 while most entries are O(1)) against the quantised-model oracle evaluated
+    here on the CPU (`wan_oracle` with `quant_oracle`'s linear under the reference's exclusion dict; DAX itself: unpinned).  Floor rule
+    on the output and on the update, floors from the quantised oracle's own bf16-SDPA vs exact-attention runs."""
+    import gen_golden_block_heavy as GH
+    import quant_oracle as Q
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_hip_quant import _quantised
+    cfg = GH.config()
+    W = GH.heavy_weights(cfg)
+    d = GH.make_inputs(cfg)
+    fs = cfg.frame_seqlen
+    n = 3 * fs
+    fmt = Q.FP8 if which == "fp8" else Q.INT8
+    freqs = O.rope_freqs(cfg.head_dim)
+    want = {}
+    for impl in ("sdpa", "math"):
+        st = O.CacheState.allocate(cfg, 1, BF, cache_tokens=2 * n)
+        with O.linear_override(Q.model_hook(Q.reference_qconfig_dict(fmt))):
+            want[impl] = [O.block_forward(d[f"x{b}"], d[f"e0_{b}"], d["context"], W, 0, cfg, (3, cfg.latent_h // 2, cfg.latent_w // 2), freqs,
+                                          st, b * n, attn_impl=impl)[0] for b in range(2)]
+    m, _ = _quantised(cfg, W, which)
+    outs, _ = _heavy_block_run(m, d, cfg, n, fs)
+    for b in range(2):
+        ref, exact, x = want["sdpa"][b], want["math"][b].to(BF), d[f"x{b}"][0]
+        assert torch.isfinite(outs[b].float()).all()
+        upd = lambda t: t.double() - x.double()
+        floor, r, rx = rel_l2(ref, exact), rel_l2(outs[b], ref), rel_l2(outs[b], exact)
+        floor_u, r_u, rx_u = rel_l2(upd(ref), upd(exact)), rel_l2(upd(outs[b]), upd(ref)), rel_l2(upd(outs[b]), upd(exact))
+        print(f"heavy-tailed {which} block #{b}: output floor {floor:.3e}, HIP vs q8 oracle {r:.3e}, vs exact {rx:.3e}; update floor {floor_u:.3e}, "
+              f"HIP vs q8 oracle {r_u:.3e}, vs exact {rx_u:.3e}")
+        assert r <= 1.25 * floor + 5e-4 and rx <= 1.25 * floor + 5e-4, (b, floor, r, rx)
+        assert r_u <= 1.25 * floor_u + 5e-4 and rx_u <= 1.25 * floor_u + 5e-4, (b, floor_u, r_u, rx_u)
