@@ -959,6 +959,19 @@ def main():
                          "measured_on": "HIP events around every self-attention launch of ONE clip run right behind the timed region "
                                         "(same process, same launches; kept out of `value`)"},
         }
+        if world > 1:
+            # the first real multi-GPU line is to be read against a PREDICTION (round-5 verdict, item 6): one emulated rank of `world` on one
+            # GPU with the exchange replaced by local copies = this rank's kernels with ZERO wire cost (profiles/sp_emulated_prediction.json,
+            # measured by `bench.py --emulate-sp P --sp-exchange peer`).  xGMI can only add to it: measured / predicted >= 1 is expected,
+            # and predicted 1-GPU / P-GPU ratios of 1.7 / 2.6 / 3.7 say that >= 4x at 8 GPUs is NOT expected from this decomposition.
+            try:
+                with open(os.path.join(ROOT, "profiles", "sp_emulated_prediction.json")) as f:
+                    pred = json.load(f)
+                p_ms = pred.get("ms_per_clip", {}).get(f"sp{world}")
+                res["sp_prediction"] = {"emulated_rank_ms_per_clip": p_ms, "one_gpu_ms_per_clip_same_box": pred.get("ms_per_clip", {}).get("sp1"),
+                                        "measured_over_predicted": round(dt / a.steps * 1e3 / p_ms, 3) if p_ms else None, "source": pred.get("source")}
+            except Exception as e:
+                res["sp_prediction"] = {"error": f"{type(e).__name__}: {e}"}
         if a.layers:
             res["config"]["INVALID"] = "debug run with fewer layers"
         if a.emulate_sp > 1:

@@ -63,8 +63,9 @@ def main():
             r = orig(x, in_slots, w, bias, kt=kt, ks=ks, y=y, out_slots=out_slots, upsample=upsample, residual=residual)
             e_.record()
             ho, wo = y.shape[1], y.shape[2]
-            key = f"k{kt}x{ks}x{ks}{'u' if upsample else ''} {x.shape[3]}->{w.shape[2]} @{ho}x{wo} t{len(out_slots)}"
-            recs.append((key, s_, e_, 2.0 * len(out_slots) * ho * wo * w.shape[2] * x.shape[3] * w.shape[0]))
+            cin = x.shape[1] * 32 if x.dim() == 5 else x.shape[3]            # planar frame rings: [slots, cin/32, h, w, 32]
+            key = f"k{kt}x{ks}x{ks}{'u' if upsample else ''} {cin}->{w.shape[2]} @{ho}x{wo} t{len(out_slots)}"
+            recs.append((key, s_, e_, 2.0 * len(out_slots) * ho * wo * w.shape[2] * cin * w.shape[0]))
             return r
 
         import inferix_amd.vae as vmod

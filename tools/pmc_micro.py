@@ -63,7 +63,7 @@ if "norm" in which:
 if "conv" in which:
     # the three dominant decoder shapes: 96->96 @480x832 (12 frames), 192->192 @240x416 (12), 384->384 @120x208 (6)
     for c, h, w_, t in ((96, 480, 832, 12), (192, 240, 416, 12), (384, 120, 208, 6)):
-        ring = rnd(t + 2, h, w_, c)
+        ring = ops.to_planar(rnd(t + 2, h, w_, c))           # as the decoder's frame rings hand the frames over (32-channel planes)
         wt = (rnd(27, c // 32, c, 32) * (27 * c) ** -0.5).contiguous()
         b = rnd(c)
         res = rnd(t, h, w_, c)

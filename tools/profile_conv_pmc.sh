@@ -10,7 +10,7 @@ MICRO="python $R/tools/pmc_micro.py conv 0 2"
 : > $OUT/${TAG}_pmc_conv.md
 pass() {
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "conv_cl" -d $OUT/${TAG}_pmcc_$name -o pmc -- $MICRO > /dev/null 2> $OUT/${TAG}_pmcc_$name.err
+  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "conv_(cl|pp)_kernel" -d $OUT/${TAG}_pmcc_$name -o pmc -- $MICRO > /dev/null 2> $OUT/${TAG}_pmcc_$name.err
   local db=$(ls $OUT/${TAG}_pmcc_$name/*/*.db $OUT/${TAG}_pmcc_$name/*.db 2>/dev/null | head -1)
   echo -e "\n## pass: $name\n" >> $OUT/${TAG}_pmc_conv.md
   python $R/tools/rocpd_pmc.py $db >> $OUT/${TAG}_pmc_conv.md 2>/dev/null
