@@ -2,6 +2,7 @@
 """Run single legs of bench.py on one GPU without the timed headline region (development aid):
     python tools/run_bench_leg.py streaming [blocks]     # streaming_steady_leg
     python tools/run_bench_leg.py config1                # cpu_baseline + config1_gpu + the hard parity check against config1_full.npz
+    python tools/run_bench_leg.py batch [B]              # batch_leg
     python tools/run_bench_leg.py decode                 # per_block_decode_leg + vae_decode_leg
 """
 import json
@@ -22,6 +23,8 @@ if which == "streaming":
     res = bench.streaming_steady_leg(model, gen, device, blocks=int(sys.argv[2]) if len(sys.argv) > 2 else 30)
 elif which == "config1":
     res = bench.cpu_baseline(30, gpu_leg=lambda W: bench.config1_gpu(model, gen, device, W))
+elif which == "batch":
+    res = bench.batch_leg(model, gen, device, int(sys.argv[2]) if len(sys.argv) > 2 else 2)
 elif which == "decode":
     from inferix_amd.core import DecodeMode
     from inferix_amd.kvcache_manager import KVCacheManager, KVCacheRequest
