@@ -309,7 +309,17 @@ def vae_decode_leg():
     vae.decode_to_pixel(lat, use_cache=True, chunk_size=BLOCK)
     ops.set_kernel_timer(None)
     cs = t.summary()["conv3d"]
-    return {"workload": f"Wan2.1 VAE decoder (dim 96), latent {LATENT[1]}x{LATENT[2]} -> {vid.shape[-2]}x{vid.shape[-1]} px, bf16, "
+    # shader clock while the decoder runs (the conv kernels sit at the socket power limit like the attention kernel: the fraction of the
+    # peak AT THE SUSTAINED CLOCK is reported beside the contract figure against the nominal 2.4 GHz peak)
+    with ClockSampler(0) as clocks:
+        for _ in range(4):
+            vae.decode_to_pixel(lat, use_cache=True, chunk_size=BLOCK)
+        torch.cuda.synchronize()
+    ck = clocks.summary()
+    conv_tf = cs["flops"] / (cs["ms"] * 1e-3) / 1e12
+    at_clock = round(conv_tf / (PEAK_BF16_TFLOPS * ck["sclk_mhz_median"] / 2400.0), 4) if ck.get("sclk_mhz_median") else None
+    return {"clocks": ck, "conv_frac_at_clock": at_clock,
+            "workload": f"Wan2.1 VAE decoder (dim 96), latent {LATENT[1]}x{LATENT[2]} -> {vid.shape[-2]}x{vid.shape[-1]} px, bf16, "
                         "synthetic weights; includes the fp32 [-1,1] pixel hand-off",
             "ms_per_block_streaming": round(blk_ms, 2), "video_frames_per_block": int(blk.shape[1]),
             "ms_per_clip": round(clip_ms, 1), "video_frames_per_clip": int(vid.shape[1]),

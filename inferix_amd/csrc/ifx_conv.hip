@@ -421,7 +421,7 @@ struct GeoP {
   // a stage's NPI patch pieces: group 0 moves the first 4 * PG0 (one per wave in each of its loader phases 6t-1, 6t+1, 6t+3: its loader
   // phases carry the 4-5 weight pieces per wave, ~90 cycles each, and a patch piece costs ~300 — 64-byte rows 192+ bytes apart), group 1
   // the rest in two batches (loader phases 6t, 6t+2)
-  static constexpr int PG0 = UPS ? 1 : 3;
+  static constexpr int PG0 = UPS ? 1 : 3;               // (1 or 2 for the plain kernel: group 1's lane terms no longer fit, 1-3 registers spill)
   static constexpr int NP1 = NPI - 4 * PG0;
   static constexpr int PPW = (NP1 + 3) / 4;             // patch piece slots per wave of group 1 and stage
   static constexpr int QA = (PPW + 1) / 2;              // of which in the first of the stage's two batches
