@@ -65,6 +65,8 @@ CASES += [
     (3, 3, 0, 32, 96, 21, 130, 1, False),
     (1, 3, 1, 384, 192, 9, 40, 2, False),
     (1, 3, 0, 96, 96, 17, 64, 2, True),
+    (3, 3, 0, 96, 3, 40, 150, 3, False),
+    (3, 3, 0, 64, 24, 19, 70, 2, True),
 ]
 
 

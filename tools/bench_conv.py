@@ -26,7 +26,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
 # (cin, cout, h, w, t, kt, upsample, residual)
 SHAPES = [(96, 96, 480, 832, 12, 3, 0, 1), (192, 192, 240, 416, 12, 3, 0, 1), (384, 384, 120, 208, 6, 3, 0, 1),
-          (384, 384, 60, 104, 3, 3, 0, 1), (192, 96, 240, 416, 12, 1, 1, 0)]
+          (384, 384, 60, 104, 3, 3, 0, 1), (192, 96, 240, 416, 12, 1, 1, 0), (96, 3, 480, 832, 12, 3, 0, 0)]
 if a.shapes == "all":
     SHAPES += [(384, 192, 120, 208, 12, 1, 1, 0), (192, 384, 120, 208, 6, 3, 0, 0), (96, 96, 480, 832, 1, 3, 0, 1), (384, 384, 60, 104, 1, 3, 0, 1),
                (32, 384, 60, 104, 3, 3, 0, 0), (96, 96, 50, 70, 2, 3, 0, 1), (192, 96, 25, 35, 2, 1, 1, 0)]
