@@ -563,28 +563,37 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(ln));                      // lane-derived addressing re-derived here: it would stay live across the K loop
     const int e31 = ln & 31, ehi = ln >> 5;
-    constexpr int PITCH = G::PITCH, CR = BN / 8, NIT = (32 * CR + 63) / 64;
+    constexpr int PITCH = G::PITCH, CG = BN / 32, NIT = 2 * CG;      // an iteration moves 16 pixels x one 32-channel group (4 chunks of 16 B)
     unsigned char* tr = smem + G::E_OFF + w4 * G::SCR;
     const int oh = t.h0 + wave;
-#ifdef IFX_CONVPP_NORES
-    const unsigned short* rf = nullptr;               // lab: what does the epilogue cost without the residual rows?
-#else
-    const unsigned short* rf = A.res ? A.res + (long long)t.to * A.Ho * A.Wo * A.Cout : nullptr;
-#endif
-    const bool row_ok = oh < A.Ho;
-    u16x8 rv[TJ][NIT];
-    if (rf != nullptr) {
+    if (oh >= A.Ho) return;                            // (wave-uniform: an image row below the frame)
+    // Whole-pixel-row accesses through buffer descriptors: a lane's byte offset = a term that depends on the lane alone (pixel of the
+    // 32-pixel block and 16-byte chunk it moves: computed once per epilogue) + a wave-uniform base per block — no per-access address
+    // arithmetic (the first version spent ~300 of the epilogue's ~1000 VALU instructions on 64-bit addresses, divisions by the chunk
+    // count and bounds).  Pixels right of the frame (last tile column only) get an out-of-range offset: loads return 0, stores are dropped.
+    const int frame_out_bytes = A.Ho * A.Wo * A.Cout * 2;
+    const __amdgpu_buffer_rsrc_t rs_y =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(A.y + (long long)A.out_slot[t.to] * A.out_frame_stride), 0, frame_out_bytes, 0x00020000);
+    const bool has_res = A.res != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_res ? A.res + (long long)t.to * A.Ho * A.Wo * A.Cout : A.y), 0, has_res ? frame_out_bytes : 0, 0x00020000);
+    // lane -> (pixel ln >> 2 of a 16-pixel half block, chunk ln & 3 of a 32-channel group): iteration it = (half hb, group cg) adds
+    // compile-time constants to two lane terms — 64-byte runs per pixel and instruction, the three groups of a pixel back to back
+    const int pl = ln >> 2;
+    const int l_lane = pl * PITCH + (ln & 3) * 16, g_lane = (pl * A.Cout + (ln & 3) * 8) * 2;
+    const int cols_left = A.Wo - t.w0;                 // pixels of the tile's 64 columns that lie inside the frame
+    u32x4 rv[TJ][NIT];
+    if (has_res) {
 #pragma unroll
-      for (int j = 0; j < TJ; ++j)
+      for (int j = 0; j < TJ; ++j) {
+        const int sbase = ((oh * A.Wo + t.w0 + 32 * j) * A.Cout + t.n_base) * 2;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int idx = it * 64 + ln;
-          const int p = idx / CR, c = idx - p * CR;
-          const int ow = t.w0 + j * 32 + p;
-          const bool ok = row_ok && p < 32 && ow < A.Wo;
-          const size_t off = ok ? ((size_t)oh * A.Wo + ow) * A.Cout + t.n_base + c * 8 : 0;
-          rv[j][it] = *reinterpret_cast<const u16x8*>(rf + off);
+          const int hb = it / CG, cg = it - hb * CG;
+          rv[j][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, pl < cols_left - 32 * j - 16 * hb ? g_lane : (int)0x80000000,
+                                                            sbase + (16 * hb * A.Cout + cg * 32) * 2, 0);
         }
+      }
     }
     u32x2 e_bias[TI][4];                               // from the copy the workgroup made in LDS (zeros without a bias): no memory round trip
 #pragma unroll
@@ -592,7 +601,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         e_bias[i][g] = *reinterpret_cast<const u32x2*>(smem + G::B_OFF + (t.n_base + i * 32 + g * 8 + ehi * 4) * 2);
-    unsigned short* yf = A.y + (long long)A.out_slot[t.to] * A.out_frame_stride;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
 #pragma unroll
@@ -611,21 +619,19 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
           *reinterpret_cast<u16x4*>(tr + e31 * PITCH + (i * 32 + g * 8 + ehi * 4) * 2) = o;
         }
       wait_lds();                                     // wave-private region: no barrier
+      const int sbase = ((oh * A.Wo + t.w0 + 32 * j) * A.Cout + t.n_base) * 2;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 64 + ln;
-        const int p = idx / CR, c = idx - p * CR;
-        const int ow = t.w0 + j * 32 + p;
-        const bool ok = row_ok && p < 32 && ow < A.Wo;
-        u16x8 v = *reinterpret_cast<const u16x8*>(tr + min(p, 31) * PITCH + c * 16);
-        if (rf != nullptr) {
+        const int hb = it / CG, cg = it - hb * CG;
+        u16x8 v = *reinterpret_cast<const u16x8*>(tr + l_lane + 16 * hb * PITCH + cg * 64);
+        if (has_res) {
+          const u16x8 r8 = __builtin_bit_cast(u16x8, rv[j][it]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[j][it][e]));
+          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r8[e]));
         }
-#ifdef IFX_CONVPP_NOSTORE
-        if (ok && v[0] == 0x7fc1) *reinterpret_cast<u16x8*>(yf + ((size_t)oh * A.Wo + ow) * A.Cout + t.n_base + c * 8) = v;      // lab: (almost) never
-#else
-        if (ok) *reinterpret_cast<u16x8*>(yf + ((size_t)oh * A.Wo + ow) * A.Cout + t.n_base + c * 8) = v;
+#ifndef IFX_CONVPP_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, pl < cols_left - 32 * j - 16 * hb ? g_lane : (int)0x80000000,
+                                               sbase + (16 * hb * A.Cout + cg * 32) * 2, 0);
 #endif
       }
       // (the LDS operations of one wave execute in order: the next block's writes cannot overtake these reads)
