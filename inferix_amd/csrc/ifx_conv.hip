@@ -499,17 +499,16 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       b_term[i] = (n * 64 + (((n >> 2) & 3) << 4)) ^ (fhi << 4);
     }
   }
-  // fragments of kernel row r of the stage in patch slot ps, weights in ring slot ws; `between(tg)` runs ahead of tap tg's reads (the
-  // loader's DMA instructions go there: the reads queue up at the LDS while the wave sits in a DMA issue stall)
+  // fragments of kernel row r of the stage in patch slot ps, weights in ring slot ws; `between(tg)` runs BEHIND tap tg's reads (the
+  // loader's DMA instructions go there: the reads just issued are served by the LDS while the wave sits in a DMA issue stall, and the
+  // other group's requests of the phase before have drained from the CU's vector-memory path by then — the first request of a phase
+  // waited ~480 cycles for them when it was issued straight behind the barrier)
   auto read_frags = [&](int r, int ps, int ws, auto between) __attribute__((always_inline)) {
     const unsigned char* pb = smem + G::P_OFF + ps * G::P_SLOT + (UPS ? (wave + r + 1) >> 1 : wave + r) * (PW * 64);
     const unsigned char* wg = smem + G::W_OFF + ws * G::W_STEP;
 #pragma unroll
     for (int tg = 0; tg < 3; ++tg) {
-      between(tg);
-#ifdef IFX_CONVPP_NOFRAG
-      continue;                                       // lab: DMA (and MFMAs on stale registers) only
-#endif
+#ifndef IFX_CONVPP_NOFRAG
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -518,6 +517,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fb[tg][ks][i] = *reinterpret_cast<const bf16x8*>(wg + tg * G::W_TAP + (b_term[i] ^ (ks << 5)));
+#endif
+      between(tg);
     }
   };
   f32x16 acc[TI][TJ];
@@ -812,11 +813,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       }
       CP_STAMP(3);
       if (c_s == S - 1 && c_r == 1) res_warm(c_t);
-      p_mine();
       CP_STAMP(7);
       // (the reads are unconditional: behind the last step they fetch stale LDS that nobody multiplies — a conditional read would keep the
       //  OLD fragments alive through the epilogue on the not-taken path, 120 registers next to the accumulators)
-      read_frags(c_r, c_sg & 1, (g + 1) & 1, w_between);          // + the weights of step g+2 into the slot step g was read from
+      read_frags(c_r, c_sg & 1, (g + 1) & 1, [&](int tg) __attribute__((always_inline)) {      // + the weights of step g+2 into the slot step g was read from
+        w_between(tg);
+        if (tg == 2) p_mine();
+      });
       __builtin_amdgcn_sched_barrier(0);
       CP_STAMP(4);
       wait_lds();
