@@ -83,6 +83,32 @@ def test_cabi_argument_validation_without_gpu():
     assert b"head_dim" in lib.ifx_last_error()
 
 
+def test_cabi_round6_additions_without_gpu():
+    """ABI minor 7 (round 6), checked without a GPU: the planar-input flag of `ifx_conv3d_desc` and the flags of `ifx_rmsnorm_cl` are
+    validated before any launch, the new option keys round-trip through `ifx_set_option` / `ifx_get_option`, and `hip_ops.to_planar`
+    is the documented layout `[t, c/32, h, w, 32]`."""
+    import ctypes as C
+    import torch
+    from inferix_amd import _hip, hip_ops
+    lib = _hip.load()
+    assert (lib.ifx_version() >> 8) & 255 == 7 == _hip.ABI_MINOR
+    slots3, slots1 = (C.c_int32 * 3)(0, 1, 2), (C.c_int32 * 1)(0)
+    d = _hip.Conv3dDesc(8, 8 * 8 * 64, slots3, 8, 8, 64, 0, 8, None, 3, 3, 8, 8 * 8 * 96, slots1, 96, 1, None, 8, 2)      # in_planar = 2
+    assert lib.ifx_conv3d_cl(C.byref(d), None) == -1 and b"in_planar" in lib.ifx_last_error()
+    assert lib.ifx_rmsnorm_cl(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 64 * 48, slots1, 1, 64, 48, 2, None) == -1      # planar output, 48 channels
+    assert b"planar" in lib.ifx_last_error()
+    assert lib.ifx_rmsnorm_cl(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 64 * 64, slots1, 1, 64, 64, 4, None) == -1      # unknown flag bit
+    v = C.c_int32(-1)
+    assert lib.ifx_set_option(b"conv_variant", 1) == 0 and lib.ifx_get_option(b"conv_variant", C.byref(v)) == 0 and v.value == 1
+    assert lib.ifx_set_option(b"conv_variant", 2) != 0 and lib.ifx_set_option(b"conv_variant", 0) == 0
+    assert lib.ifx_get_option(b"attn_debug_counters", C.byref(v)) == 0 and v.value == 0
+    assert lib.ifx_get_option(b"attn_rescale_count", C.byref(v)) == 0 and v.value == 0        # never enabled: no device word, reads 0
+    x = torch.arange(2 * 3 * 4 * 64, dtype=torch.float32).view(2, 3, 4, 64).to(torch.bfloat16)
+    xp = hip_ops.to_planar(x)
+    assert xp.shape == (2, 2, 3, 4, 32) and xp.is_contiguous()
+    assert torch.equal(xp[1, 1, 2, 3], x[1, 2, 3, 32:]) and torch.equal(xp[0, 0, 1, 2], x[0, 1, 2, :32])
+
+
 def test_ops_refuse_cpu_tensors():
     from inferix_amd import _hip, hip_ops
     with pytest.raises(_hip.HipKernelError):
