@@ -411,3 +411,48 @@ def test_all_hip_image_to_video(tmp_path):
     assert torch.equal(video[:, :1].float().cpu(), first.float().cpu())
     ref0 = V.VaeEncoderOracle(vcfg, VW).encode_to_latent(image)
     assert rel_l2(lat0.float().cpu(), ref0) < 2e-2
+
+
+def test_conv3d_ping_pong_equals_lock_step_on_random_shapes(ops):
+    """The persistent ping-pong kernel walks cursors over tiles, stages and kernel rows, masks halo columns by tile position and splits
+    its requests between wave groups; the lock-step kernel of round 1 derives everything per tile.  Same K order, same epilogue rounding:
+    on 40 random launches — frames from 1 x 3 to 70 x 200 pixels (one tile that is both first and last column, ragged last rows /
+    columns, several tiles per workgroup), 32 .. 288 input and 96 / 192 / 288 output channels, 1 .. 6 output frames, temporal kernel
+    1 / 3 with zero frames in front, fused upsampling, with and without residual, planar and channels-last inputs, shuffled frame
+    slots — the two must agree BIT FOR BIT."""
+    g = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(40):
+        ups = ri(0, 3) == 0
+        kt = 1 if ups else (3 if ri(0, 3) else 1)
+        cin, cout = 32 * ri(1, 9), 96 * ri(1, 3)
+        h, w = (ri(1, 35), ri(2, 100)) if ups else (ri(1, 70), ri(3, 200))
+        t = ri(1, 6)
+        res = (not ups) and ri(0, 1) == 1
+        planar = (not ups) and ri(0, 1) == 1
+        n_in = t + kt - 1
+        ho, wo = (2 * h, 2 * w) if ups else (h, w)
+        frames = rnd(g, n_in + 1, h, w, cin).cuda()
+        slots = torch.randperm(n_in + 1, generator=g)[:n_in].tolist()
+        if kt == 3 and ri(0, 1):
+            slots[0] = -1
+            if ri(0, 1):
+                slots[1] = -1
+        wt = rnd(g, kt * 9, cin // 32, cout, 32, scale=(cin * kt * 9) ** -0.5).cuda()
+        b = rnd(g, cout, scale=0.1).cuda() if ri(0, 3) else None
+        residual = rnd(g, t, ho, wo, cout).cuda() if res else None
+        xin = ops.to_planar(frames) if planar else frames
+        outs = []
+        for variant in (0, 1):
+            y = torch.full((t + 1, ho, wo, cout), 7.0, dtype=BF, device="cuda")
+            out_slots = list(range(1, t + 1))
+            ops.set_option("conv_variant", variant)
+            try:
+                ops.conv3d_cl(xin, slots, wt, b, kt=kt, ks=3, y=y, out_slots=out_slots, upsample=ups, residual=residual)
+            finally:
+                ops.set_option("conv_variant", 0)
+            outs.append(y)
+        what = f"case {case}: kt{kt} ups{int(ups)} {cin}->{cout} @{h}x{w} t{t} res{int(res)} planar{int(planar)} slots{slots}"
+        assert torch.isfinite(outs[0].float()).all(), what
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), what
+        assert float((outs[0][0].float() - 7.0).abs().max()) == 0.0, what + ": a slot that was not named was written"
