@@ -363,7 +363,14 @@ static void launch(const ConvArgs& a, hipStream_t s) {
 //     vmcnt(0) at the end of its MFMA phase 2g+2: visible from phase 2g+3, where group 0 itself reads them.  Group 1 requests the
 //     patch of stage t+1 in its loader phases 6t and 6t+2 (half of its pieces each; the slot's last reader was group 1 itself in phase
 //     6t-2) and waits at the head of its loader phase 6t+4: visible from phase 6t+5, where group 0 reads the first fragments of
-//     stage t+1.  Every request has at least one whole MFMA phase (>= 1152 matrix-pipe cycles) to land, the patch (HBM) three.
+//     stage t+1.  Group 0 moves 12 of a stage's 42 patch pieces as well (one per wave in each of its loader phases 6t-1, 6t+1, 6t+3,
+//     covered by the same end-of-MFMA-phase wait): its weight pieces cost ~90 cycles of issue each, a patch piece ~200-300, and the
+//     two loader phases are what the step time is made of.  Every request has at least one whole MFMA phase (>= 1152 matrix-pipe
+//     cycles) to land, the patch (HBM) three.
+//   * epilogue: bias from an LDS copy, bf16(acc + bias) transposed through the wave's LDS region 32 pixels at a time, residual rows
+//     (their cache lines touched three steps ahead by two 4-byte-per-lane DMA requests into a sink) and output rows moved by buffer
+//     instructions whose offsets are TWO lane terms + wave-uniform bases (no per-access address arithmetic: 998 -> 604 VALU
+//     instructions, the largest single gain after the schedule).
 //   * DMA by inline asm through buffer descriptors (hipcc fences every later ds_read behind a `global_load_lds` builtin with
 //     vmcnt(0)); padding pixels and the zero frames in front of the stream are out-of-range offsets / empty descriptors, which
 //     return zeros: no zero page.  A loader wave interleaves its DMA instructions with its fragment reads (the reads do not wait
@@ -380,6 +387,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef IFX_CONVPP_TRACE
 #define IFX_CONVPP_TRACE 0      // 1: s_memtime segment sums of workgroup 0 (printed by the launcher after a synchronisation; lab only)
 #endif
+// Further lab switches for the trace build (`make convtrace CXXFLAGS+=-DIFX_CONVPP_NOFRAG ...`; results are garbage, only the segment times
+// matter): IFX_CONVPP_NOFRAG no fragment reads, IFX_CONVPP_NOMFMA no MFMAs behind a tile's first step, IFX_CONVPP_NORES no residual rows,
+// IFX_CONVPP_NOSTORE no output stores — how DESIGN 13's "what bounds the kernel" numbers were taken.
 #if IFX_CONVPP_TRACE
 #define CP_STAMP(i)                                                \
   do {                                                             \
@@ -733,7 +743,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
     int ln0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int lane_w = (ln0 >> 2) * 64 + (((ln0 & 3) ^ ((ln0 >> 4) & 3)) << 4);
     const v4i w_rs = make_rsrc(A.w, (unsigned)((long long)A.KT * 9 * CC * A.Cout * 64));
-    const int tap_stride = CC * A.Cout * 64;
     int w_it = 0, w_dt = 0, w_cc = 0, w_r = 0, w_g = 0;
     int w_nb = c_t.n_base;
     auto w_piece = [&](int q) __attribute__((always_inline)) {       // piece slot q of the cursor's step
@@ -741,7 +750,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       if (w_it >= n_my || idx >= G::WPS) return;
       const int tg = idx / G::WP, pr = idx - tg * G::WP;
       const int base = ((w_dt * 9 + w_r * 3 + tg) * CC + w_cc) * (A.Cout * 64) + w_nb * 64 + pr * 1024;
-      (void)tap_stride;
       dma16(w_rs, lds0 + G::W_OFF + (w_g & 1) * G::W_STEP + tg * G::W_TAP + pr * 1024, lane_w, base);
     };
     auto w_next = [&]() __attribute__((always_inline)) {
