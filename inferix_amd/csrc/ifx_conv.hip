@@ -438,14 +438,9 @@ struct GeoP {
   static constexpr int P_SLOT = NPI * 1024;
   static constexpr int WP = BN / 16;                    // 1 KiB weight pieces per tap
   static constexpr int W_TAP = BN * 64, W_STEP = 3 * W_TAP;
-  static constexpr int WPS = 3 * WP;                    // weight pieces per step
-  // group 0 moves the pieces of taps 0 and 1 of a step, group 1 those of tap 2 (+ most of the patch): the two loader phases of a step
-  // then carry about the same LDS-DMA issue time, which is what they are made of (s_memtime trace: 1293 + 65 against 756 cycles of
-  // request stalls per step before the split)
-  static constexpr int NW0 = 2 * WP, WPW0 = (NW0 + 3) / 4, WPW1 = (WPS - NW0 + 3) / 4;
-  static constexpr int WRING = 3;                       // weight ring in steps: group 1's share lands two phases after its request
-  static constexpr int PITCH = BN * 2 + 16, SCR = 16 * PITCH;  // transpose region of one wave: 16 pixels x BN channels
-  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, E_OFF = W_OFF + WRING * W_STEP;
+  static constexpr int WPS = 3 * WP, WPW = (WPS + 3) / 4;      // weight pieces per step / piece slots per wave of group 0 and step
+  static constexpr int PITCH = BN * 2 + 16, SCR = 32 * PITCH;  // transpose region of one wave: 32 pixels x BN channels
+  static constexpr int P_OFF = 0, W_OFF = 2 * P_SLOT, E_OFF = W_OFF + 2 * W_STEP;
   static constexpr int B_OFF = E_OFF + 4 * SCR;         // the launch's bias vector (Cout <= 512 channels) as bf16
   static constexpr int S_OFF = B_OFF + 1024;            // 256-byte sinks of the residual warm-up requests, one per wave
   static constexpr int LDS = S_OFF + 8 * 256;
@@ -619,54 +614,48 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
         e_bias[i][g] = *reinterpret_cast<const u32x2*>(smem + G::B_OFF + (t.n_base + i * 32 + g * 8 + ehi * 4) * 2);
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          const u32x2 b = e_bias[i][g];
+          v[0] += __builtin_bit_cast(float, b[0] << 16);
+          v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
+          v[2] += __builtin_bit_cast(float, b[1] << 16);
+          v[3] += __builtin_bit_cast(float, b[1] & 0xffff0000u);
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          *reinterpret_cast<u16x4*>(tr + e31 * PITCH + (i * 32 + g * 8 + ehi * 4) * 2) = o;
+        }
+      wait_lds();                                     // wave-private region: no barrier
       const int sbase = ((oh * A.Wo + t.w0 + 32 * j) * A.Cout + t.n_base) * 2;
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {                 // 16-pixel half blocks: the transpose region holds 16 pixels (the weight ring took the rest)
-        if ((e31 >> 4) == hb) {
+      for (int it = 0; it < NIT; ++it) {
+        const int hb = it / CG, cg = it - hb * CG;
+        u16x8 v = *reinterpret_cast<const u16x8*>(tr + l_lane + 16 * hb * PITCH + cg * 64);
+        if (has_res) {
+          const u16x8 r8 = __builtin_bit_cast(u16x8, rv[j][it]);
 #pragma unroll
-          for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-              const u32x2 b = e_bias[i][g];
-              v[0] += __builtin_bit_cast(float, b[0] << 16);
-              v[1] += __builtin_bit_cast(float, b[0] & 0xffff0000u);
-              v[2] += __builtin_bit_cast(float, b[1] << 16);
-              v[3] += __builtin_bit_cast(float, b[1] & 0xffff0000u);
-              u16x4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-              *reinterpret_cast<u16x4*>(tr + (e31 & 15) * PITCH + (i * 32 + g * 8 + ehi * 4) * 2) = o;
-            }
+          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r8[e]));
         }
-        wait_lds();                                   // wave-private region: no barrier
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg) {
-          const int it = hb * CG + cg;
-          u16x8 v = *reinterpret_cast<const u16x8*>(tr + l_lane + cg * 64);
-          if (has_res) {
-            const u16x8 r8 = __builtin_bit_cast(u16x8, rv[j][it]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r8[e]));
-          }
 #ifndef IFX_CONVPP_NOSTORE
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, pl < cols_left - 32 * j - 16 * hb ? g_lane : (int)0x80000000,
-                                                 sbase + (16 * hb * A.Cout + cg * 32) * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, pl < cols_left - 32 * j - 16 * hb ? g_lane : (int)0x80000000,
+                                               sbase + (16 * hb * A.Cout + cg * 32) * 2, 0);
 #endif
-        }
-        // (the LDS operations of one wave execute in order: the next half block's writes cannot overtake these reads)
       }
+      // (the LDS operations of one wave execute in order: the next block's writes cannot overtake these reads)
     }
   };
 
   const unsigned frame_bytes = (unsigned)((long long)A.Hs * A.Ws * A.Cin * 2);
   // compute-side cursor: step c_g of the stream = kernel row c_r of stage c_s of tile c_it; c_sg = global stage index
-  int c_it = 0, c_s = 0, c_r = 0, c_sg = 0, c_ws = 0;      // c_ws: slot of the weight ring the step's weights sit in
+  int c_it = 0, c_s = 0, c_r = 0, c_sg = 0;
   Tile c_t = tile_of(0);
   auto c_first = [&]() __attribute__((always_inline)) { return c_s == 0 && c_r == 0; };
   auto c_last = [&]() __attribute__((always_inline)) { return c_s == S - 1 && c_r == 2; };
   auto c_next = [&]() __attribute__((always_inline)) {
-    c_ws = c_ws == G::WRING - 1 ? 0 : c_ws + 1;
     if (++c_r == 3) {
       c_r = 0;
       ++c_sg;
@@ -749,46 +738,45 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
   unsigned long long t_last = __builtin_readcyclecounter();
 #endif
 
-  // ---- weight requests: every wave runs a cursor over the steps of the stream and moves its group's share of a step — group 0 the
-  //      pieces of taps 0 and 1 (idx < NW0), group 1 those of tap 2 — into slot (step % 3) of the ring
-  const int lane_w = (int)(((threadIdx.x & 63) >> 2) * 64 + ((((threadIdx.x & 63) & 3) ^ (((threadIdx.x & 63) >> 4) & 3)) << 4));
-  const v4i w_rs = make_rsrc(A.w, (unsigned)((long long)A.KT * 9 * CC * A.Cout * 64));
-  int w_it = 0, w_dt = 0, w_cc = 0, w_r = 0, w_slot = 0;
-  int w_nb = c_t.n_base;
-  auto w_piece = [&](int q) __attribute__((always_inline)) {         // piece slot q of this group's share of the cursor's step
-    const int idx = (grp == 0 ? 0 : G::NW0) + w4 + 4 * q;
-    if (w_it >= n_my || idx >= (grp == 0 ? G::NW0 : G::WPS)) return;
-    const int tg = idx / G::WP, pr = idx - tg * G::WP;
-    const int base = ((w_dt * 9 + w_r * 3 + tg) * CC + w_cc) * (A.Cout * 64) + w_nb * 64 + pr * 1024;
-    dma16(w_rs, lds0 + G::W_OFF + w_slot * G::W_STEP + tg * G::W_TAP + pr * 1024, lane_w, base);
-  };
-  auto w_next = [&]() __attribute__((always_inline)) {
-    w_slot = w_slot == G::WRING - 1 ? 0 : w_slot + 1;
-    if (++w_r == 3) {
-      w_r = 0;
-      if (++w_cc == CC) {
-        w_cc = 0;
-        if (++w_dt == A.KT) {
-          w_dt = 0;
-          if (++w_it < n_my) w_nb = tile_of(w_it).n_base;
+  if (grp == 0) {
+    // ---- weight requests: a cursor over the steps of the stream; wave w4 moves pieces w4, w4 + 4, ... of a step's 3 x WP
+    int ln0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int lane_w = (ln0 >> 2) * 64 + (((ln0 & 3) ^ ((ln0 >> 4) & 3)) << 4);
+    const v4i w_rs = make_rsrc(A.w, (unsigned)((long long)A.KT * 9 * CC * A.Cout * 64));
+    int w_it = 0, w_dt = 0, w_cc = 0, w_r = 0, w_g = 0;
+    int w_nb = c_t.n_base;
+    auto w_piece = [&](int q) __attribute__((always_inline)) {       // piece slot q of the cursor's step
+      const int idx = w4 + 4 * q;
+      if (w_it >= n_my || idx >= G::WPS) return;
+      const int tg = idx / G::WP, pr = idx - tg * G::WP;
+      const int base = ((w_dt * 9 + w_r * 3 + tg) * CC + w_cc) * (A.Cout * 64) + w_nb * 64 + pr * 1024;
+      dma16(w_rs, lds0 + G::W_OFF + (w_g & 1) * G::W_STEP + tg * G::W_TAP + pr * 1024, lane_w, base);
+    };
+    auto w_next = [&]() __attribute__((always_inline)) {
+      ++w_g;
+      if (++w_r == 3) {
+        w_r = 0;
+        if (++w_cc == CC) {
+          w_cc = 0;
+          if (++w_dt == A.KT) {
+            w_dt = 0;
+            if (++w_it < n_my) w_nb = tile_of(w_it).n_base;
+          }
         }
       }
-    }
-  };
-  auto w_all = [&]() __attribute__((always_inline)) {
+    };
+    auto w_all = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < (G::WPW0 > G::WPW1 ? G::WPW0 : G::WPW1); ++q) w_piece(q);
-    w_next();
-  };
-  // this group's pieces of the cursor's step spread over the three taps' reads of a loader phase
-  auto w_between = [&](int tg) __attribute__((always_inline)) {
-    const int n = grp == 0 ? G::WPW0 : G::WPW1;
+      for (int q = 0; q < G::WPW; ++q) w_piece(q);
+      w_next();
+    };
+    // pieces of the cursor's step spread over the three taps' reads of a loader phase
+    auto w_between = [&](int tg) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < (G::WPW0 > G::WPW1 ? G::WPW0 : G::WPW1); ++q)
-      if (q < n && q * 3 / n == tg) w_piece(q);
-    if (tg == 2) w_next();
-  };
-  if (grp == 0) {
+      for (int q = 0; q < G::WPW; ++q)
+        if (q * 3 / G::WPW == tg) w_piece(q);
+      if (tg == 2) w_next();
+    };
     // this group's patch pieces: w4 + 4 k, k < PG0, of every stage; piece k in the k-th of the three loader phases in front of the stage
     int p_k = 0;
     int p_lt[G::PG0];
@@ -800,11 +788,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
         if (p_k == k) p_piece(w4 + 4 * k, p_lt[k]);
       if (++p_k == 3) p_k = 0, p_next();
     };
-    w_all(), w_all(), w_all();                        // this group's share of steps 0, 1 and 2
+    w_all(), w_all();                                 // steps 0 and 1
     p_mine(), p_mine(), p_mine();                     // stage 0
     wait_lds();                                       // (the bias copy)
     wait_vm0();
-    __builtin_amdgcn_s_barrier();                     // B0: patch 0, weights 0 .. 2, the bias are in LDS
+    __builtin_amdgcn_s_barrier();                     // B0: patch 0, weights 0 and 1, the bias are in LDS
     p_mine();                                         // phase -1: stage 1
     read_frags(0, 0, 0, [&](int) __attribute__((always_inline)) {});
     wait_lds();
@@ -820,7 +808,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       c_next();
       __builtin_amdgcn_sched_barrier(0);
       CP_STAMP(0);
-      wait_vm0();                                     // this group's requests of one phase ago (weights of step g+2, a patch piece) have landed; so have an epilogue's stores
+      wait_vm0();                                     // the weights of step g+1 (requested one phase ago) have landed; so have an epilogue's stores
       __builtin_amdgcn_sched_barrier(0);
       CP_STAMP(1);
       __builtin_amdgcn_s_barrier();
@@ -836,7 +824,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       CP_STAMP(7);
       // (the reads are unconditional: behind the last step they fetch stale LDS that nobody multiplies — a conditional read would keep the
       //  OLD fragments alive through the epilogue on the not-taken path, 120 registers next to the accumulators)
-      read_frags(c_r, c_sg & 1, c_ws, [&](int tg) __attribute__((always_inline)) {      // + this group's share of the weights of step g+3 into the slot step g was read from
+      read_frags(c_r, c_sg & 1, (g + 1) & 1, [&](int tg) __attribute__((always_inline)) {      // + the weights of step g+2 into the slot step g was read from
         w_between(tg);
         if (tg == 2) p_mine();
       });
@@ -850,7 +838,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       CP_STAMP(6);
     }
 #if IFX_CONVPP_TRACE
-    if (blockIdx.x == 0 && wave == 0 && (threadIdx.x & 63) == 0 && A.trace != nullptr)
+    if (blockIdx.x == 0 && wave == 0 && ln0 == 0 && A.trace != nullptr)
       for (int i = 0; i < 8; ++i) A.trace[i] = seg[i];
 #endif
   } else {
@@ -861,7 +849,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
 #pragma unroll
     for (int q = 0; q < G::PPW; ++q) p_piece(4 * G::PG0 + w4 + 4 * q, p_lt[q]);      // stage 0
     p_next();
-    w_all(), w_all(), w_all();                        // this group's share of steps 0, 1 and 2
     wait_lds();                                       // (the bias copy)
     wait_vm0();
     __builtin_amdgcn_s_barrier();                     // B0
@@ -869,9 +856,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
     CP_STAMP(7);
     for (int g = 0; g < GT; ++g) {
       // ---------------- phase 2g: loader ----------------
-      // this wave's requests of its previous loader phase (two phases ago: its share of the weights of step g+1, patch pieces of the
-      // next stage) have landed; visible to group 0 behind this phase's barrier — phase 2g+1, where it reads the fragments of step g+1
-      wait_vm0();
+      // head of phase 6t+4: this wave's pieces of stage t+1 (requested in phases 6t and 6t+2) have landed
+      if (c_r == 2) wait_vm0();
       CP_STAMP(0);
       if (g > 0 && c_first()) {                        // (c_t still names the tile that ended one phase ago)
         epilogue(c_t);
@@ -879,8 +865,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       }
       CP_STAMP(1);
       const int batch = c_r;                          // 0 / 1: that half of the next stage's pieces; 2: none
-      read_frags(c_r, c_sg & 1, c_ws, [&](int tg) __attribute__((always_inline)) {
-        if (g > 0) w_between(tg);                       // this group's share of the weights of step g+2 (steps 0 .. 2: the prologue)
+      read_frags(c_r, c_sg & 1, g & 1, [&](int tg) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < G::PPW; ++q) {
           const int b = q < G::QA ? 0 : 1, qq = b == 0 ? q : q - G::QA, nb = b == 0 ? G::QA : G::PPW - G::QA;
