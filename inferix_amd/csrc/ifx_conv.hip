@@ -7,7 +7,7 @@
 // Design (LDS-tiled direct convolution on the matrix cores, not an im2col GEMM):
 //   * activations are [frame][h][w][C] bf16; a workgroup (8 waves) owns an 8 x 64 pixel tile of ONE output frame and BN
 //     output channels; wave w computes image row w of the tile (two 32-pixel MFMA blocks) for all BN channels.
-//   * the K loop runs over stages (input frame dt, 32-channel chunk cc).  Per stage the (8+2) x (64+2) pixel halo patch of
+//   * the K loop runs over stages (32-channel chunk cc outer, input frame dt inner: round 6, see conv_pp_kernel).  Per stage the (8+2) x (64+2) pixel halo patch of
 //     that frame / chunk is DMA'd into LDS once (`global_load_lds`, 64 B per pixel, zero page for padding pixels and for
 //     the all-zero frames in front of the stream) and ALL nine spatial taps read their A fragments from it at a per-tap
 //     offset — 3.9 patch loads per output pixel-chunk instead of the 27 an implicit GEMM gathers.  The nearest-2x
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
   const int CC = A.Cin >> 5;
   const int S = A.KT * CC, totalG = S * GPS;
   auto issue_patch = [&](int s, int r) {            // piece r of this wave for stage s
-    const int dt = s / CC, cc = s - dt * CC;
+    const int cc = s / A.KT, dt = s - cc * A.KT;      // stage order: channel chunk outer, input frame inner (round 6, see conv_pp_kernel)
     const int f = A.in_slot[to + dt];
     const unsigned short* base = A.x + (long long)f * A.in_frame_stride + (A.in_planar ? (long long)cc * A.Hs * A.Ws * 32 : cc * 32);
     const int p = wave + LW * r;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void conv_cl_kernel(ConvArgs A) {
   }
   auto issue_w = [&](int g) {                       // all weight pieces of this wave for group g
     const int s = g / GPS, gi = g - s * GPS;
-    const int dt = s / CC, cc = s - dt * CC;
+    const int cc = s / A.KT, dt = s - cc * A.KT;      // stage order: channel chunk outer, input frame inner (round 6, see conv_pp_kernel)
     const unsigned short* wbase = A.w + ((size_t)(dt * TAPS + gi * TG) * CC + cc) * A.Cout * 32;
     unsigned char* ring = smem + G::W_OFF + (g % WRG) * (TG * G::W_TAP);
 #pragma unroll
@@ -378,8 +378,11 @@ static void launch(const ConvArgs& a, hipStream_t s) {
 //   * patch swizzle by COLUMN ((col >> 2) & 3, not by linear patch pixel): a fragment address is a wave-uniform row base + a
 //     lane term that does not depend on the row — half the address arithmetic of the lock-step kernel's loader.
 //   * tile order: channel tile fastest, then OUTPUT FRAME, then the spatial tile: the workgroups resident on an XCD work on
-//     consecutive ids = the same spatial tile of consecutive frames, whose three input frames overlap two by two in that XCD's L2.
-//   * arithmetic, K order (dt, cc, dh, dw, 16-channel k-step), epilogue rounding: those of conv_cl_kernel — bit-identical outputs
+//     consecutive ids = the same spatial tile of consecutive frames, whose three input frames overlap two by two — and the stage order
+//     is channel chunk OUTER, input frame INNER (both kernels, round 6): output frame `to` reads chunk cc of frame f = to + dt at stage
+//     3 cc + dt, its neighbours to - 1 / to - 2 read the same chunk one / two stages later, while it is still in that XCD's L2
+//     (FETCH_SIZE 1.212e6 -> 0.944e6 KiB per launch: fabric reads 2.3x -> 1.77x algorithmic, profiles/r6_pmc_conv.md).
+//   * arithmetic, K order (cc, dt, dh, dw, 16-channel k-step), epilogue rounding: those of conv_cl_kernel — bit-identical outputs
 //     (tools/bench_conv.py compares the two kernels bit for bit on every shape it times).
 namespace pp {
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -703,10 +706,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
   };
   auto p_next = [&]() __attribute__((always_inline)) {
     ++p_sg;
-    if (++p_cc == CC) {
-      p_cc = 0;
-      if (++p_dt == A.KT) {
-        p_dt = 0;
+    if (++p_dt == A.KT) {                              // stage order: channel chunk outer, input frame inner
+      p_dt = 0;
+      if (++p_cc == CC) {
+        p_cc = 0;
         if (++p_it < n_my) p_t = tile_of(p_it), p_tile_terms();
       }
     }
@@ -756,10 +759,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
       ++w_g;
       if (++w_r == 3) {
         w_r = 0;
-        if (++w_cc == CC) {
-          w_cc = 0;
-          if (++w_dt == A.KT) {
-            w_dt = 0;
+        if (++w_dt == A.KT) {
+          w_dt = 0;
+          if (++w_cc == CC) {
+            w_cc = 0;
             if (++w_it < n_my) w_nb = tile_of(w_it).n_base;
           }
         }
