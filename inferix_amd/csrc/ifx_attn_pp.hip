@@ -100,11 +100,10 @@ struct AttnArgsPP {
   // [rt0[r], rt0[r + 1]) of a head belong to range r (MAGI: the denoising chunks of one forward in ONE launch)
   int n_ranges;
   int rq0[8], rq1[8], rk0[8], rk1[8], rt0[9];
-  // paged views with a table (round 6): every workgroup copies the table into LDS at `pt_lds_off` (bytes; < 0: not available, look it
-  // up in global memory per key) and translates key -> page with a multiply-high by `ps_magic` = floor(2^32 / page_size) + 1 (exact
-  // while key * page_size < 2^32).  Before: a runtime integer division and a DEPENDENT global load of the table entry per lane in
-  // front of every K/V piece request — the paged kernel ran at 0.54x the contiguous one (943 -> 1746 us over 32760 keys).
-  int pt_lds_off, n_pages;
+  // paged views (PAGED = 1 instantiations): key -> page by a multiply-high with `ps_magic` = floor(2^32 / page_size) + 1 (exact while
+  // key * page_size < 2^32), on the SCALAR side, once per page (see the request lambda).  History: round 5 divided and loaded the table
+  // entry per LANE in front of every K/V request (0.54x the contiguous kernel over 32760 keys), early round 6 read an LDS copy of the
+  // table per lane (0.86x: the reads and their waits sit in the software-pipelined loop, the kernel was twice the contiguous one's size).
   unsigned ps_magic;
   // tests (option "attn_debug_counters"): a device word that counts the (wave, tile) pairs that took the rescale branch of the lazy
   // row maximum; nullptr in every normal launch (the increment sits inside the rare branch only)
@@ -164,7 +163,30 @@ __device__ __forceinline__ void pp_wait_tiles(int tiles) {
 // FR = 1: free-running schedule (attn_variant 4): every wave runs QK(t) -> softmax(t) -> PV(t) for its own 32 queries with ONE
 // workgroup barrier per tile and no phase assignment — the two waves of a SIMD drift apart by themselves, the older one takes
 // the matrix pipe first and its softmax then overlaps with the younger wave's MFMAs (tools/probe_roles.hip).
-template <bool PAGED, bool SPLIT, int NG, int FR = 0>
+// PAGED = 1: the page (or segment) that holds key `kk` -> its key range [lo, hi) and the row offset physical - logical.  All scalar;
+// the table entry comes through the scalar cache (s_load_dword from inline asm with its own wait: a compiler-visible load would
+// put lgkmcnt / vmcnt waits for it into the software-pipelined loop around the call).
+__device__ __forceinline__ void pp_page_range(const KvAddr& ka, unsigned ps_magic, int kk, int& lo, int& hi, int& off) {
+  if (ka.pt == nullptr) {
+    const bool up = ka.seg_split > 0 && kk >= ka.seg_split;
+    lo = up ? ka.seg_split : 0;
+    hi = (up || ka.seg_split <= 0) ? 0x7fffffff : ka.seg_split;
+    off = up ? ka.seg_delta : 0;
+    return;
+  }
+  const int pg = (int)__umulhi((unsigned)kk, ps_magic);
+  int entry;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(entry) : "s"(ka.pt), "s"(pg * 4) : "memory");
+  lo = pg * ka.ps;
+  hi = lo + ka.ps;
+  off = entry * ka.ps - lo;
+}
+
+// PAGED: 0 = contiguous cache (logical row = physical row); 1 = page table with pages of at least 3 rows, or a two-segment view —
+// wave-uniform translation (a 4-key request piece spans at most two pages); 2 = one- and two-row pages, tables whose multiply-high
+// page index would not be exact — per-lane translation (KvAddr::slot: a division and a table load per request), instantiated for the
+// plain two-group schedule only (the launcher routes such views there).
+template <int PAGED, bool SPLIT, int NG, int FR = 0>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(AttnArgsPP A) {
   using namespace pp;
   constexpr int QT = 128 * NG;
@@ -240,16 +262,6 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   // carries them as "maybe pending" around the loop back-edge and protects every first use of qf in the loop with
   // vmcnt(7..0) — which, since the asm-issued DMA below shares the counter, drains the K/V prefetch queue every tile.
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  const int* pt_lds = nullptr;
-  if constexpr (PAGED) {
-    if (A.pt_lds_off >= 0) {
-      int* dst = reinterpret_cast<int*>(smem + A.pt_lds_off);
-      for (int i = tid; i < A.n_pages; i += NG * 256) dst[i] = A.ka.pt[i];
-      __syncthreads();                               // (workgroup-uniform: before the first request)
-      pt_lds = dst;
-    }
-  }
-
   // ---- LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): a tile is 16 K pieces + 16 V pieces of
   //      1 KiB (4 key rows x 256 B); wave w moves pieces w and w+8.  Per lane only a 32-bit voffset per piece is
   //      live (row * row_bytes + swizzled source chunk); the tile offset is a scalar soffset.  Rows beyond the
@@ -266,6 +278,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   const pp_v4i vrs = pp_make_rsrc(A.v + kvh * HD, nrec);
   const unsigned lds00 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem;
   const int last_key = kv_e - 1;
+  int pc_lo = 0, pc_hi = 0, pc_off = 0;              // PAGED = 1: key range and (physical - logical) row offset of the page of the last request
   auto issue_w = [&](int t, int wv, int what = 3) {  // the pieces that belong to wave `wv` (rows 4 wv .. 4 wv + 3 of each half); what: 1 K, 2 V
     const unsigned lds0 = lds00 + wv * 1024;
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -282,18 +295,41 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff, soff + r * 32 * row_bytes);
         if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff, soff + r * 32 * row_bytes);
       }
+    } else if constexpr (PAGED == 1) {
+      // A piece is four CONSECUTIVE keys, nearly always inside ONE page: the translation is wave-uniform.  The physical row of
+      // the piece's first key goes into the scalar offset, the lane offsets are the contiguous cache's; the page of the last request is
+      // remembered in three scalars (a page is ~24 tiles) and looked up again — one scalar load from the table, inline asm so that the
+      // compiler's wait counters never see it — only when a request leaves it.  The common path has no memory operation and two VALU
+      // instructions per request.  Keys behind the last one read the last key's row (as the per-lane form did: finite values under
+      // the mask) by a lane-row clamp, and a piece that straddles a page boundary adds the next page's offset to its upper lanes:
+      // both in one scalar branch that only boundary pieces take.
+      const int wv_rows = wv * 4 * row_bytes;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int key0 = __builtin_amdgcn_readfirstlane(kv_s + t * KT + wv * 4 + 32 * r);
+        const int kk = min(key0, last_key);
+        if (kk < pc_lo || kk >= pc_hi) pp_page_range(A.ka, A.ps_magic, kk, pc_lo, pc_hi, pc_off);
+        int soff = (kk + pc_off) * row_bytes;
+        int adj = wv_rows;
+        if (kk + 3 > last_key || kk + 3 >= pc_hi) {        // rare: the ragged last piece of the key range, or a piece that runs into the next page
+          const int j = min(ln >> 4, last_key - kk);
+          adj += ((ln >> 4) - j) * row_bytes;
+          if (kk + min(3, last_key - kk) >= pc_hi) {      // its rows from pc_hi on live in the NEXT page (a piece spans at most two: page_size >= 3)
+            int lo2, hi2, off2;
+            pp_page_range(A.ka, A.ps_magic, pc_hi, lo2, hi2, off2);
+            // whole physical row per lane (the next page may lie anywhere, and a lane offset cannot go negative); scalar offset 0
+            adj -= (kk + ((kk + j >= pc_hi) ? off2 : pc_off)) * row_bytes;
+            soff = 0;
+          }
+        }
+        if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff - adj, soff);
+        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff - adj, soff);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int key = min(kv_s + t * KT + d_row0 + 32 * r, last_key);
-        int phys;
-        if (pt_lds != nullptr) {
-          const int pg = (int)__umulhi((unsigned)key, A.ps_magic);
-          phys = pt_lds[pg] * A.ka.ps + (key - pg * A.ka.ps);
-        } else {
-          phys = A.ka.slot(key);
-        }
-        const int delta = (phys - d_row0) * row_bytes;                  // physical row instead of tile row
+        const int delta = (A.ka.slot(key) - d_row0) * row_bytes;        // physical row instead of tile row
         if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff + delta, 0);
         if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff + delta, 0);
       }
@@ -1197,73 +1233,50 @@ int attn_pp_split_heuristic(int q_rows, int heads, int nkeys, int qt, int slots)
 #ifndef PP_DUAL_FR
 #define PP_DUAL_FR 6     // 6: six-times unrolled over constant LDS slots; 3: the two-times unrolled form it replaced
 #endif
-template <int DFR>
-static void launch_pp_dual(const AttnArgsPP& a, bool paged, bool split, dim3 grid, hipStream_t stream) {
-  constexpr int LDS_DUAL = 5 * 16384;                   // 80 KiB: two workgroups per CU
+// `paged`: 0 contiguous, 1 wave-uniform page translation (PAGED = 1 instantiations); launch_attn_pp sends every other geometry to
+// launch_pp_generic before it gets here
+template <int NG, int FR>
+static void launch_pp_any(const AttnArgsPP& a, int paged, bool split, dim3 grid, int lds, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 1, DFR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DUAL);
-    attr_set = true;
-  }
-  const dim3 block(256);
-  if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 1, DFR>), grid, block, LDS_DUAL, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 1, DFR>), grid, block, LDS_DUAL, stream, a);
-  } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, DFR>), grid, block, LDS_DUAL, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 1, DFR>), grid, block, LDS_DUAL, stream, a);
-  }
-}
-
-constexpr int PT_LDS_BYTES = 4096;       // LDS copy of a page table: up to 1024 pages, behind the K/V rings of the one-per-CU schedules
-
-template <int FR>
-static void launch_pp_fr(AttnArgsPP a, bool paged, bool split, dim3 grid, hipStream_t stream) {
-  using namespace pp;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, 2, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    attr_set = true;
-  }
-  const dim3 block(512);
-  int lds = LDS_ALLOC;
-  if (paged && a.ka.pt != nullptr && a.n_pages * 4 <= PT_LDS_BYTES && a.ps_magic != 0) a.pt_lds_off = LDS_ALLOC, lds += PT_LDS_BYTES;
-  if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, 2, FR>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, 2, FR>), grid, block, lds, stream, a);
-  } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2, FR>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 2, FR>), grid, block, lds, stream, a);
-  }
-}
-
-template <int NG>
-static void launch_pp_ng(AttnArgsPP a, bool paged, bool split, dim3 grid, hipStream_t stream) {
-  using namespace pp;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC + PT_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, true, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<1, false, NG, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<0, false, NG, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<1, true, NG, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<0, true, NG, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const dim3 block(NG * 256);
-  int lds = LDS_ALLOC;
-  if (paged && a.ka.pt != nullptr && a.n_pages * 4 <= PT_LDS_BYTES && a.ps_magic != 0) a.pt_lds_off = LDS_ALLOC, lds += PT_LDS_BYTES;
   if (split) {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true, NG>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, true, NG>), grid, block, lds, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<1, true, NG, FR>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<0, true, NG, FR>), grid, block, lds, stream, a);
   } else {
-    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, NG>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, NG>), grid, block, lds, stream, a);
+    if (paged) hipLaunchKernelGGL((attn_fwd_pp_kernel<1, false, NG, FR>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<0, false, NG, FR>), grid, block, lds, stream, a);
   }
+}
+template <int DFR>
+static void launch_pp_dual(const AttnArgsPP& a, int paged, bool split, dim3 grid, hipStream_t stream) {
+  launch_pp_any<1, DFR>(a, paged, split, grid, 5 * 16384, stream);      // 80 KiB: two workgroups per CU
+}
+template <int FR>
+static void launch_pp_fr(const AttnArgsPP& a, int paged, bool split, dim3 grid, hipStream_t stream) {
+  launch_pp_any<2, FR>(a, paged, split, grid, pp::LDS_ALLOC, stream);
+}
+template <int NG>
+static void launch_pp_ng(const AttnArgsPP& a, int paged, bool split, dim3 grid, hipStream_t stream) {
+  launch_pp_any<NG, 0>(a, paged, split, grid, pp::LDS_ALLOC, stream);
+}
+// page geometries whose request pieces may straddle pages (page_size % 4 != 0, unaligned range starts, one-row pages ...): per-lane
+// translation on the plain two-group schedule
+static void launch_pp_generic(const AttnArgsPP& a, bool split, dim3 grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<2, false, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_ALLOC);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<2, true, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_ALLOC);
+    attr_set = true;
+  }
+  if (split) hipLaunchKernelGGL((attn_fwd_pp_kernel<2, true, 2, 0>), grid, dim3(512), pp::LDS_ALLOC, stream, a);
+  else hipLaunchKernelGGL((attn_fwd_pp_kernel<2, false, 2, 0>), grid, dim3(512), pp::LDS_ALLOC, stream, a);
 }
 
 // groups: 2 = ping-pong (256 query rows per workgroup), 3 = three-phase (384 rows), 4 = free-running (256 rows).
@@ -1275,7 +1288,15 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
                    hipStream_t stream, int slot_base = 0, int slot_cap = 0, int* slots_used = nullptr, int ldq = 0, int ldo = 0,
                    int n_ranges = 0, const int* q_ranges = nullptr, const int* k_ranges = nullptr) {
   using namespace pp;
-  const int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : (groups == 7 ? 5 : 0)));   // attn_variant 4 / 5 / 6 / 7
+  int fr_mode = groups == 4 ? 1 : (groups == 5 ? 2 : (groups == 6 ? 3 : (groups == 7 ? 5 : 0)));   // attn_variant 4 / 5 / 6 / 7
+  // page geometry: 0 contiguous; 1 a page table with pages of >= 3 rows (multiply-high page index exact) or a two-segment view — every
+  // schedule; 2 anything else — per-lane translation, the plain two-group schedule only
+  const unsigned ps_magic = (kv->page_table && kv->page_size >= 2 && (long long)kv->num_slots * kv->page_size < (1ll << 32))
+                                ? (unsigned)((1ull << 32) / (unsigned)kv->page_size) + 1u : 0u;
+  int paged = 0;
+  if (kv->page_table != nullptr) paged = (kv->page_size >= 3 && ps_magic != 0) ? 1 : 2;
+  else if (kv->seg_split > 0) paged = 1;
+  if (paged == 2) fr_mode = 0, groups = 2;
   if (fr_mode) groups = fr_mode == 3 ? 1 : 2;
   const int QT = 128 * groups;
   AttnArgsPP a;
@@ -1296,9 +1317,7 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
   a.q_per_kv = heads / kv->kv_heads;
   a.q_tiles = (q_rows + QT - 1) / QT;
   a.dbg_rescales = attn_debug_counter();
-  a.pt_lds_off = -1;                                 // the launchers of the one-per-CU schedules turn the LDS table on
-  a.n_pages = kv->page_table ? (kv->num_slots + kv->page_size - 1) / kv->page_size : 0;
-  a.ps_magic = (kv->page_table && kv->page_size >= 2 && (long long)kv->num_slots * kv->page_size < (1ll << 32)) ? (unsigned)((1ull << 32) / (unsigned)kv->page_size) + 1u : 0u;
+  a.ps_magic = ps_magic;
   a.n_ranges = 0;
   if (n_ranges > 0) {
     // longest key ranges first: tile ids are handed out in order, so the expensive tiles must not be the tail of the launch
@@ -1344,15 +1363,15 @@ int launch_attn_pp(const unsigned short* q, unsigned short* out, float* lse, con
     return IFX_EINVAL;
   }
   const bool pre = fabsf(a.scale_log2 - 1.0f) <= 2.5e-7f;   // q carries scale * log2(e) already (ifx_rope_grid.q_scale): scores are exponents
-  if (fr_mode == 3 && pre && PP_DUAL_FR == 6) launch_pp_dual<8>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (fr_mode == 3) launch_pp_dual<PP_DUAL_FR>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (fr_mode == 2) launch_pp_fr<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (fr_mode == 5 && pre)
-    launch_pp_fr<7>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (fr_mode == 5) launch_pp_fr<5>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (fr_mode == 1) launch_pp_fr<1>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else if (groups == 3) launch_pp_ng<3>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
-  else launch_pp_ng<2>(a, (kv->page_table != nullptr || kv->seg_split > 0), write_partials, grid, stream);
+  if (paged == 2) launch_pp_generic(a, write_partials, grid, stream);
+  else if (fr_mode == 3 && pre && PP_DUAL_FR == 6) launch_pp_dual<8>(a, paged, write_partials, grid, stream);
+  else if (fr_mode == 3) launch_pp_dual<PP_DUAL_FR>(a, paged, write_partials, grid, stream);
+  else if (fr_mode == 2) launch_pp_fr<2>(a, paged, write_partials, grid, stream);
+  else if (fr_mode == 5 && pre) launch_pp_fr<7>(a, paged, write_partials, grid, stream);
+  else if (fr_mode == 5) launch_pp_fr<5>(a, paged, write_partials, grid, stream);
+  else if (fr_mode == 1) launch_pp_fr<1>(a, paged, write_partials, grid, stream);
+  else if (groups == 3) launch_pp_ng<3>(a, paged, write_partials, grid, stream);
+  else launch_pp_ng<2>(a, paged, write_partials, grid, stream);
   if (slots_used) *slots_used = a.splits;
   if (!partial && a.splits > 1) {
     const int pairs = q_rows * heads;

@@ -190,6 +190,66 @@ def test_attention_paged(ops):
     _attn_case(ops, 130, 12, 1000, cap=1560, page=120)
 
 
+@pytest.mark.parametrize("variant", [7, 6, 2])
+def test_attention_page_geometries_on_the_pingpong_kernels(ops, variant):
+    """The wave-uniform page translation of the ping-pong kernels (PAGED = 1: one scalar table lookup per page, boundary pieces patched
+    per lane) against the SAME launch over a contiguous cache, bit for bit: page sizes that divide the 4-key request pieces (1560,
+    64), that make pieces straddle pages (130, 7, 3), a two-segment view with an odd split, ragged key ranges, key ranges that start
+    inside a page (partial launches), split launches — unused cache slots hold NaN.  One- and two-row pages take the per-lane form on
+    the plain two-group schedule (PAGED = 2): compared against exact attention at the usual bound."""
+    g = torch.Generator().manual_seed(77)
+    rows, heads, hd = 600, 12, 128
+    L = 4680 + 1560 + 37
+    q, k, v = rnd(g, rows, heads, hd), rnd(g, L, heads, hd), rnd(g, L, heads, hd)
+    qs, scale = ops.attn_q_prescale(hd)
+    qg = gpu((q.float() * qs).to(BF))
+    kg, vg = gpu(k), gpu(v)
+
+    def paged_view(ps):
+        npg = (L + ps - 1) // ps + 2
+        perm = torch.randperm(npg, generator=g)
+        kc = torch.full((npg * ps, heads, hd), float("nan"), dtype=BF)
+        vc = torch.full((npg * ps, heads, hd), float("nan"), dtype=BF)
+        t = torch.arange(L)
+        slot = perm[t // ps] * ps + t % ps
+        kc[slot], vc[slot] = k, v
+        return ops.KvCacheView(gpu(kc), gpu(vc), gpu(perm.to(torch.int32)), ps)
+
+    def segment_view(split, delta):
+        kc = torch.full((L + delta, heads, hd), float("nan"), dtype=BF)
+        vc = torch.full((L + delta, heads, hd), float("nan"), dtype=BF)
+        kc[:split], vc[:split] = k[:split], v[:split]
+        kc[split + delta:], vc[split + delta:] = k[split:], v[split:]
+        return ops.KvCacheView(gpu(kc), gpu(vc), None, 1, split, delta)
+
+    def run(view, kv_len, kv_start, splits):
+        if kv_start == 0:
+            return ops.attention(qg, view, kv_len, scale=scale, splits=splits)
+        s = splits or 2
+        ws = ops.attention_workspace(qg, s)
+        u = ops.attention_partial(qg, view, kv_len, kv_start, s, ws, 0, s, scale=scale)
+        out = torch.empty_like(qg)
+        ops.attention_merge(ws, s, u, out)
+        return out
+
+    cases = [(L, 0, 1), (L, 0, 3), (4680 + 1560, 0, 1), (L, 4680, 2), (L - 5, 1563, 2)]
+    with ops.option_scope("attn_variant", variant):
+        plain = ops.KvCacheView(kg, vg)
+        refs = [run(plain, *c).clone() for c in cases]
+        views = [("page 1560", paged_view(1560)), ("page 64", paged_view(64)), ("page 130", paged_view(130)), ("page 7", paged_view(7)),
+                 ("page 3", paged_view(3)), ("segments 4681 + 11", segment_view(4681, 11)), ("segments 6000 + 4", segment_view(6000, 4))]
+        for name, view in views:
+            for c, ref in zip(cases, refs):
+                out = run(view, *c)
+                assert torch.equal(out, ref), (name, c, float((out.float() - ref.float()).abs().max()))
+        ref64 = O.attention((qg[:64].cpu().double() * (scale * math.sqrt(hd)))[None], k[None], v[None], impl="math")[0]
+        for ps in (1, 2):
+            out = run(paged_view(ps), L, 0, 1)
+            assert torch.isfinite(out.float()).all()
+            assert rel_l2(out.cpu(), refs[0].cpu()) < 5e-3, ps
+            assert (out[:64].cpu().double() - ref64).abs().max().item() < 1.5e-2, ps
+
+
 @pytest.mark.parametrize("rows,heads,kv_len,splits,page", [
     (72, 2, 1000, 2, None), (129, 2, 1025, 3, None), (300, 12, 2048, 7, None), (40, 2, 130, 5, None),
     (130, 12, 1000, 4, 120), (72, 2, 200, 2, 24), (585, 12, 4680, None, None)])

@@ -30,7 +30,7 @@ for line in open(md):
     m = re.match(r"\| `void ifx::(\w+<[^>]*>).*` \| (\w+) \| (\d+) \| ([0-9.e+]+) \|", line)
     if m:
         rows.setdefault(m.group(1), {})[m.group(2)] = (int(m.group(3)), float(m.group(4)))
-attn = [k for k in rows if k.startswith("attn_fwd_pp_kernel<false, false, 2,")]
+attn = [k for k in rows if re.match(r"attn_fwd_pp_kernel<(0|false), false, 2,", k)]
 if len(attn) != 1 or not {"FETCH_SIZE", "WRITE_SIZE"} <= set(rows[attn[0]]):
     raise SystemExit(f"attention rows not found in {md}: {sorted(rows)}")
 a = rows[attn[0]]
