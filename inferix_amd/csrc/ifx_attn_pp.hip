@@ -304,26 +304,39 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       // the mask) by a lane-row clamp, and a piece that straddles a page boundary adds the next page's offset to its upper lanes:
       // both in one scalar branch that only boundary pieces take.
       const int wv_rows = wv * 4 * row_bytes;
+      const int key00 = __builtin_amdgcn_readfirstlane(kv_s + t * KT + wv * 4);
+      if (key00 >= pc_lo && key00 + 35 < pc_hi && key00 + 35 <= last_key) {
+        // both pieces of the wave (keys key00 .. +3 and key00 + 32 .. +35) inside the remembered page and the key range: the
+        // contiguous kernel's requests with another scalar offset (the loop is bound by instruction issue: every scalar
+        // instruction per request shows)
+        const int soff = (key00 + pc_off) * row_bytes;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int key0 = __builtin_amdgcn_readfirstlane(kv_s + t * KT + wv * 4 + 32 * r);
-        const int kk = min(key0, last_key);
-        if (kk < pc_lo || kk >= pc_hi) pp_page_range(A.ka, A.ps_magic, kk, pc_lo, pc_hi, pc_off);
-        int soff = (kk + pc_off) * row_bytes;
-        int adj = wv_rows;
-        if (kk + 3 > last_key || kk + 3 >= pc_hi) {        // rare: the ragged last piece of the key range, or a piece that runs into the next page
-          const int j = min(ln >> 4, last_key - kk);
-          adj += ((ln >> 4) - j) * row_bytes;
-          if (kk + min(3, last_key - kk) >= pc_hi) {      // its rows from pc_hi on live in the NEXT page (a piece spans at most two: page_size >= 3)
-            int lo2, hi2, off2;
-            pp_page_range(A.ka, A.ps_magic, pc_hi, lo2, hi2, off2);
-            // whole physical row per lane (the next page may lie anywhere, and a lane offset cannot go negative); scalar offset 0
-            adj -= (kk + ((kk + j >= pc_hi) ? off2 : pc_off)) * row_bytes;
-            soff = 0;
-          }
+        for (int r = 0; r < 2; ++r) {
+          if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff - wv_rows, soff + r * 32 * row_bytes);
+          if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff - wv_rows, soff + r * 32 * row_bytes);
         }
-        if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff - adj, soff);
-        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff - adj, soff);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int key0 = key00 + 32 * r;
+          const int kk = min(key0, last_key);
+          if (kk < pc_lo || kk >= pc_hi) pp_page_range(A.ka, A.ps_magic, kk, pc_lo, pc_hi, pc_off);
+          int soff = (kk + pc_off) * row_bytes;
+          int adj = wv_rows;
+          if (kk + 3 > last_key || kk + 3 >= pc_hi) {        // rare: the ragged last piece of the key range, or a piece that runs into the next page
+            const int j = min(ln >> 4, last_key - kk);
+            adj += ((ln >> 4) - j) * row_bytes;
+            if (kk + min(3, last_key - kk) >= pc_hi) {      // its rows from pc_hi on live in the NEXT page (a piece spans at most two: page_size >= 3)
+              int lo2, hi2, off2;
+              pp_page_range(A.ka, A.ps_magic, pc_hi, lo2, hi2, off2);
+              // whole physical row per lane (the next page may lie anywhere, and a lane offset cannot go negative); scalar offset 0
+              adj -= (kk + ((kk + j >= pc_hi) ? off2 : pc_off)) * row_bytes;
+              soff = 0;
+            }
+          }
+          if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff - adj, soff);
+          if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff - adj, soff);
+        }
       }
     } else {
 #pragma unroll
