@@ -5,8 +5,9 @@
 
 One "step" = one full pass of the hot path over one batch of synthetic input: a 21-latent-frame clip
 (1 x 21 x 16 x 60 x 104), block_size 3 -> 7 blocks x (4 denoise steps + 1 clean-context re-run) = 35
-generator forwards of the 30-layer Wan2.1-1.3B causal DiT with a growing paged KV prefix
-(4680 ... 32760 keys).  Text encoder and VAE are outside the path (prompt embeddings are synthetic,
+generator forwards of the 30-layer Wan2.1-1.3B causal DiT with a growing KV prefix (4680 ... 32760 keys) in the
+KV manager's per-request cache (an `ifx_kv_view` with the identity page map; the page-table form of the same
+cache is timed in the `streaming_steady` leg: within 2 % of it).  Text encoder and VAE are outside the path (prompt embeddings are synthetic,
 decode_mode = NO_DECODE; the per-block callback receives latents).  Inputs/weights are resident in HBM
 before the timed region.
 
@@ -998,8 +999,8 @@ def main():
             "dtype": "bf16" if a.quant == "none" else f"{a.quant} linears (per-token x per-channel) + bf16 attention",
             "data": "synthetic",
             "config": {"workload": "Self-Forcing 480p bf16 (Wan2.1-T2V-1.3B causal DiT, 30 layers), block_size=3, "
-                                   "21 latent frames = 7 blocks x (4 denoise + 1 context) generator forwards, paged KV "
-                                   "prefix 4680..32760 keys; `value` counts the generator calls (SURVEY 8d), the per-block VAE decode of config 2 "
+                                   "21 latent frames = 7 blocks x (4 denoise + 1 context) generator forwards, KV "
+                                   "prefix 4680..32760 keys in the KV manager's cache (identity page map; page-table form: `streaming_steady`); `value` counts the generator calls (SURVEY 8d), the per-block VAE decode of config 2 "
                                    "is measured beside it (`per_block_decode`, `vae_decode`), the text encoder in `text_encoder`",
                        "batch": 1, "latent": [FRAMES, *LATENT], "denoising_step_list": STEPS_LIST,
                        "timestep_shift": 5.0, "parallelism": f"sp{world}" if world > 1 else "single",
@@ -1013,7 +1014,7 @@ def main():
                                                 "between block callbacks; with the pairs on a block's re-run overlaps the next block's first step, so "
                                                 "`ms_per_denoise_step` x 28 + re-runs (measured with the pairs off) does not add up to `ms_per_step`, this does"},
             "generator_forwards_timed": forwards,
-            "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (block-causal paged flash attention, self-attention launches)", "bound": "mfma",
+            "roofline": {"kernel": "ifx::attn_fwd_pp_kernel (block-causal flash attention over the KV manager's view, `ifx_attn_fwd_paged`; self-attention launches)", "bound": "mfma",
                          "achieved": round(attn_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(attn_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / max(ks["launches"], 1), 4),
