@@ -244,10 +244,13 @@ def test_attention_page_geometries_on_the_pingpong_kernels(ops, variant):
                 assert torch.equal(out, ref), (name, c, float((out.float() - ref.float()).abs().max()))
         ref64 = O.attention((qg[:64].cpu().double() * (scale * math.sqrt(hd)))[None], k[None], v[None], impl="math")[0]
         for ps in (1, 2):
-            out = run(paged_view(ps), L, 0, 1)
-            assert torch.isfinite(out.float()).all()
-            assert rel_l2(out.cpu(), refs[0].cpu()) < 5e-3, ps
-            assert (out[:64].cpu().double() - ref64).abs().max().item() < 1.5e-2, ps
+            view = paged_view(ps)
+            for c, ref in zip(cases, refs):
+                out = run(view, *c)
+                assert torch.isfinite(out.float()).all()
+                assert rel_l2(out.cpu(), ref.cpu()) < 5e-3, (ps, c)
+                if c == cases[0]:
+                    assert (out[:64].cpu().double() - ref64).abs().max().item() < 1.5e-2, ps
 
 
 @pytest.mark.parametrize("rows,heads,kv_len,splits,page", [
