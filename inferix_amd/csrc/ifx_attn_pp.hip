@@ -279,21 +279,35 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
   const unsigned lds00 = (unsigned)(unsigned long long)(pp_lds_ptr_t)smem;
   const int last_key = kv_e - 1;
   int pc_lo = 0, pc_hi = 0, pc_off = 0;              // PAGED = 1: key range and (physical - logical) row offset of the page of the last request
+  // The two lane offsets of a request (K and V rows of this wave's pieces: row * row_bytes + swizzled 16-byte chunk) in ONE register kept
+  // across the loop: row_bytes is a multiple of 256, so bits 0-7 hold the K chunk, bits 8-27 the row term and bits 28-31 the V chunk index.
+  // A call unpacks its offset with one (K) or three (V) VALU instructions instead of re-deriving it from the lane id with seven or eight —
+  // the older wave of every SIMD issues eight requests per tile and the loop is bound by instruction issue.  Pieces of wave `wv` != wave
+  // (wave + 4: sixteen rows on) have the same swizzle phase: the same lane offsets.
+  int lane_pack;
+  {
+    const int ln0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int pc0 = ln0 & 15, row0 = wave * 4 + (ln0 >> 4);          // the row term holds the lane's row INSIDE the piece (0 .. 3) only:
+    lane_pack = (ln0 >> 4) * row_bytes + ((pc0 ^ (row0 & 15)) << 4) +   // the piece's first row is the scalar side's business
+                (int)((unsigned)((((pc0 >> 2) ^ (row0 & 3)) << 2) | (pc0 & 3)) << 28);
+  }
   auto issue_w = [&](int t, int wv, int what = 3) {  // the pieces that belong to wave `wv` (rows 4 wv .. 4 wv + 3 of each half); what: 1 K, 2 V
     const unsigned lds0 = lds00 + wv * 1024;
     int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(ln));                    // recomputed, not kept live (see stepM)
-    const int d_pc = ln & 15, d_row0 = wv * 4 + (ln >> 4);
-    const int k_voff = d_row0 * row_bytes + ((d_pc ^ (d_row0 & 15)) << 4);
-    const int v_voff = d_row0 * row_bytes + (((((d_pc >> 2) ^ (d_row0 & 3)) << 2) | (d_pc & 3)) << 4);
+    asm volatile("" : "+v"(ln));                    // recomputed, not kept live (see stepM); only the boundary / per-lane paths below use it
+    int lp = lane_pack;
+    asm volatile("" : "+v"(lp));                    // (unpacked at every call: two derived registers kept live would spill)
+    const int k_lane = lp & 0x0fffffff;
+    const int v_lane = (lp & 0x0fffff00) | (int)(((unsigned)lp >> 28) << 4);
+    const int wv_rows = wv * 4 * row_bytes;         // scalar: first row of the piece inside the tile
     const unsigned kb = lds0 + K_OFF + (t % RK) * 16384;
     const unsigned vb = lds0 + V_OFF + (t % RV) * 16384;
     if (!PAGED) {
-      const int soff = (kv_s + t * KT) * row_bytes;
+      const int soff = (kv_s + t * KT) * row_bytes + wv_rows;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff, soff + r * 32 * row_bytes);
-        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff, soff + r * 32 * row_bytes);
+        if (what & 1) pp_dma16(krs, kb + r * 8192, k_lane, soff + r * 32 * row_bytes);
+        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_lane, soff + r * 32 * row_bytes);
       }
     } else if constexpr (PAGED == 1) {
       // A piece is four CONSECUTIVE keys, nearly always inside ONE page: the translation is wave-uniform.  The physical row of
@@ -303,7 +317,6 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       // instructions per request.  Keys behind the last one read the last key's row (as the per-lane form did: finite values under
       // the mask) by a lane-row clamp, and a piece that straddles a page boundary adds the next page's offset to its upper lanes:
       // both in one scalar branch that only boundary pieces take.
-      const int wv_rows = wv * 4 * row_bytes;
       const int key00 = __builtin_amdgcn_readfirstlane(kv_s + t * KT + wv * 4);
       if (key00 >= pc_lo && key00 + 35 < pc_hi && key00 + 35 <= last_key) {
         // both pieces of the wave (keys key00 .. +3 and key00 + 32 .. +35) inside the remembered page and the key range: the
@@ -312,8 +325,8 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
         const int soff = (key00 + pc_off) * row_bytes;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff - wv_rows, soff + r * 32 * row_bytes);
-          if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff - wv_rows, soff + r * 32 * row_bytes);
+          if (what & 1) pp_dma16(krs, kb + r * 8192, k_lane, soff + r * 32 * row_bytes);
+          if (what & 2) pp_dma16(vrs, vb + r * 8192, v_lane, soff + r * 32 * row_bytes);
         }
       } else {
 #pragma unroll
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
           const int kk = min(key0, last_key);
           if (kk < pc_lo || kk >= pc_hi) pp_page_range(A.ka, A.ps_magic, kk, pc_lo, pc_hi, pc_off);
           int soff = (kk + pc_off) * row_bytes;
-          int adj = wv_rows;
+          int adj = 0;
           if (kk + 3 > last_key || kk + 3 >= pc_hi) {        // rare: the ragged last piece of the key range, or a piece that runs into the next page
             const int j = min(ln >> 4, last_key - kk);
             adj += ((ln >> 4) - j) * row_bytes;
@@ -334,17 +347,17 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
               soff = 0;
             }
           }
-          if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff - adj, soff);
-          if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff - adj, soff);
+          if (what & 1) pp_dma16(krs, kb + r * 8192, k_lane - adj, soff);
+          if (what & 2) pp_dma16(vrs, vb + r * 8192, v_lane - adj, soff);
         }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int key = min(kv_s + t * KT + d_row0 + 32 * r, last_key);
-        const int delta = (A.ka.slot(key) - d_row0) * row_bytes;        // physical row instead of tile row
-        if (what & 1) pp_dma16(krs, kb + r * 8192, k_voff + delta, 0);
-        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_voff + delta, 0);
+        const int key = min(kv_s + t * KT + wv * 4 + (ln >> 4) + 32 * r, last_key);
+        const int delta = (A.ka.slot(key) - (ln >> 4)) * row_bytes;     // physical row instead of the row inside the piece
+        if (what & 1) pp_dma16(krs, kb + r * 8192, k_lane + delta, 0);
+        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_lane + delta, 0);
       }
     }
   };
