@@ -292,22 +292,30 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
                 (int)((unsigned)((((pc0 >> 2) ^ (row0 & 3)) << 2) | (pc0 & 3)) << 28);
   }
   auto issue_w = [&](int t, int wv, int what = 3) {  // the pieces that belong to wave `wv` (rows 4 wv .. 4 wv + 3 of each half); what: 1 K, 2 V
-    const unsigned lds0 = lds00 + wv * 1024;
-    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(ln));                    // recomputed, not kept live (see stepM); only the boundary / per-lane paths below use it
+    // (opaque: hipcc otherwise precomputes every (ring slot, half, wave) destination address of the unrolled loop — 32 loop-invariant
+    //  scalars, spilled to lanes and fetched with a v_readlane in front of each request; one s_add per request is cheaper in a loop
+    //  that is bound by VALU issue)
+    unsigned lds0 = lds00 + wv * 1024;
+    asm volatile("" : "+s"(lds0));
+    int ln = 0;                                     // lane id: only the boundary / per-lane paths of the paged forms use it
+    if constexpr (PAGED != 0) {
+      ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(ln));                  // recomputed, not kept live (see stepM)
+    }
     int lp = lane_pack;
     asm volatile("" : "+v"(lp));                    // (unpacked at every call: two derived registers kept live would spill)
     const int k_lane = lp & 0x0fffffff;
     const int v_lane = (lp & 0x0fffff00) | (int)(((unsigned)lp >> 28) << 4);
-    const int wv_rows = wv * 4 * row_bytes;         // scalar: first row of the piece inside the tile
     const unsigned kb = lds0 + K_OFF + (t % RK) * 16384;
     const unsigned vb = lds0 + V_OFF + (t % RV) * 16384;
     if (!PAGED) {
-      const int soff = (kv_s + t * KT) * row_bytes + wv_rows;
+      int rb = row_bytes;
+      asm volatile("" : "+s"(rb));                  // (opaque for the same reason: one s_mul per request instead of 16 spilled row offsets)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (what & 1) pp_dma16(krs, kb + r * 8192, k_lane, soff + r * 32 * row_bytes);
-        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_lane, soff + r * 32 * row_bytes);
+        const int soff = (kv_s + t * KT + wv * 4 + 32 * r) * rb;     // first row of the piece
+        if (what & 1) pp_dma16(krs, kb + r * 8192, k_lane, soff);
+        if (what & 2) pp_dma16(vrs, vb + r * 8192, v_lane, soff);
       }
     } else if constexpr (PAGED == 1) {
       // A piece is four CONSECUTIVE keys, nearly always inside ONE page: the translation is wave-uniform.  The physical row of
@@ -619,7 +627,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void attn_fwd_pp_kernel(
       }
     };
     auto mask_ragged = [&](int t, f32x16(&sx)[2]) {
-      const int kidx = t * KT + 4 * hi;
+      // (opaque on purpose: the 32 comparisons below are loop-invariant lane masks — hipcc hoisted them out of the tile loop and kept
+      //  64 scalar registers alive for a branch that one tile per work item takes; the scalars the loop does use — LDS slot addresses,
+      //  row offsets of the K / V requests — were spilled to lanes and read back with v_readlane in front of every request)
+      int kidx = t * KT + 4 * hi;
+      asm volatile("" : "+v"(kidx));
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
