@@ -748,11 +748,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
     const v4i w_rs = make_rsrc(A.w, (unsigned)((long long)A.KT * 9 * CC * A.Cout * 64));
     int w_it = 0, w_dt = 0, w_cc = 0, w_r = 0, w_g = 0;
     int w_nb = c_t.n_base;
+    // byte offset of the cursor's step (tap 0 of its kernel row, channel row 0 of the tile) in the packed weights, refreshed ONCE per step;
+    // a piece adds its tap and row-block terms.  (The five multiplications per piece this replaces sat in front of every request of the
+    // loader phase, whose length bounds the kernel: -1.5 ... -3 % per launch at 192 / 384 channels.  Hoisting the patch requests' slot and
+    // chunk terms the same way bought nothing: what it saves in scalar instructions it costs in scalar registers spilled to lanes.)
+    const int w_tap_stride = CC * A.Cout * 64;
+    int w_step_base = w_nb * 64;
     auto w_piece = [&](int q) __attribute__((always_inline)) {       // piece slot q of the cursor's step
       const int idx = w4 + 4 * q;
       if (w_it >= n_my || idx >= G::WPS) return;
       const int tg = idx / G::WP, pr = idx - tg * G::WP;
-      const int base = ((w_dt * 9 + w_r * 3 + tg) * CC + w_cc) * (A.Cout * 64) + w_nb * 64 + pr * 1024;
+      const int base = w_step_base + tg * w_tap_stride + pr * 1024;
       dma16(w_rs, lds0 + G::W_OFF + (w_g & 1) * G::W_STEP + tg * G::W_TAP + pr * 1024, lane_w, base);
     };
     auto w_next = [&]() __attribute__((always_inline)) {
@@ -767,6 +773,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvArgs A) {
           }
         }
       }
+      w_step_base = ((w_dt * 9 + w_r * 3) * CC + w_cc) * (A.Cout * 64) + w_nb * 64;
     };
     auto w_all = [&]() __attribute__((always_inline)) {
 #pragma unroll
