@@ -37,6 +37,10 @@
 #ifndef IFX_PP_TRACE
 #define IFX_PP_TRACE 0      // 1: s_memtime segment sums of workgroup 0 (tools/gemm_lab.cpp -t reads them back)
 #endif
+#ifndef IFX_PP_LAB
+#define IFX_PP_LAB IFX_PP_TRACE   // 1: the IFX_PP_DEBUG lab switches (bits 1 / 2 / 4 / 8 / 16) are live; 0: they are compile-time zeros — their run-time
+#endif                            // tests (a K rotation select per request block, a flag test per phase) sat in front of every LDS-DMA request block
+
 
 namespace ifx {
 
@@ -93,6 +97,8 @@ __device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F);
 // one request cursor: K-step kt of tile i (the g-th K-step of this workgroup's stream), descriptor of that tile's operand rows
 struct Cursor {
   int i, kt, g, rot, k0, len;     // k0 / len: first K-step and number of K-steps of the item inside the tile's K range (split-K, stream-K)
+  int kb;                         // byte offset of the cursor's K-step in an operand row, (k0 + kt) * 128: advanced, not recomputed per request block
+  unsigned stg;                   // LDS byte offset of the cursor's stage, (g & 1) * STAGE: toggled
   v4i rs;
 };
 }  // namespace gpp
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
                                                          float* __restrict__ ws_part, unsigned* __restrict__ ws_flag,
                                                          unsigned* __restrict__ err_word, long long spin_ticks) {
   using namespace gpp;
+  dbg = IFX_PP_LAB ? dbg : (dbg & 32);   // (bit 32 = the split-K fault injection of the tests, outside the K loop)
   constexpr int BM = 64 * TJ;               // tokens per tile: two groups x TJ blocks of 32
   constexpr int GM = 4;                     // row tiles per rasterisation group (see ifx_gemm_glds.hip)
   constexpr bool RES = EPI == IFX_EPI_RESIDUAL || EPI == IFX_EPI_GATE_RES;
@@ -194,15 +201,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
     c.rot = (!SK && (dbg & 4)) ? ((nb / BN) * 3) % KT : 0;    // lab: K rotation by column tile
     c.k0 = item_k0(c.i);
     c.len = item_len(c.i);
+    c.kb = c.k0 * 128;
     if (grp == 0) c.rs = make_rsrc(wb + (size_t)nb * K * ES, (unsigned)min(((long)N - nb) * (long)K * ES, 0xffffffffL));
     else c.rs = make_rsrc(xb + (size_t)mb * ldx * ES, (unsigned)min(((long)M - mb - 1) * (long)ldx * ES + (long)K * ES, 0xffffffffL));
   };
   auto cur_init = [&](Cursor& c) __attribute__((always_inline)) {
-    c.i = 0, c.kt = 0, c.g = 0;
+    c.i = 0, c.kt = 0, c.g = 0, c.stg = 0;
     cur_desc(c);
   };
   auto cur_next = [&](Cursor& c) __attribute__((always_inline)) {
     ++c.g;
+    c.stg ^= STAGE;
+    c.kb += 128;
     if (++c.kt == c.len) {
       c.kt = 0;
       if (++c.i < n_my) cur_desc(c);
@@ -210,9 +220,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const unsigned short* _
   };
   // `pieces` 1 KiB pieces of the cursor's K-step: rows row0 + (q * 4 + w4) * 8 ... of the tile's operand -> slot `slot` of its stage
   auto issue = [&](const Cursor& c, int slot, int row0, int pieces) __attribute__((always_inline)) {
+    // (every scalar instruction in front of a request block lengthens the loader phase: the K-step offset and the stage are running
+    //  values of the cursor; the lab rotation keeps the recomputed form)
     const int kk = c.kt + c.rot;
-    const int kb = ((!SK && kk >= KT ? kk - KT : kk) + c.k0) * 128;
-    const unsigned p = lds_piece0 + (c.g & 1) * STAGE + slot;
+    const int kb = IFX_PP_LAB ? ((!SK && kk >= KT ? kk - KT : kk) + c.k0) * 128 : c.kb;
+    const unsigned p = lds_piece0 + c.stg + slot;
     if ((dbg & 8) && c.g >= 2) return;               // lab: no DMA after the first two K-steps (what would a loader phase of reads alone cost?)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
